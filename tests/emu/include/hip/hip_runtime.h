@@ -1,0 +1,278 @@
+// TEST INFRASTRUCTURE ONLY -- SIMT emulator shim.
+//
+// This header shadows <hip/hip_runtime.h> when the kernel sources under
+// geomapnet_amd/csrc are compiled for the x86 host by tests/emu/Makefile.  It lets the
+// CPU-only test-suite execute the *same kernel source* (LDS tiling, swizzles, MFMA fragment
+// maps, wave reductions, barriers) that hipcc compiles for gfx950, so kernel logic is
+// debugged before any GPU minute is spent.  Every GPU thread is a fiber; __syncthreads and
+// the wave-collective intrinsics are cooperative barriers; MFMA builtins are evaluated
+// from the documented gfx950 lane->element maps.
+//
+// The product (geomapnet_amd) never loads the emulator build: geomapnet_amd/_binding.py
+// only ever dlopens libmapnet_hip.so and raises if it is missing.
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <utility>
+
+#define MAPNET_EMU_BUILD 1
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+struct uint3 {
+  unsigned x, y, z;
+};
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef void* hipStream_t;
+typedef struct emu_event* hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorUnknown = 999 };
+enum hipMemcpyKind {
+  hipMemcpyHostToHost = 0,
+  hipMemcpyHostToDevice = 1,
+  hipMemcpyDeviceToHost = 2,
+  hipMemcpyDeviceToDevice = 3,
+  hipMemcpyDefault = 4
+};
+
+namespace emu {
+struct Ctx {
+  uint3 tid, bid;
+  dim3 bdim, gdim;
+  int lane, wave, linear;
+};
+extern thread_local Ctx* cur;
+void block_sync();
+void wave_sync();
+// per-wave exchange buffer: 64 slots of 256 bytes
+unsigned char* wave_slot(int lane);
+int wave_live_lanes();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+}  // namespace emu
+
+#define threadIdx (emu::cur->tid)
+#define blockIdx (emu::cur->bid)
+#define blockDim (emu::cur->bdim)
+#define gridDim (emu::cur->gdim)
+#define warpSize 64
+
+inline void __syncthreads() { emu::block_sync(); }
+inline void __threadfence() {}
+
+// ---- host API subset ------------------------------------------------------------------
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emu error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t = nullptr) {
+  memset(p, v, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
+  memcpy(d, s, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+  memcpy(d, s, n);
+  return hipSuccess;
+}
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+
+template <typename... KArgs, typename... Args>
+inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t /*shmem*/,
+                               hipStream_t /*stream*/, Args... args) {
+  emu::launch(grid, block, [=]() { kernel(args...); });
+}
+
+// ---- atomics (blocks run on several OS threads) ----------------------------------------
+template <typename T>
+inline T emu_atomic_add(T* p, T v) {
+  T old, neu;
+  do {
+    __atomic_load(p, &old, __ATOMIC_RELAXED);
+    neu = old + v;
+  } while (!__atomic_compare_exchange(p, &old, &neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return old;
+}
+inline float atomicAdd(float* p, float v) { return emu_atomic_add(p, v); }
+inline double atomicAdd(double* p, double v) { return emu_atomic_add(p, v); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline float unsafeAtomicAdd(float* p, float v) { return emu_atomic_add(p, v); }
+inline double unsafeAtomicAdd(double* p, double v) { return emu_atomic_add(p, v); }
+
+// ---- wave collectives ---------------------------------------------------------------------
+template <typename T>
+inline T emu_wave_exchange(T v, int src_lane) {
+  static_assert(sizeof(T) <= 256, "slot too small");
+  memcpy(emu::wave_slot(emu::cur->lane), &v, sizeof(T));
+  emu::wave_sync();
+  T r;
+  memcpy(&r, emu::wave_slot(src_lane & 63), sizeof(T));
+  emu::wave_sync();
+  return r;
+}
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+  int l = emu::cur->lane;
+  int base = l & ~(width - 1);
+  return emu_wave_exchange(v, base + (src & (width - 1)));
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  int l = emu::cur->lane;
+  int t = l ^ mask;
+  if ((t & ~(width - 1)) != (l & ~(width - 1))) t = l;
+  return emu_wave_exchange(v, t);
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned d, int width = 64) {
+  int l = emu::cur->lane;
+  int t = l + (int)d;
+  if ((t & ~(width - 1)) != (l & ~(width - 1))) t = l;
+  return emu_wave_exchange(v, t);
+}
+inline unsigned long long __ballot(int pred) {
+  int p = pred ? 1 : 0;
+  memcpy(emu::wave_slot(emu::cur->lane), &p, sizeof(int));
+  emu::wave_sync();
+  unsigned long long m = 0;
+  int n = emu::wave_live_lanes();
+  for (int i = 0; i < n; ++i) {
+    int q;
+    memcpy(&q, emu::wave_slot(i), sizeof(int));
+    if (q) m |= 1ull << i;
+  }
+  emu::wave_sync();
+  return m;
+}
+
+// ---- math helpers that exist in HIP device code -------------------------------------------
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __expf(float x) { return expf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+
+// ---- MFMA builtins, from the gfx950 lane->element maps (cdna_hip_programming.md section 3) ----
+typedef _Float16 emu_half8 __attribute__((ext_vector_type(8)));
+typedef float emu_floatx4 __attribute__((ext_vector_type(4)));
+typedef float emu_floatx16 __attribute__((ext_vector_type(16)));
+
+struct emu_mfma_slot_h {
+  emu_half8 a, b;
+};
+struct emu_mfma_slot_f {
+  float a, b;
+};
+
+// v_mfma_f32_32x32x16_f16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31],
+// D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5)
+inline emu_floatx16 __builtin_amdgcn_mfma_f32_32x32x16_f16(emu_half8 a, emu_half8 b, emu_floatx16 c, int, int,
+                                                           int) {
+  int l = emu::cur->lane;
+  emu_mfma_slot_h s{a, b};
+  memcpy(emu::wave_slot(l), &s, sizeof(s));
+  emu::wave_sync();
+  int j = l & 31;
+  for (int reg = 0; reg < 16; ++reg) {
+    int i = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
+    float acc = c[reg];
+    for (int k = 0; k < 16; ++k) {
+      emu_mfma_slot_h sa, sb;
+      memcpy(&sa, emu::wave_slot(i + 32 * (k >> 3)), sizeof(sa));
+      memcpy(&sb, emu::wave_slot(j + 32 * (k >> 3)), sizeof(sb));
+      acc += (float)sa.a[k & 7] * (float)sb.b[k & 7];
+    }
+    c[reg] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
+// v_mfma_f32_16x16x32_f16: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15],
+// D: col=l&15, row=4*(l>>4)+reg
+inline emu_floatx4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu_half8 a, emu_half8 b, emu_floatx4 c, int, int, int) {
+  int l = emu::cur->lane;
+  emu_mfma_slot_h s{a, b};
+  memcpy(emu::wave_slot(l), &s, sizeof(s));
+  emu::wave_sync();
+  int j = l & 15;
+  for (int reg = 0; reg < 4; ++reg) {
+    int i = 4 * (l >> 4) + reg;
+    float acc = c[reg];
+    for (int k = 0; k < 32; ++k) {
+      emu_mfma_slot_h sa, sb;
+      memcpy(&sa, emu::wave_slot(i + 16 * (k >> 3)), sizeof(sa));
+      memcpy(&sb, emu::wave_slot(j + 16 * (k >> 3)), sizeof(sb));
+      acc += (float)sa.a[k & 7] * (float)sb.b[k & 7];
+    }
+    c[reg] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; exact k-ordered fmaf chain.
+inline emu_floatx16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_floatx16 c, int, int, int) {
+  int l = emu::cur->lane;
+  emu_mfma_slot_f s{a, b};
+  memcpy(emu::wave_slot(l), &s, sizeof(s));
+  emu::wave_sync();
+  int j = l & 31;
+  for (int reg = 0; reg < 16; ++reg) {
+    int i = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
+    float acc = c[reg];
+    for (int k = 0; k < 2; ++k) {
+      emu_mfma_slot_f sa, sb;
+      memcpy(&sa, emu::wave_slot(i + 32 * k), sizeof(sa));
+      memcpy(&sb, emu::wave_slot(j + 32 * k), sizeof(sb));
+      acc = fmaf(sa.a, sb.b, acc);
+    }
+    c[reg] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]
+inline emu_floatx4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_floatx4 c, int, int, int) {
+  int l = emu::cur->lane;
+  emu_mfma_slot_f s{a, b};
+  memcpy(emu::wave_slot(l), &s, sizeof(s));
+  emu::wave_sync();
+  int j = l & 15;
+  for (int reg = 0; reg < 4; ++reg) {
+    int i = 4 * (l >> 4) + reg;
+    float acc = c[reg];
+    for (int k = 0; k < 4; ++k) {
+      emu_mfma_slot_f sa, sb;
+      memcpy(&sa, emu::wave_slot(i + 16 * k), sizeof(sa));
+      memcpy(&sb, emu::wave_slot(j + 16 * k), sizeof(sb));
+      acc = fmaf(sa.a, sb.b, acc);
+    }
+    c[reg] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}

@@ -1,0 +1,83 @@
+"""Loads the reference's own Python modules from /root/reference (TEST INFRASTRUCTURE).
+
+Only usable where the reference tree is mounted (this build container); the GPU box has no
+/root/reference, so nothing that runs there may call this.  Used by
+tests/test_oracle_pinned_to_reference.py and tests/golden/make_golden.py to pin the oracle
+restatement to the reference implementation itself.
+
+What is executed unmodified:
+  * models/posenet.py              (PoseNet, MapNet, filter_hook)
+  * common/criterion.py            (PoseNetCriterion, MapNetCriterion, MapNetOnlineCriterion)
+  * common/pose_utils.py:1-304     (torch section) -- the file as a whole is Python-2 only
+    (print statements from :800) and imports transforms3d (:13-14, not installed), so the
+    torch section is exec'd with `xrange = range` and those two import lines dropped.
+`MapNetOnlineCriterion.forward` divides with `/` at :150 (Python-2 integer division); a
+subclass re-evaluates the same source with `//`.
+"""
+import importlib
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("GEOMAPNET_REFERENCE", "/root/reference")
+
+
+def available():
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "common", "pose_utils.py"))
+
+
+_cache = {}
+
+
+def load():
+    """-> namespace with .pose_utils, .criterion, .posenet (reference modules)."""
+    if "ns" in _cache:
+        return _cache["ns"]
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    with open(os.path.join(REFERENCE_ROOT, "common", "pose_utils.py")) as f:
+        lines = f.read().split("\n")[:304]
+    src = "\n".join(l for l in lines if "transforms3d" not in l)
+    pose_utils = types.ModuleType("common.pose_utils")
+    pose_utils.__dict__["xrange"] = range
+    exec(compile(src, "reference:common/pose_utils.py[1:304]", "exec"), pose_utils.__dict__)
+
+    saved = {k: sys.modules.get(k) for k in ("common", "common.pose_utils", "common.criterion")}
+    pkg = types.ModuleType("common")
+    pkg.__path__ = [os.path.join(REFERENCE_ROOT, "common")]
+    pkg.pose_utils = pose_utils
+    sys.modules["common"] = pkg
+    sys.modules["common.pose_utils"] = pose_utils
+    try:
+        criterion = importlib.import_module("common.criterion")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    env_zoo, path0 = os.environ.get("TORCH_MODEL_ZOO"), list(sys.path)
+    spec = importlib.util.spec_from_file_location("reference_models_posenet",
+                                                  os.path.join(REFERENCE_ROOT, "models", "posenet.py"))
+    posenet = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(posenet)
+    sys.path[:] = path0  # undo the module's sys.path.insert(0, '../') (:18-19)
+    if env_zoo is None:
+        os.environ.pop("TORCH_MODEL_ZOO", None)
+
+    # Python-3 rendition of MapNetOnlineCriterion.forward: same source, '/' -> '//' at :150
+    import inspect
+    import textwrap
+    fsrc = textwrap.dedent(inspect.getsource(criterion.MapNetOnlineCriterion.forward))
+    assert "T = s[1] / 2" in fsrc
+    g = dict(criterion.__dict__)
+    exec(compile(fsrc.replace("T = s[1] / 2", "T = s[1] // 2"), "reference:common/criterion.py[137:184]", "exec"), g)
+
+    class MapNetOnlineCriterionPy3(criterion.MapNetOnlineCriterion):
+        forward = g["forward"]
+
+    ns = types.SimpleNamespace(pose_utils=pose_utils, criterion=criterion, posenet=posenet,
+                               MapNetOnlineCriterionPy3=MapNetOnlineCriterionPy3)
+    _cache["ns"] = ns
+    return ns

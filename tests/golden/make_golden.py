@@ -1,0 +1,118 @@
+"""Generates the golden vectors under tests/golden/ by EXECUTING THE REFERENCE's own modules
+(models/posenet.py, common/criterion.py, common/pose_utils.py:1-304 from /root/reference, via
+oracle/ref_loader.py).  Run in the build container only:  python tests/golden/make_golden.py
+The reference ships no golden vectors for this path; these files are what pins parity on the
+GPU box, where /root/reference does not exist.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+warnings.filterwarnings("ignore")
+
+import oracle  # noqa: E402
+from oracle import ref_loader  # noqa: E402
+from oracle.synthetic import _poses  # noqa: E402
+
+
+def crit_case(crit, pred, targ, names):
+    crit = crit.double()
+    p = pred.double().clone().requires_grad_(True)
+    loss = crit(p, targ.double())
+    loss.backward()
+    out = {"pred": pred.numpy(), "targ": targ.numpy(), "loss": np.float64(loss.item()), "dpred": p.grad.numpy()}
+    for n in names:
+        out["s_" + n] = np.float64(getattr(crit, n).item())
+        out["d_" + n] = np.float64(getattr(crit, n).grad.item())
+    return out
+
+
+def main():
+    ns = ref_loader.load()
+    C = ns.criterion
+    gen = torch.Generator().manual_seed(1234)
+    cases = {}
+    # --- criteria on prediction/target pose sets (pred = target + noise) --------------------
+    for tag, n in (("n5", 5), ("n64", 64)):
+        targ = _poses(gen, n, 3)
+        pred = targ + 0.3 * torch.randn(n, 3, 6, generator=gen)
+        cases["posenet_" + tag] = crit_case(C.PoseNetCriterion(sax=0.3, saq=-3.0, learn_beta=True), pred[:, 0], targ[:, 0],
+                                            ["sax", "saq"])
+        cases["mapnet_" + tag] = crit_case(
+            C.MapNetCriterion(sax=0.3, saq=-3.0, srx=-0.2, srq=-3.0, learn_beta=True, learn_gamma=True), pred, targ,
+            ["sax", "saq", "srx", "srq"])
+        _, targ_o = oracle.make_batch("mapnet++", n, 2, 2, seed=100 + n)
+        pred_o = torch.cat((targ_o[:, :3], _poses(gen, n, 3)), dim=1) + 0.2 * torch.randn(n, 6, 6, generator=gen)
+        cases["online_" + tag] = crit_case(
+            ns.MapNetOnlineCriterionPy3(sax=0.0, saq=-3.0, srx=0.1, srq=-3.0, learn_beta=True, learn_gamma=True), pred_o,
+            targ_o, ["sax", "saq", "srx", "srq"])
+        _, targ_g = oracle.make_batch("mapnet++", n, 2, 2, seed=200 + n, gps_mode=True)
+        pred_g = targ_g + 0.2 * torch.randn(n, 6, 6, generator=gen)
+        cases["gps_" + tag] = crit_case(
+            ns.MapNetOnlineCriterionPy3(sax=0.0, saq=-3.0, srx=0.1, srq=-3.0, learn_beta=True, learn_gamma=True,
+                                        gps_mode=True), pred_g, targ_g, ["sax", "saq", "srx"])
+    # ragged edge: a single window
+    targ = _poses(gen, 1, 3)
+    pred = targ + 0.3 * torch.randn(1, 3, 6, generator=gen)
+    cases["mapnet_n1"] = crit_case(C.MapNetCriterion(saq=-3.0, srq=-3.0, learn_beta=True, learn_gamma=True), pred, targ,
+                                   ["sax", "saq", "srx", "srq"])
+    # NaN hazard: two consecutive identical predicted rotations in the VO half
+    _, targ_o = oracle.make_batch("mapnet++", 2, 2, 2, seed=5)
+    pred_o = torch.cat((targ_o[:, :3], _poses(gen, 2, 3)), dim=1)
+    pred_o[0, 4, 3:] = pred_o[0, 3, 3:]
+    cases["online_nan"] = crit_case(
+        ns.MapNetOnlineCriterionPy3(saq=-3.0, srq=-3.0, learn_beta=True, learn_gamma=True), pred_o, targ_o,
+        ["sax", "saq", "srx", "srq"])
+    flat = {}
+    for k, d in cases.items():
+        for kk, v in d.items():
+            flat[k + "/" + kk] = v
+    np.savez_compressed(os.path.join(HERE, "criteria.npz"), **flat)
+
+    # --- pose algebra: calc_vos, calc_vos_simple + a VJP --------------------------------------
+    P = ns.pose_utils
+    poses = _poses(gen, 7, 4).double()
+    R = torch.randn(7, 3, 6, generator=gen).double()
+    p = poses.clone().requires_grad_(True)
+    vos = P.calc_vos(p)
+    (vos * R).sum().backward()
+    pa = {"poses": poses.numpy(), "cot": R.numpy(), "calc_vos": vos.detach().numpy(), "calc_vos_vjp": p.grad.numpy(),
+          "calc_vos_simple": P.calc_vos_simple(poses).numpy()}
+    lq = poses[:, 0, 3:]
+    pa["qexp"] = P.qexp_t(lq).numpy()
+    pa["qlog_qexp"] = P.qlog_t(P.qexp_t(lq)).numpy()
+    np.savez_compressed(os.path.join(HERE, "pose_algebra.npz"), **pa)
+
+    # --- network: reference PoseNet/MapNet modules over the restated ResNet-34 ----------------
+    torch.manual_seed(7)
+    net = ns.posenet.MapNet(ns.posenet.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False))
+    crit = C.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True)
+    x, t = oracle.make_batch("mapnet", 2, 64, 85, seed=7)
+    params = [{"params": net.parameters()}, {"params": [crit.sax, crit.saq]}, {"params": [crit.srx, crit.srq]}]
+    opt = oracle.Optimizer(params, "adam", base_lr=1e-4, weight_decay=5e-4)
+    net.train()
+    out = {"seed": np.int64(7), "shape": np.array([2, 3, 64, 85])}
+    for step in range(2):
+        loss, poses = oracle.step_feedfwd(x, net, False, t, crit, opt, train=True)
+        out["loss%d" % step] = np.float64(loss)
+        out["poses%d" % step] = poses.detach().numpy()
+        if step == 0:
+            out["gradnorm0"] = np.array([float(p.grad.norm()) for p in net.parameters()])
+            out["crit_grad0"] = np.array([float(c.grad) for c in (crit.sax, crit.saq, crit.srx, crit.srq)])
+    out["crit_after"] = np.array([float(c) for c in (crit.sax, crit.saq, crit.srx, crit.srq)])
+    out["bn1_running_mean"] = net.mapnet.feature_extractor.bn1.running_mean.numpy()
+    out["bn1_running_var"] = net.mapnet.feature_extractor.bn1.running_var.numpy()
+    net.eval()
+    with torch.no_grad():
+        out["poses_eval"] = net(x).numpy()
+    np.savez_compressed(os.path.join(HERE, "mapnet_tiny.npz"), **out)
+    print("wrote", sorted(os.listdir(HERE)))
+
+
+if __name__ == "__main__":
+    main()

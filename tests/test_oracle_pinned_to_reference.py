@@ -1,0 +1,96 @@
+"""Pins the oracle restatement to the reference implementation itself, executed from
+/root/reference.  Skipped where that tree is absent (GPU box); the committed golden vectors
+(tests/test_oracle_golden.py) carry the pin there."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import pose_math, ref_loader
+from oracle.synthetic import _poses
+
+pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference tree not mounted")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return ref_loader.load()
+
+
+def _grad_pair(rc, oc, pred, targ):
+    p1 = pred.clone().requires_grad_(True)
+    p2 = pred.clone().requires_grad_(True)
+    l1, l2 = rc(p1, targ), oc(p2, targ)
+    l1.backward()
+    l2.backward()
+    return l1.item(), l2.item(), p1.grad, p2.grad
+
+
+@pytest.mark.parametrize("n", [1, 5, 33])
+def test_criteria_fp64(ref, n):
+    gen = torch.Generator().manual_seed(n)
+    targ = _poses(gen, n, 3).double()
+    pred = targ + 0.4 * torch.randn(n, 3, 6, generator=gen).double()
+    C = ref.criterion
+    pairs = [
+        (C.PoseNetCriterion(sax=0.2, saq=-3, learn_beta=True), oracle.PoseNetCriterion(0.2, -3, True), pred[:, 0], targ[:, 0]),
+        (C.MapNetCriterion(sax=0.2, saq=-3, srx=0.1, srq=-3, learn_beta=True, learn_gamma=True),
+         oracle.MapNetCriterion(0.2, -3, 0.1, -3, True, True), pred, targ),
+    ]
+    _, to = oracle.make_batch("mapnet++", n, 2, 2, seed=n)
+    po = torch.cat((to[:, :3], _poses(gen, n, 3)), 1).double() + 0.1 * torch.randn(n, 6, 6, generator=gen).double()
+    pairs.append((ref.MapNetOnlineCriterionPy3(saq=-3, srq=-3, learn_beta=True, learn_gamma=True),
+                  oracle.MapNetOnlineCriterion(0, -3, 0, -3, True, True), po, to.double()))
+    _, tg = oracle.make_batch("mapnet++", n, 2, 2, seed=n, gps_mode=True)
+    pairs.append((ref.MapNetOnlineCriterionPy3(saq=-3, srq=-3, learn_beta=True, learn_gamma=True, gps_mode=True),
+                  oracle.MapNetOnlineCriterion(0, -3, 0, -3, True, True, gps_mode=True),
+                  tg.double() + 0.1 * torch.randn(n, 6, 6, generator=gen).double(), tg.double()))
+    for rc, oc, p, t in pairs:
+        l1, l2, g1, g2 = _grad_pair(rc.double(), oc.double(), p, t)
+        assert abs(l1 - l2) < 1e-13
+        np.testing.assert_allclose(g1.numpy(), g2.numpy(), atol=1e-14)
+        for nm in ("sax", "saq", "srx", "srq"):
+            if hasattr(oc, nm) and getattr(rc, nm).grad is not None:
+                assert abs(getattr(rc, nm).grad.item() - getattr(oc, nm).grad.item()) < 1e-13
+
+
+def test_pose_chain_fp32_and_identities(ref):
+    P = ref.pose_utils
+    gen = torch.Generator().manual_seed(3)
+    poses = _poses(gen, 9, 4)
+    np.testing.assert_array_equal(P.calc_vos(poses).numpy(), pose_math.calc_vos(poses).numpy())
+    np.testing.assert_array_equal(P.calc_vos_simple(poses).numpy(), pose_math.calc_vos_simple(poses).numpy())
+    # calc_vo_logq(p, p) = 0 (N=1), compose/invert identity from test_pose_utils (:1197-1253)
+    p = poses[0, :1]
+    assert float(P.calc_vo_logq(p, p).abs().max()) < 1e-6
+    p7 = torch.cat((p[:, :3], P.qexp_t(p[:, 3:])), 1)
+    ident = P.compose_pose_quaternion(p7, P.invert_pose_quaternion(p7))
+    np.testing.assert_allclose(ident.numpy(), [[0, 0, 0, 1, 0, 0, 0]], atol=1e-6)
+
+
+def test_posenet_module_equivalence(ref):
+    torch.manual_seed(11)
+    a = ref.posenet.MapNet(ref.posenet.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False))
+    torch.manual_seed(11)
+    b = oracle.MapNet(oracle.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False))
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    for (k, u), v in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(u, v), k
+    x, _ = oracle.make_batch("mapnet", 2, 32, 43)
+    np.testing.assert_array_equal(a(x).detach().numpy(), b(x).detach().numpy())
+
+
+def test_filter_nans_hook_equivalence(ref):
+    """mapnet++: NaN gradients entering fc_wpqr are zeroed in d(input), d(weight), d(bias)."""
+    torch.manual_seed(5)
+    a = ref.posenet.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False, filter_nans=True)
+    torch.manual_seed(5)
+    b = oracle.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False, filter_nans=True)
+    x, _ = oracle.make_batch("posenet", 3, 32, 43)
+    cot = torch.ones(3, 6)
+    cot[1, 4] = float("nan")
+    for m in (a, b):
+        m.zero_grad()
+        (m(x) * cot).sum().backward()
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=1e-5, atol=1e-7, equal_nan=True, err_msg=k)

@@ -1,0 +1,7 @@
+"""geomapnet_amd: the MapNet training hot path of NVlabs/geomapnet as hand-written gfx950
+(MI355X) kernels behind the reference's own Python API.  See DESIGN.md / INTEGRATION.md."""
+from .engine import set_compute_dtype, get_compute_dtype  # noqa: F401
+from .posenet import PoseNet, MapNet, resnet34  # noqa: F401
+from .criterion import PoseNetCriterion, MapNetCriterion, MapNetOnlineCriterion  # noqa: F401
+from .optimizer import Optimizer  # noqa: F401
+from .train import step_feedfwd  # noqa: F401

@@ -1,0 +1,709 @@
+// MapNet / PoseNet training plan: the host-side schedule of one training step
+// (/root/reference/common/train.py:322-363) as a fixed sequence of gfx950 kernel launches on
+// caller-provided arenas.  See include/mapnet_hip.h for the ABI and DESIGN.md for the layout.
+#include "../../include/mapnet_hip.h"
+
+#include <cmath>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "criterion.h"
+#include "elementwise.h"
+#include "head.h"
+#include "igemm.h"
+#include "layout.h"
+#include "optim.h"
+#include "util.h"
+#include "wgrad.h"
+
+using namespace mn;
+
+// ---- model layout entry points ------------------------------------------------------------------
+static const Layout& layout_for(int feat_dim) {
+  static thread_local std::unique_ptr<Layout> cache;
+  if (!cache || cache->feat_dim != feat_dim) cache.reset(new Layout(feat_dim));
+  return *cache;
+}
+extern "C" int mn_model_entries(int feat_dim) { return (int)layout_for(feat_dim).entries.size(); }
+extern "C" int mn_model_entry(int feat_dim, int idx, mn_entry* out) {
+  const Layout& L = layout_for(feat_dim);
+  if (idx < 0 || idx >= (int)L.entries.size()) return fail("mn_model_entry: index out of range");
+  *out = L.entries[idx];
+  return 0;
+}
+extern "C" int64_t mn_model_param_floats(int feat_dim) { return layout_for(feat_dim).param_floats; }
+extern "C" int64_t mn_model_buffer_bytes(int feat_dim) { return layout_for(feat_dim).buffer_bytes; }
+
+namespace {
+
+struct Bump {
+  size_t cur = 0;
+  size_t take(size_t bytes) {
+    size_t o = cur;
+    cur += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+// event-pair timer for kernel classes (igemm, wgrad, whole step)
+struct KernelTimer {
+  bool enabled = false;
+  struct Pair {
+    hipEvent_t a, b;
+    int cat;
+  };
+  std::vector<Pair> pool;
+  size_t used = 0;
+  float ms[4] = {0, 0, 0, 0};
+  int launches[4] = {0, 0, 0, 0};
+  Pair* begin(int cat, hipStream_t s) {
+    if (!enabled) return nullptr;
+    if (used == pool.size()) {
+      Pair p;
+      hipEventCreate(&p.a);
+      hipEventCreate(&p.b);
+      pool.push_back(p);
+    }
+    Pair* p = &pool[used++];
+    p->cat = cat;
+    hipEventRecord(p->a, s);
+    return p;
+  }
+  void end(Pair* p, hipStream_t s) {
+    if (p) hipEventRecord(p->b, s);
+  }
+  void reset() { used = 0; }
+  void collect() {  // caller has synchronised the stream
+    for (int i = 0; i < 4; ++i) {
+      ms[i] = 0;
+      launches[i] = 0;
+    }
+    for (size_t i = 0; i < used; ++i) {
+      float t = 0;
+      hipEventSynchronize(pool[i].b);
+      hipEventElapsedTime(&t, pool[i].a, pool[i].b);
+      ms[pool[i].cat] += t;
+      launches[pool[i].cat]++;
+    }
+  }
+  ~KernelTimer() {
+    for (auto& p : pool) {
+      hipEventDestroy(p.a);
+      hipEventDestroy(p.b);
+    }
+  }
+};
+
+struct PlanBase {
+  virtual ~PlanBase() {}
+  virtual int forward(const float* images, float* poses_out, int training, hipStream_t s) = 0;
+  virtual int loss_only(const float* pred, const float* targ, float* loss_out, hipStream_t s) = 0;
+  virtual int forward_loss(const float* images, const float* targets, float* loss_out, float* poses_out,
+                           hipStream_t s) = 0;
+  virtual int backward_stage(int stage, hipStream_t s) = 0;
+  virtual int optim_step(float grad_mul, hipStream_t s) = 0;
+  mn_config cfg;
+  Layout L{2048};
+  float lr = 1e-4f, wd = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, max_grad_norm = 0.f;
+  int64_t step = 0;
+  bool weights_dirty = true;
+  int learn_beta = 0, learn_gamma = 0;
+  KernelTimer timer;
+};
+
+template <typename T>
+struct Plan : PlanBase {
+  static constexpr int VEC = ElemTraits<T>::VEC;
+  static constexpr int DT = ElemTraits<T>::DTYPE;
+
+  struct Unit {  // conv + BatchNorm
+    ConvP cp;
+    BnP bp;
+    int Hin, Win, Hout, Wout;
+    long M;
+    GatherGeom gf, gd;
+    T* wf = nullptr;  // forward operand  [Cout][K]
+    T* wd = nullptr;  // data-gradient operand [Cin][R*S*Cout]
+    T* y = nullptr;   // raw conv output [M][Cout]
+    T* gy = nullptr;  // its gradient
+    float *mean, *invstd, *scale, *shift, *coef;
+    double* accum;
+    int ldw;           // row pitch of the master weight gradient
+    const int* colmap = nullptr;
+  };
+  struct Block {
+    Unit u1, u2, ud;
+    bool down;
+    int stage;
+    const T* x;   // block input
+    T* gx;        // gradient w.r.t. block input (written by this block's backward)
+    T* a1;        // relu(bn1(conv1 x))
+    T* ga1;
+    T* zd;        // bn_d(conv_d x) when down
+    T* out;       // block output
+    T* gout;      // gradient w.r.t. block output (written by the consumer)
+  };
+
+  float *params, *grads, *m1, *m2;
+  char* buffers;
+  char* work;
+  int B, H, W, Hp, Wp;
+  int frames;  // images per window
+  T* xpad;
+  Unit stem;
+  T *a0, *ga0, *p0, *gp0;
+  int H0, W0, H1, W1;  // stem conv output, pooled output
+  std::vector<Block> blocks;
+  int Hl, Wl;  // last feature map
+  float *pooled, *feat, *poses, *dposes, *dz, *dpooled, *fcT, *loss_dev;
+  float* stats_partial;
+  double* sqnorm;
+  unsigned char* frozen;
+  int* stem_colmap;
+  const float* cur_targets = nullptr;
+  float* cur_loss = nullptr;
+
+  // ---- construction -----------------------------------------------------------------------
+  size_t carve(char* base) {
+    Bump b;
+    auto A = [&](size_t bytes) { return base ? base + b.take(bytes) : (b.take(bytes), (char*)nullptr); };
+    auto unit_bufs = [&](Unit& u) {
+      int C = u.cp.cout;
+      u.y = (T*)A((size_t)u.M * C * sizeof(T));
+      u.gy = (T*)A((size_t)u.M * C * sizeof(T));
+      u.mean = (float*)A(C * 4);
+      u.invstd = (float*)A(C * 4);
+      u.scale = (float*)A(C * 4);
+      u.shift = (float*)A(C * 4);
+      u.coef = (float*)A(3 * C * 4);
+      u.accum = (double*)A(2 * C * 8);
+    };
+    xpad = (T*)A((size_t)B * Hp * Wp * 4 * sizeof(T));
+    // stem
+    unit_bufs(stem);
+    stem.wf = (T*)A((size_t)64 * 224 * sizeof(T));
+    size_t n0 = (size_t)B * H0 * W0 * 64, n1 = (size_t)B * H1 * W1 * 64;
+    a0 = (T*)A(n0 * sizeof(T));
+    ga0 = (T*)A(n0 * sizeof(T));
+    p0 = (T*)A(n1 * sizeof(T));
+    gp0 = (T*)A(n1 * sizeof(T));
+    const T* x = p0;
+    T* gx = gp0;
+    size_t max_partial = (size_t)igemm_grid_m((int)stem.M) * 2 * 64;
+    for (auto& blk : blocks) {
+      blk.x = x;
+      blk.gx = gx;
+      Unit* us[3] = {&blk.u1, &blk.u2, blk.down ? &blk.ud : nullptr};
+      for (Unit* u : us) {
+        if (!u) continue;
+        unit_bufs(*u);
+        size_t wn = (size_t)u->cp.cout * u->cp.cin * u->cp.k * u->cp.k;
+        if (DT == MN_F16)
+          u->wf = (T*)A(wn * sizeof(T));
+        else
+          u->wf = base ? (T*)(params + u->cp.w) : nullptr;  // fp32: the OHWI master is the operand
+        u->wd = (T*)A(wn * sizeof(T));
+        size_t part = (size_t)igemm_grid_m((int)u->M) * 2 * u->cp.cout;
+        if (part > max_partial) max_partial = part;
+      }
+      size_t no = (size_t)blk.u2.M * blk.u2.cp.cout;
+      blk.a1 = (T*)A(no * sizeof(T));
+      blk.ga1 = (T*)A(no * sizeof(T));
+      blk.zd = blk.down ? (T*)A(no * sizeof(T)) : nullptr;
+      blk.out = (T*)A(no * sizeof(T));
+      blk.gout = (T*)A(no * sizeof(T));
+      x = blk.out;
+      gx = blk.gout;
+    }
+    int F = cfg.feat_dim;
+    pooled = (float*)A((size_t)B * 512 * 4);
+    feat = (float*)A((size_t)B * F * 4);
+    poses = (float*)A((size_t)B * 6 * 4);
+    dposes = (float*)A((size_t)B * 6 * 4);
+    dz = (float*)A((size_t)B * F * 4);
+    dpooled = (float*)A((size_t)B * 512 * 4);
+    fcT = (float*)A((size_t)512 * F * 4);
+    loss_dev = (float*)A(256);
+    stats_partial = (float*)A(max_partial * 4);
+    sqnorm = (double*)A(256);
+    frozen = (unsigned char*)A(256);
+    stem_colmap = (int*)A(224 * 4);
+    return b.cur;
+  }
+
+  static GatherGeom fwd_geom(int B, int Hin, int Win, const ConvP& c, int Hout, int Wout) {
+    GatherGeom g;
+    g.B = B; g.Hi = Hin; g.Wi = Win; g.C = c.cin; g.P = Hout; g.Q = Wout; g.R = c.k; g.S = c.k;
+    g.mul_p = c.stride; g.mul_q = c.stride; g.rsign = 1; g.ssign = 1; g.off_h = -c.pad; g.off_w = -c.pad; g.div = 1;
+    g.M = B * Hout * Wout; g.N = c.cout; g.K = c.k * c.k * c.cin;
+    return g;
+  }
+  static GatherGeom dgrad_geom(int B, int Hin, int Win, const ConvP& c, int Hout, int Wout) {
+    GatherGeom g;
+    g.B = B; g.Hi = Hout; g.Wi = Wout; g.C = c.cout; g.P = Hin; g.Q = Win; g.R = c.k; g.S = c.k;
+    g.mul_p = 1; g.mul_q = 1; g.rsign = -1; g.ssign = -1; g.off_h = c.pad; g.off_w = c.pad; g.div = c.stride;
+    g.M = B * Hin * Win; g.N = c.cin; g.K = c.k * c.k * c.cout;
+    return g;
+  }
+  void init_unit(Unit& u, const ConvP& c, const BnP& b, int Hin, int Win) {
+    u.cp = c;
+    u.bp = b;
+    u.Hin = Hin;
+    u.Win = Win;
+    u.Hout = (Hin + 2 * c.pad - c.k) / c.stride + 1;
+    u.Wout = (Win + 2 * c.pad - c.k) / c.stride + 1;
+    u.M = (long)B * u.Hout * u.Wout;
+    u.gf = fwd_geom(B, Hin, Win, c, u.Hout, u.Wout);
+    u.gd = dgrad_geom(B, Hin, Win, c, u.Hout, u.Wout);
+    u.ldw = c.k * c.k * c.cin;
+  }
+
+  Plan(const mn_config& c) {
+    cfg = c;
+    L = Layout(c.feat_dim);
+    frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
+    B = c.windows * frames;
+    H = c.H;
+    W = c.W;
+    Hp = H + 6;
+    Wp = (W + 6 + 1 + 1) & ~1;  // even, >= W + 7
+    // stem as a 7x4 conv over pixel pairs (C = 8), stride (2,1), no padding
+    H0 = (H + 6 - 7) / 2 + 1;
+    W0 = (W + 6 - 7) / 2 + 1;
+    stem.cp = L.stem;
+    stem.bp = L.stem_bn;
+    stem.Hin = H; stem.Win = W; stem.Hout = H0; stem.Wout = W0;
+    stem.M = (long)B * H0 * W0;
+    GatherGeom g;
+    g.B = B; g.Hi = Hp; g.Wi = Wp / 2; g.C = 8; g.P = H0; g.Q = W0; g.R = 7; g.S = 4;
+    g.mul_p = 2; g.mul_q = 1; g.rsign = 1; g.ssign = 1; g.off_h = 0; g.off_w = 0; g.div = 1;
+    g.M = B * H0 * W0; g.N = 64; g.K = 224;
+    stem.gf = g;
+    stem.ldw = 147;
+    H1 = (H0 + 2 - 3) / 2 + 1;
+    W1 = (W0 + 2 - 3) / 2 + 1;
+    int h = H1, w = W1;
+    for (const BlockP& bp : L.blocks) {
+      Block blk;
+      blk.down = bp.down;
+      blk.stage = bp.stage;
+      init_unit(blk.u1, bp.c1, bp.b1, h, w);
+      init_unit(blk.u2, bp.c2, bp.b2, blk.u1.Hout, blk.u1.Wout);
+      if (bp.down) init_unit(blk.ud, bp.cd, bp.bd, h, w);
+      h = blk.u1.Hout;
+      w = blk.u1.Wout;
+      blocks.push_back(blk);
+    }
+    Hl = h;
+    Wl = w;
+  }
+
+  int attach(float* params_, float* opt_state, void* buffers_, void* work_, hipStream_t s) {
+    params = params_;
+    grads = opt_state;
+    m1 = opt_state + L.param_floats;
+    m2 = opt_state + 2 * L.param_floats;
+    buffers = (char*)buffers_;
+    work = (char*)work_;
+    size_t total = carve(work);
+    hipMemsetAsync(work, 0, total, s);
+    // stem column map: compute column (r, s4, e) -> dense OHWI column (r, s', ch) or -1
+    std::vector<int> cm(224);
+    for (int r = 0; r < 7; ++r)
+      for (int s4 = 0; s4 < 4; ++s4)
+        for (int e = 0; e < 8; ++e) {
+          int sp = 2 * s4 + (e >> 2), ch = e & 3;
+          cm[(r * 4 + s4) * 8 + e] = (sp < 7 && ch < 3) ? (r * 7 + sp) * 3 + ch : -1;
+        }
+    hipMemcpyAsync(stem_colmap, cm.data(), 224 * 4, hipMemcpyHostToDevice, s);
+    hipStreamSynchronize(s);  // cm is a host temporary
+    stem.colmap = stem_colmap;
+    update_frozen(s);
+    weights_dirty = true;
+    return check_launch("attach");
+  }
+
+  void update_frozen(hipStream_t s) {
+    unsigned char f[4] = {(unsigned char)!learn_beta, (unsigned char)!learn_beta, (unsigned char)!learn_gamma,
+                          (unsigned char)!learn_gamma};
+    hipMemcpyAsync(frozen, f, 4, hipMemcpyHostToDevice, s);
+    hipStreamSynchronize(s);
+  }
+
+  // ---- weights: fp32 master -> compute layouts ------------------------------------------------
+  void repack(hipStream_t s) {
+    hipLaunchKernelGGL((repack_kernel<T>), dim3(ew_grid(64 * 224)), dim3(256), 0, s, (const float*)(params + stem.cp.w),
+                       stem.wf, 64, 7, 7, 3, 2);
+    for (auto& blk : blocks) {
+      Unit* us[3] = {&blk.u1, &blk.u2, blk.down ? &blk.ud : nullptr};
+      for (Unit* u : us) {
+        if (!u) continue;
+        const ConvP& c = u->cp;
+        long n = (long)c.cout * c.cin * c.k * c.k;
+        const float* src = params + c.w;
+        if (DT == MN_F16)
+          hipLaunchKernelGGL((repack_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, src, u->wf, c.cout, c.k, c.k, c.cin, 0);
+        hipLaunchKernelGGL((repack_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, src, u->wd, c.cout, c.k, c.k, c.cin, 1);
+      }
+    }
+    hipLaunchKernelGGL(transpose_kernel, dim3(ew_grid((long)512 * cfg.feat_dim)), dim3(256), 0, s,
+                       (const float*)(params + L.fc_w), fcT, cfg.feat_dim, 512);
+    weights_dirty = false;
+  }
+
+  // ---- forward ------------------------------------------------------------------------------------
+  BnParams bn_params(const Unit& u) {
+    BnParams p;
+    p.gamma = params + u.bp.gamma;
+    p.beta = params + u.bp.beta;
+    p.running_mean = (float*)buffers + u.bp.rm;
+    p.running_var = (float*)buffers + u.bp.rv;
+    p.num_batches_tracked = (long long*)(buffers + u.bp.nbt);
+    p.mean = u.mean;
+    p.invstd = u.invstd;
+    p.scale = u.scale;
+    p.shift = u.shift;
+    p.eps = 1e-5f;
+    p.momentum = 0.1f;
+    return p;
+  }
+  void conv_bn_stats(Unit& u, const T* x, int training, hipStream_t s) {
+    Epilogue ep;
+    ep.out = u.y; ep.ldc = u.cp.cout; ep.stats = training ? stats_partial : nullptr; ep.bias = nullptr; ep.relu = 0;
+    ep.res = nullptr; ep.res_gate = nullptr; ep.alpha = 1.f;
+    auto* tp = timer.begin(0, s);
+    launch_igemm<T>(u.gf, x, u.wf, ep, s);
+    timer.end(tp, s);
+    int N = u.cp.cout;
+    if (training) {
+      int GM = igemm_grid_m((int)u.M);
+      hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(GM, 64), cdiv(N, 64)), dim3(256), 0, s,
+                         (const float*)stats_partial, GM, N, u.accum, 64);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, u.accum, N, (double)u.M, bn_params(u),
+                       training);
+  }
+  void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s) {
+    long np = u.M * u.cp.cout / VEC;
+    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const float*)u.scale,
+                       (const float*)u.shift, res, out, np, u.cp.cout, relu);
+  }
+
+  int forward(const float* images, float* poses_out, int training, hipStream_t s) override {
+    if (weights_dirty) repack(s);
+    hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s, images, xpad, B,
+                       H, W, Hp, Wp);
+    conv_bn_stats(stem, xpad, training, s);
+    bn_act(stem, nullptr, 1, a0, s);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
+                       (const T*)a0, p0, B, H0, W0, 64, H1, W1);
+    for (auto& blk : blocks) {
+      conv_bn_stats(blk.u1, blk.x, training, s);
+      bn_act(blk.u1, nullptr, 1, blk.a1, s);
+      conv_bn_stats(blk.u2, blk.a1, training, s);
+      const T* res = blk.x;
+      if (blk.down) {
+        conv_bn_stats(blk.ud, blk.x, training, s);
+        bn_act(blk.ud, nullptr, 0, blk.zd, s);
+        res = blk.zd;
+      }
+      bn_act(blk.u2, res, 1, blk.out, s);
+    }
+    const Block& last = blocks.back();
+    int F = cfg.feat_dim;
+    hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(cdiv((long)B * 512, 256)), dim3(256), 0, s, (const T*)last.out, pooled,
+                       B, Hl * Wl, 512);
+    // fc 512 -> feat_dim, bias, ReLU (models/posenet.py:46,65-66); dropout is the identity under the
+    // reference's pinned torch 0.4.1 (F.dropout default training=False)
+    GatherGeom g;
+    g.B = B; g.Hi = 1; g.Wi = 1; g.C = 512; g.P = 1; g.Q = 1; g.R = 1; g.S = 1; g.mul_p = 1; g.mul_q = 1; g.rsign = 1;
+    g.ssign = 1; g.off_h = 0; g.off_w = 0; g.div = 1; g.M = B; g.N = F; g.K = 512;
+    Epilogue ep;
+    ep.out = feat; ep.ldc = F; ep.stats = nullptr; ep.bias = params + L.fc_b; ep.relu = 1; ep.res = nullptr;
+    ep.res_gate = nullptr; ep.alpha = 1.f;
+    launch_igemm<float>(g, (const float*)pooled, (const float*)(params + L.fc_w), ep, s);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(cdiv((long)B * 6 * 64, 256)), dim3(256), 0, s, (const float*)feat,
+                       (const float*)(params + L.xyz_w), (const float*)(params + L.xyz_b),
+                       (const float*)(params + L.wpqr_w), (const float*)(params + L.wpqr_b), poses, B, F);
+    if (poses_out) hipMemcpyAsync(poses_out, poses, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, s);
+    return check_launch("forward");
+  }
+
+  void run_criterion(const float* pred, const float* targ, float* loss, float* dpred, float* ds, hipStream_t s) {
+    CriterionArgs a;
+    a.mode = cfg.mode; a.N = cfg.windows; a.T = cfg.T; a.pred = pred; a.targ = targ; a.s = params + L.crit; a.loss = loss;
+    a.dpred = dpred; a.ds = ds; a.vos_out = nullptr; a.grad_scale = cfg.loss_scale;
+    hipLaunchKernelGGL(criterion_kernel, dim3(1), dim3(256), 0, s, a);
+  }
+  int loss_only(const float* pred, const float* targ, float* loss_out, hipStream_t s) override {
+    run_criterion(pred, targ, loss_out, nullptr, nullptr, s);
+    return check_launch("loss");
+  }
+  int forward_loss(const float* images, const float* targets, float* loss_out, float* poses_out, hipStream_t s) override {
+    if (int e = forward(images, poses_out, 1, s)) return e;
+    cur_targets = targets;
+    cur_loss = loss_out ? loss_out : loss_dev;
+    return 0;
+  }
+
+  // ---- backward -------------------------------------------------------------------------------------
+  void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s) {
+    launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
+                     grads + u.bp.beta, u.gy, u.coef, u.accum, 1.f / cfg.loss_scale, s);
+  }
+  void conv_wgrad(Unit& u, const T* x, hipStream_t s) {
+    WgradArgs a;
+    a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
+    a.alpha = 1.f / cfg.loss_scale; a.rows_per_split = 0;
+    auto* tp = timer.begin(1, s);
+    launch_wgrad<T>(a, 1024, s);
+    timer.end(tp, s);
+  }
+  void conv_dgrad(Unit& u, T* gx, const T* res, const T* gate, hipStream_t s) {
+    Epilogue ep;
+    ep.out = gx; ep.ldc = u.cp.cin; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = res; ep.res_gate = gate;
+    ep.alpha = 1.f;
+    auto* tp = timer.begin(0, s);
+    launch_igemm<T>(u.gd, (const T*)u.gy, (const T*)u.wd, ep, s);
+    timer.end(tp, s);
+  }
+  void block_backward(Block& blk, hipStream_t s) {
+    // gm = gout * (out > 0) feeds bn2 (and bn_d); see DESIGN.md section 4
+    bn_bwd(blk.u2, blk.gout, blk.out, s);
+    conv_wgrad(blk.u2, blk.a1, s);
+    conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
+    bn_bwd(blk.u1, blk.ga1, blk.a1, s);
+    conv_wgrad(blk.u1, blk.x, s);
+    if (blk.down) {
+      bn_bwd(blk.ud, blk.gout, blk.out, s);
+      conv_wgrad(blk.ud, blk.x, s);
+      conv_dgrad(blk.u1, blk.gx, nullptr, nullptr, s);
+      conv_dgrad(blk.ud, blk.gx, blk.gx, nullptr, s);  // accumulate the projection path in place
+    } else {
+      conv_dgrad(blk.u1, blk.gx, blk.gout, blk.out, s);  // + identity path, gated by the block ReLU
+    }
+  }
+  void head_backward(hipStream_t s) {
+    int F = cfg.feat_dim;
+    float unscale = 1.f / cfg.loss_scale;
+    hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, s);  // optim.learner.zero_grad()
+    run_criterion(poses, cur_targets, cur_loss, dposes, grads + L.crit, s);
+    hipLaunchKernelGGL(head_bwd_input_kernel, dim3(cdiv((long)B * F, 256)), dim3(256), 0, s, (const float*)dposes,
+                       (const float*)feat, (const float*)(params + L.xyz_w), (const float*)(params + L.wpqr_w), dz, B, F,
+                       cfg.filter_nans);
+    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(cdiv(6L * (F + 1), 256)), dim3(256), 0, s, (const float*)dposes,
+                       (const float*)feat, grads + L.xyz_w, grads + L.xyz_b, grads + L.wpqr_w, grads + L.wpqr_b, B, F,
+                       unscale, cfg.filter_nans);
+    // fc backward
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(F, 256)), dim3(256), 0, s, (const float*)dz, grads + L.fc_b, B, F, unscale);
+    GatherGeom g;
+    g.B = B; g.Hi = 1; g.Wi = 1; g.C = 512; g.P = 1; g.Q = 1; g.R = 1; g.S = 1; g.mul_p = 1; g.mul_q = 1; g.rsign = 1;
+    g.ssign = 1; g.off_h = 0; g.off_w = 0; g.div = 1; g.M = B; g.N = F; g.K = 512;
+    WgradArgs a;
+    a.g = g; a.dY = dz; a.ldy = F; a.X = pooled; a.dW = grads + L.fc_w; a.ldw = 512; a.colmap = nullptr; a.alpha = unscale;
+    a.rows_per_split = 0;
+    launch_wgrad<float>(a, 1, s);
+    GatherGeom gd = g;
+    gd.C = F; gd.N = 512; gd.K = F;
+    Epilogue ep;
+    ep.out = dpooled; ep.ldc = 512; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = nullptr;
+    ep.res_gate = nullptr; ep.alpha = 1.f;
+    launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s);
+    Block& last = blocks.back();
+    hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
+                       (const float*)dpooled, last.gout, B, Hl * Wl, 512);
+  }
+  void stem_backward(hipStream_t s) {
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s, (const T*)a0,
+                       (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
+    bn_bwd(stem, ga0, a0, s);
+    conv_wgrad(stem, xpad, s);  // the input gradient of the stem is not needed (nothing consumes it)
+  }
+  int backward_stage(int stage, hipStream_t s) override {
+    if (stage < 0 || stage > 3) return fail("backward_stage: stage must be 0..3");
+    if (!cur_targets) return fail("backward_stage: call mn_train_forward_loss first");
+    if (stage == 3) head_backward(s);
+    for (int i = (int)blocks.size() - 1; i >= 0; --i)
+      if (blocks[i].stage == stage) block_backward(blocks[i], s);
+    if (stage == 0) {
+      stem_backward(s);
+      cur_targets = nullptr;
+    }
+    return check_launch("backward_stage");
+  }
+
+  // ---- optimiser -----------------------------------------------------------------------------------
+  int optim_step(float grad_mul, hipStream_t s) override {
+    step += 1;
+    if (max_grad_norm > 0.f) {
+      hipMemsetAsync(sqnorm, 0, sizeof(double), s);
+      hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(ew_grid(L.model_floats)), dim3(256), 0, s, (const float*)grads,
+                         (long)L.model_floats, sqnorm);
+    }
+    AdamArgs a;
+    a.p = params; a.g = grads; a.m = m1; a.v = m2; a.n = L.param_floats; a.n_clip = L.model_floats; a.lr = lr; a.wd = wd;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+    a.bc2 = (float)(1.0 - std::pow((double)beta2, (double)step));
+    a.grad_mul = grad_mul; a.max_norm = max_grad_norm; a.sqnorm = sqnorm; a.frozen = frozen; a.eps_mode = cfg.eps_mode;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(L.param_floats)), dim3(256), 0, s, a);
+    weights_dirty = true;
+    return check_launch("optim_step");
+  }
+};
+
+}  // namespace
+
+struct mn_handle {
+  std::unique_ptr<PlanBase> plan;
+};
+
+static int validate(const mn_config* c) {
+  if (!c) return fail("null config");
+  if (c->mode < 0 || c->mode > 3) return fail("config: bad mode");
+  if (c->dtype != MN_DTYPE_F32 && c->dtype != MN_DTYPE_F16) return fail("config: bad dtype");
+  if (c->windows < 1 || c->T < 1 || c->T > 4) return fail("config: windows >= 1 and 1 <= T <= 4 required");
+  if (c->mode == MN_MODE_POSENET && c->T != 1) return fail("config: PoseNet mode requires T = 1");
+  if (c->mode >= MN_MODE_MAPNET && c->T < 2) return fail("config: MapNet modes require T >= 2");
+  if (c->H < 32 || c->W < 32) return fail("config: image must be at least 32x32");
+  if (c->feat_dim < 64 || c->feat_dim % 64 != 0) return fail("config: feat_dim must be a multiple of 64");
+  if (!(c->loss_scale > 0.f)) return fail("config: loss_scale must be positive");
+  return 0;
+}
+
+extern "C" int64_t mn_plan_bytes(const mn_config* cfg) {
+  if (validate(cfg)) return -1;
+  if (cfg->dtype == MN_DTYPE_F16) {
+    Plan<half> p(*cfg);
+    return (int64_t)p.carve(nullptr);
+  }
+  Plan<float> p(*cfg);
+  return (int64_t)p.carve(nullptr);
+}
+
+extern "C" mn_handle* mn_create(const mn_config* cfg, float* params, float* opt_state, void* buffers, void* work,
+                                void* stream) {
+  if (validate(cfg)) return nullptr;
+  if (!params || !opt_state || !buffers || !work) {
+    fail("mn_create: null arena");
+    return nullptr;
+  }
+  mn_handle* h = new mn_handle();
+  int rc;
+  if (cfg->dtype == MN_DTYPE_F16) {
+    auto* p = new Plan<half>(*cfg);
+    h->plan.reset(p);
+    rc = p->attach(params, opt_state, buffers, work, (hipStream_t)stream);
+  } else {
+    auto* p = new Plan<float>(*cfg);
+    h->plan.reset(p);
+    rc = p->attach(params, opt_state, buffers, work, (hipStream_t)stream);
+  }
+  if (rc) {
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+extern "C" void mn_destroy(mn_handle* h) { delete h; }
+
+#define MN_H(h)                      \
+  if (!(h) || !(h)->plan) return fail("null handle"); \
+  PlanBase& P = *(h)->plan;
+
+extern "C" int mn_set_learn_flags(mn_handle* h, int learn_beta, int learn_gamma) {
+  MN_H(h);
+  P.learn_beta = learn_beta;
+  P.learn_gamma = learn_gamma;
+  if (P.cfg.dtype == MN_DTYPE_F16)
+    static_cast<Plan<half>&>(P).update_frozen(nullptr);
+  else
+    static_cast<Plan<float>&>(P).update_frozen(nullptr);
+  return 0;
+}
+extern "C" int mn_set_optim(mn_handle* h, float lr, float weight_decay, float beta1, float beta2, float eps,
+                            float max_grad_norm) {
+  MN_H(h);
+  P.lr = lr; P.wd = weight_decay; P.beta1 = beta1; P.beta2 = beta2; P.eps = eps; P.max_grad_norm = max_grad_norm;
+  return 0;
+}
+extern "C" int mn_set_step_count(mn_handle* h, int64_t step) {
+  MN_H(h);
+  P.step = step;
+  return 0;
+}
+extern "C" int64_t mn_get_step_count(mn_handle* h) { return (h && h->plan) ? h->plan->step : -1; }
+extern "C" int mn_forward(mn_handle* h, const float* images, float* poses_out, int training, void* stream) {
+  MN_H(h);
+  return P.forward(images, poses_out, training, (hipStream_t)stream);
+}
+extern "C" int mn_loss(mn_handle* h, const float* pred, const float* targ, float* loss_out, void* stream) {
+  MN_H(h);
+  return P.loss_only(pred, targ, loss_out, (hipStream_t)stream);
+}
+extern "C" int mn_train_forward_loss(mn_handle* h, const float* images, const float* targets, float* loss_out,
+                                     float* poses_out, void* stream) {
+  MN_H(h);
+  P.timer.reset();
+  return P.forward_loss(images, targets, loss_out, poses_out, (hipStream_t)stream);
+}
+extern "C" int mn_train_backward_stage(mn_handle* h, int stage, void* stream) {
+  MN_H(h);
+  return P.backward_stage(stage, (hipStream_t)stream);
+}
+extern "C" int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t* count) {
+  MN_H(h);
+  if (stage < 0 || stage > 3) return fail("mn_grad_bucket: stage must be 0..3");
+  *offset = P.L.stage_begin[stage];
+  *count = P.L.stage_end[stage] - P.L.stage_begin[stage];
+  return 0;
+}
+extern "C" int mn_optim_step(mn_handle* h, float grad_mul, void* stream) {
+  MN_H(h);
+  return P.optim_step(grad_mul, (hipStream_t)stream);
+}
+extern "C" int mn_train_step(mn_handle* h, const float* images, const float* targets, float* loss_out, float* poses_out,
+                             void* stream) {
+  MN_H(h);
+  hipStream_t s = (hipStream_t)stream;
+  P.timer.reset();
+  auto* tp = P.timer.begin(3, s);
+  if (int e = P.forward_loss(images, targets, loss_out, poses_out, s)) return e;
+  for (int st = 3; st >= 0; --st)
+    if (int e = P.backward_stage(st, s)) return e;
+  int rc = P.optim_step(1.f, s);
+  P.timer.end(tp, s);
+  return rc;
+}
+extern "C" int mn_params_changed(mn_handle* h) {
+  MN_H(h);
+  P.weights_dirty = true;
+  return 0;
+}
+extern "C" int mn_set_profiling(mn_handle* h, int enable) {
+  MN_H(h);
+  P.timer.enabled = enable != 0;
+  P.timer.reset();
+  return 0;
+}
+extern "C" int mn_last_kernel_ms(mn_handle* h, int which, float* ms, int* launches) {
+  MN_H(h);
+  if (which < 0 || which > 3) return fail("mn_last_kernel_ms: which must be 0..3");
+  P.timer.collect();
+  if (which == 0) {
+    *ms = P.timer.ms[0] + P.timer.ms[1];
+    *launches = P.timer.launches[0] + P.timer.launches[1];
+  } else if (which == 1) {
+    *ms = P.timer.ms[0];
+    *launches = P.timer.launches[0];
+  } else if (which == 2) {
+    *ms = P.timer.ms[1];
+    *launches = P.timer.launches[1];
+  } else {
+    *ms = P.timer.ms[3];
+    *launches = P.timer.launches[3];
+  }
+  return 0;
+}

@@ -1,0 +1,194 @@
+// Operator-level C-ABI entry points (include/mapnet_hip.h, "Operator-level entry points").
+#include "../../include/mapnet_hip.h"
+
+#include <string>
+
+#include "common.h"
+#include "criterion.h"
+#include "elementwise.h"
+#include "head.h"
+#include "igemm.h"
+#include "optim.h"
+#include "wgrad.h"
+#include "util.h"
+
+using namespace mn;
+
+namespace mn {
+thread_local std::string g_last_error;
+}
+
+extern "C" const char* mn_last_error(void) { return mn::g_last_error.c_str(); }
+
+#ifndef MN_BACKEND_NAME
+#define MN_BACKEND_NAME "hip"
+#endif
+extern "C" const char* mn_backend(void) { return MN_BACKEND_NAME; }
+
+static GatherGeom to_geom(const mn_gather_geom* g) {
+  GatherGeom r;
+  r.B = g->B; r.Hi = g->Hi; r.Wi = g->Wi; r.C = g->C; r.P = g->P; r.Q = g->Q; r.R = g->R; r.S = g->S;
+  r.mul_p = g->mul_p; r.mul_q = g->mul_q; r.rsign = g->rsign; r.ssign = g->ssign;
+  r.off_h = g->off_h; r.off_w = g->off_w; r.div = g->div; r.M = g->M; r.N = g->N; r.K = g->K;
+  return r;
+}
+
+static int check_geom(const GatherGeom& g, int dtype) {
+  int vec = dtype == MN_F16 ? 8 : 4;
+  if (g.C % vec != 0) return fail("igemm: C must be a multiple of the 16-byte piece");
+  if (g.K != g.R * g.S * g.C) return fail("igemm: K != R*S*C");
+  if (g.K % (4 * vec) != 0) return fail("igemm: K must be a multiple of the 64-byte K-step");
+  if (g.M != g.B * g.P * g.Q) return fail("igemm: M != B*P*Q");
+  if (g.div != 1 && g.div != 2) return fail("igemm: div must be 1 or 2");
+  return 0;
+}
+
+extern "C" int mn_op_igemm_grid_m(int M) { return igemm_grid_m(M); }
+
+extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc,
+                           float* stats, const float* bias, int relu, const void* res, const void* res_gate, float alpha,
+                           void* stream) {
+  GatherGeom g = to_geom(gg);
+  if (int e = check_geom(g, dtype)) return e;
+  Epilogue ep;
+  ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
+  ep.alpha = alpha;
+  if (dtype == MN_F16)
+    launch_igemm<half>(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream);
+  else
+    launch_igemm<float>(g, (const float*)A, (const float*)Bw, ep, (hipStream_t)stream);
+  return check_launch("igemm");
+}
+
+extern "C" int mn_op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
+                           const int32_t* colmap, float alpha, int target_blocks, void* stream) {
+  WgradArgs a;
+  a.g = to_geom(gg);
+  int vec = dtype == MN_F16 ? 8 : 4;
+  if (a.g.C % vec != 0 || a.g.N % vec != 0) return fail("wgrad: channel counts must be multiples of the piece");
+  a.dY = dY; a.ldy = ldy; a.X = X; a.dW = dW; a.ldw = ldw; a.colmap = colmap; a.alpha = alpha; a.rows_per_split = 0;
+  if (dtype == MN_F16)
+    launch_wgrad<half>(a, target_blocks, (hipStream_t)stream);
+  else
+    launch_wgrad<float>(a, target_blocks, (hipStream_t)stream);
+  return check_launch("wgrad");
+}
+
+extern "C" int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream) {
+  hipLaunchKernelGGL(oihw_ohwi_kernel, dim3(ew_grid((long)O * I * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, O,
+                     I, H, W, to_ohwi);
+  return check_launch("oihw_ohwi");
+}
+
+extern "C" int mn_op_criterion(int mode, int N, int T, const float* pred, const float* targ, const float* s, float* loss,
+                               float* dpred, float* ds, float* vos_out, float grad_scale, void* stream) {
+  if (T < 1 || T > kMaxT) return fail("criterion: T out of range");
+  if (mode < 0 || mode > 3) return fail("criterion: bad mode");
+  CriterionArgs a;
+  a.mode = mode; a.N = N; a.T = T; a.pred = pred; a.targ = targ; a.s = s; a.loss = loss; a.dpred = dpred; a.ds = ds;
+  a.vos_out = vos_out; a.grad_scale = grad_scale;
+  hipLaunchKernelGGL(criterion_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("criterion");
+}
+
+extern "C" int mn_op_calc_vos(const float* poses, int N, int T, float* vos, const float* cot, float* dposes,
+                              void* stream) {
+  if (T < 2 || T > kMaxT) return fail("calc_vos: T out of range");
+  hipLaunchKernelGGL(calc_vos_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, poses, N, T, vos, cot,
+                     dposes);
+  return check_launch("calc_vos");
+}
+
+extern "C" int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip, float lr, float wd,
+                          float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm,
+                          double* sqnorm_scratch, int eps_mode, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (max_norm > 0.f) {
+    if (!sqnorm_scratch) return fail("adam: clipping needs a scratch double");
+    hipMemsetAsync(sqnorm_scratch, 0, sizeof(double), s);
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(ew_grid(n_clip)), dim3(256), 0, s, g, (long)n_clip, sqnorm_scratch);
+  }
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.n_clip = n_clip; a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2;
+  a.eps = eps; a.bc1 = (float)(1.0 - pow((double)beta1, (double)step)); a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  a.grad_mul = grad_mul; a.max_norm = max_norm; a.sqnorm = sqnorm_scratch; a.frozen = nullptr; a.eps_mode = eps_mode;
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, s, a);
+  return check_launch("adam");
+}
+
+template <typename T>
+static int bn_train_fwd_t(const void* y, int64_t M, int C, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float* mean, float* invstd, const void* res, int relu, void* out, float eps,
+                          float momentum, double* accum, hipStream_t s) {
+  // standalone operator: statistics by a direct reduction (the network path takes them from the
+  // conv epilogue instead).  accum: [2][C] doubles + [2][C] floats of scale/shift after it.
+  hipMemsetAsync(accum, 0, 2 * C * sizeof(double), s);
+  float* scale = reinterpret_cast<float*>(accum + 2 * C);
+  float* shift = scale + C;
+  int rows_per_block = 256;
+  // reuse the backward reducer with g = y, y = 0-mean trick is not applicable; use a dedicated pass:
+  hipLaunchKernelGGL((bn_fwd_stats_kernel<T>), dim3(cdiv(M, rows_per_block)), dim3(256), 0, s, (const T*)y, (long)M, C,
+                     accum, rows_per_block);
+  BnParams p;
+  p.gamma = gamma; p.beta = beta; p.running_mean = running_mean; p.running_var = running_var;
+  p.num_batches_tracked = nullptr; p.mean = mean; p.invstd = invstd; p.scale = scale; p.shift = shift; p.eps = eps;
+  p.momentum = momentum;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, accum, C, (double)M, p, 1);
+  long np = M * C / ElemTraits<T>::VEC;
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)y, (const float*)scale,
+                     (const float*)shift, (const T*)res, (T*)out, np, C, relu);
+  return check_launch("bn_train_fwd");
+}
+
+extern "C" int mn_op_bn_train_fwd(int dtype, const void* y, int64_t M, int C, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float* mean, float* invstd, const void* res,
+                                  int relu, void* out, float eps, float momentum, double* accum_scratch, void* stream) {
+  if (dtype == MN_F16)
+    return bn_train_fwd_t<half>(y, M, C, gamma, beta, running_mean, running_var, mean, invstd, res, relu, out, eps,
+                                momentum, accum_scratch, (hipStream_t)stream);
+  return bn_train_fwd_t<float>(y, M, C, gamma, beta, running_mean, running_var, mean, invstd, res, relu, out, eps,
+                               momentum, accum_scratch, (hipStream_t)stream);
+}
+
+template <typename T>
+static int bn_bwd_t(const void* g, const void* gate, const void* y, int64_t M, int C, const float* gamma, const float* mean,
+                    const float* invstd, float* dgamma, float* dbeta, void* gy, float* coef, double* accum,
+                    float grad_unscale, hipStream_t s) {
+  launch_bn_bwd<T>((const T*)g, (const T*)gate, (const T*)y, (long)M, C, gamma, mean, invstd, dgamma, dbeta, (T*)gy, coef,
+                   accum, grad_unscale, s);
+  return check_launch("bn_bwd");
+}
+
+extern "C" int mn_op_bn_bwd(int dtype, const void* g, const void* gate, const void* y, int64_t M, int C, const float* gamma,
+                            const float* mean, const float* invstd, float* dgamma, float* dbeta, void* gy,
+                            float* coef_scratch, double* accum_scratch, float grad_unscale, void* stream) {
+  hipMemsetAsync(accum_scratch, 0, 2 * C * sizeof(double), (hipStream_t)stream);
+  if (dtype == MN_F16)
+    return bn_bwd_t<half>(g, gate, y, M, C, gamma, mean, invstd, dgamma, dbeta, gy, coef_scratch, accum_scratch,
+                          grad_unscale, (hipStream_t)stream);
+  return bn_bwd_t<float>(g, gate, y, M, C, gamma, mean, invstd, dgamma, dbeta, gy, coef_scratch, accum_scratch,
+                         grad_unscale, (hipStream_t)stream);
+}
+
+extern "C" int mn_op_maxpool_fwd(int dtype, const void* in, void* out, int B, int H, int W, int C, void* stream) {
+  int Po = (H + 2 - 3) / 2 + 1, Qo = (W + 2 - 3) / 2 + 1;
+  if (dtype == MN_F16)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<half>), dim3(ew_grid((long)B * Po * Qo * C / 8)), dim3(256), 0,
+                       (hipStream_t)stream, (const half*)in, (half*)out, B, H, W, C, Po, Qo);
+  else
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid((long)B * Po * Qo * C / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)in, (float*)out, B, H, W, C, Po, Qo);
+  return check_launch("maxpool_fwd");
+}
+
+extern "C" int mn_op_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int B, int H, int W, int C,
+                                 void* stream) {
+  int Po = (H + 2 - 3) / 2 + 1, Qo = (W + 2 - 3) / 2 + 1;
+  if (dtype == MN_F16)
+    hipLaunchKernelGGL((maxpool_bwd_kernel<half>), dim3(ew_grid((long)B * H * W * C / 8)), dim3(256), 0,
+                       (hipStream_t)stream, (const half*)in, (const half*)gout, (half*)gin, B, H, W, C, Po, Qo);
+  else
+    hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid((long)B * H * W * C / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)in, (const float*)gout, (float*)gin, B, H, W, C, Po, Qo);
+  return check_launch("maxpool_bwd");
+}

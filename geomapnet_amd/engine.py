@@ -1,0 +1,159 @@
+"""Host-side owner of the device arenas and of the mn_handle plans (plumbing, not math).
+
+PyTorch tensors are used purely as containers for HBM (parameter arena, optimiser state,
+BatchNorm buffers, per-plan work arena) and as the source of the current HIP stream; all
+arithmetic happens in libmapnet_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _binding
+from ._binding import Config, MapNetHipError, ptr
+
+MODE_POSENET, MODE_MAPNET, MODE_ONLINE, MODE_GPS = 0, 1, 2, 3
+DTYPES = {"fp32": 0, "fp16": 1}
+
+_default_dtype = "fp16"
+_default_loss_scale = 1024.0
+
+
+def set_compute_dtype(name, loss_scale=None):
+    """'fp16' (MFMA f16 operands, fp32 accumulate; the benchmark configuration) or 'fp32'
+    (v_mfma_f32_32x32x2_f32; the parity configuration)."""
+    global _default_dtype, _default_loss_scale
+    if name not in DTYPES:
+        raise ValueError(name)
+    _default_dtype = name
+    if loss_scale is not None:
+        _default_loss_scale = float(loss_scale)
+
+
+def get_compute_dtype():
+    return _default_dtype
+
+
+def _stream(t):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+class Engine:
+    """One per PoseNet: parameter/optimiser/buffer arenas + a cache of plans keyed by shape."""
+
+    def __init__(self, feat_dim, binding=None, filter_nans=False):
+        self.lib = binding if binding is not None else _binding.hip()
+        self.feat_dim = feat_dim
+        self.filter_nans = bool(filter_nans)
+        self.entries = self.lib.entries(feat_dim)
+        self.n_params = int(self.lib.model_param_floats(feat_dim))
+        self.n_model = self.n_params - 4
+        self.params = torch.zeros(self.n_params, dtype=torch.float32)
+        self.buffers = torch.zeros(int(self.lib.model_buffer_bytes(feat_dim)), dtype=torch.uint8)
+        self.opt_state = None  # [3 * n_params] grads | exp_avg | exp_avg_sq, created on first train step
+        self.plans = {}
+        self.version = 0  # bumped whenever parameters change outside a plan
+        self.step_count = 0
+        self.dtype = None  # None -> module default at plan creation
+        self.loss_scale = None
+        self.eps_mode = 0
+
+    # -- arenas ---------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.params.device
+
+    def move(self, fn):
+        """apply a tensor -> tensor function (e.g. .cuda()) to every arena; plans are dropped."""
+        new = fn(self.params)
+        if new.dtype != torch.float32:
+            raise MapNetHipError("the parameter arena is fp32; use set_compute_dtype() to choose the compute type")
+        self.drop_plans()
+        self.params = new
+        self.buffers = self.buffers.to(new.device)
+        if self.opt_state is not None:
+            self.opt_state = self.opt_state.to(new.device)
+
+    def drop_plans(self):
+        for p in self.plans.values():
+            self.lib.destroy(p["handle"])
+        self.plans = {}
+
+    def __del__(self):
+        try:
+            self.drop_plans()
+        except Exception:
+            pass
+
+    def _check_device(self):
+        if self.lib.backend_name == "hip" and not self.params.is_cuda:
+            raise MapNetHipError("the MapNet HIP path needs the model on a GPU (model.cuda()); there is no CPU fallback")
+
+    def grads(self):
+        return self.opt_state[: self.n_params]
+
+    def crit_slice(self):
+        return self.params[self.n_model:]
+
+    # -- plans ------------------------------------------------------------------------------------
+    def plan(self, mode, windows, T, H, W):
+        self._check_device()
+        dtype = self.dtype or _default_dtype
+        scale = self.loss_scale if self.loss_scale is not None else (_default_loss_scale if dtype == "fp16" else 1.0)
+        key = (mode, windows, T, H, W, dtype, scale)
+        p = self.plans.get(key)
+        if p is None:
+            if self.opt_state is None:
+                self.opt_state = torch.zeros(3 * self.n_params, dtype=torch.float32, device=self.device)
+            cfg = Config(mode=mode, dtype=DTYPES[dtype], windows=windows, T=T, H=H, W=W, feat_dim=self.feat_dim,
+                         filter_nans=int(self.filter_nans), loss_scale=scale, eps_mode=self.eps_mode)
+            nbytes = int(self.lib.plan_bytes(C.byref(cfg)))
+            if nbytes < 0:
+                raise MapNetHipError(self.lib.last_error().decode())
+            work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            h = self.lib.create(C.byref(cfg), ptr(self.params), ptr(self.opt_state), ptr(self.buffers), ptr(work),
+                                _stream(self.params))
+            if not h:
+                raise MapNetHipError(self.lib.last_error().decode())
+            frames = 1 if mode == MODE_POSENET else (T if mode == MODE_MAPNET else 2 * T)
+            p = {"handle": C.c_void_p(h), "work": work, "version": self.version, "cfg": cfg, "images": windows * frames,
+                 "loss": torch.zeros(1, dtype=torch.float32, device=self.device), "dtype": dtype}
+            self.plans[key] = p
+        if p["version"] != self.version:
+            self.lib.check(self.lib.params_changed(p["handle"]))
+            p["version"] = self.version
+        self.lib.check(self.lib.set_step_count(p["handle"], self.step_count))
+        return p
+
+    def params_touched(self):
+        self.version += 1
+
+    # -- calls --------------------------------------------------------------------------------------
+    def forward(self, images, training):
+        """images: fp32 [B,3,H,W] contiguous on the engine's device -> poses [B,6]."""
+        B, _, H, W = images.shape
+        p = self.plan(MODE_POSENET, B, 1, H, W)
+        out = torch.empty(B, 6, dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.forward(p["handle"], ptr(images), ptr(out), int(bool(training)), _stream(images)))
+        return out
+
+    def configure_step(self, p, lr, weight_decay, betas, eps, max_grad_norm, learn_beta, learn_gamma):
+        h = p["handle"]
+        self.lib.check(self.lib.set_optim(h, lr, weight_decay, betas[0], betas[1], eps, max_grad_norm))
+        flags = (bool(learn_beta), bool(learn_gamma))
+        if p.get("flags") != flags:
+            self.lib.check(self.lib.set_learn_flags(h, int(flags[0]), int(flags[1])))
+            p["flags"] = flags
+
+    def train_step(self, p, images, targets):
+        poses = torch.empty(p["images"], 6, dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.train_step(p["handle"], ptr(images), ptr(targets), ptr(p["loss"]), ptr(poses),
+                                           _stream(images)))
+        self._stepped(p)
+        return p["loss"], poses
+
+    def _stepped(self, p):
+        self.step_count += 1
+        self.version += 1
+        p["version"] = self.version  # this plan repacks by itself after its own optimiser step

@@ -1,0 +1,65 @@
+"""`step_feedfwd`: one training / validation step, API of /root/reference/common/train.py:322-363.
+
+Train branch = ONE fused library call (mn_train_step): H2D copy aside, forward, criterion,
+zero_grad, backward, optional clip_grad_norm, Adam -- then `loss.item()` (the same blocking
+read-back the reference does at :361).  With torch.distributed initialised (world > 1) the step
+is issued in stages so each gradient bucket's RCCL all-reduce overlaps the remaining backward
+(geomapnet_amd/dp.py).
+"""
+import torch
+
+from .criterion import _Criterion
+from .engine import MODE_POSENET
+from .posenet import MapNet, engine_of
+from . import dp
+
+
+def _bind(engine, criterion, optim):
+    store = engine.crit_slice()
+    if criterion._store.data_ptr() != store.data_ptr():
+        criterion._rebind(store)
+    if optim is not None and getattr(optim.learner, "_engine", None) is not engine:
+        optim.learner._attach(engine)
+
+
+def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, train=True, max_grad_norm=0.0):
+    if train:
+        assert criterion is not None
+    engine = engine_of(model)
+    dev = engine.device
+    data = data.to(dev, non_blocking=True) if data.device != dev else data
+    if not train or criterion is None:
+        was = model.training
+        output = model(data)
+        if criterion is None:
+            return 0, output
+        loss = criterion(output, target.to(dev, non_blocking=True))
+        return loss.item(), output
+
+    if not isinstance(criterion, _Criterion):
+        raise TypeError("step_feedfwd(train=True) needs a geomapnet_amd criterion")
+    if not model.training:
+        raise RuntimeError("step_feedfwd(train=True) on a model in eval mode")
+    target = target.to(dev, non_blocking=True).float().contiguous()
+    data = data.float().contiguous()
+    mode = criterion.mode
+    if mode == MODE_POSENET:
+        if data.dim() != 4:
+            raise ValueError("PoseNet training expects data [N,3,H,W]")
+        n, t = data.shape[0], 1
+    else:
+        if data.dim() != 5 or not isinstance(model, MapNet):
+            raise ValueError("MapNet training expects a MapNet model and data [N,T,3,H,W]")
+        n = data.shape[0]
+        t = data.shape[1] if mode == 1 else data.shape[1] // 2
+    H, W = data.shape[-2], data.shape[-1]
+    _bind(engine, criterion, optim)
+    plan = engine.plan(mode, n, t, H, W)
+    lr, wd, betas, eps = optim.learner.hyper()
+    engine.configure_step(plan, lr, wd, betas, eps, float(max_grad_norm), criterion.learn_beta, criterion.learn_gamma)
+    if dp.world_size() > 1:
+        loss, poses = dp.train_step(engine, plan, data, target)
+    else:
+        loss, poses = engine.train_step(plan, data, target)
+    output = poses.view(n, -1, 6) if mode != MODE_POSENET else poses
+    return loss.item(), output

@@ -1,0 +1,179 @@
+/*
+ * mapnet_hip.h -- C ABI of libmapnet_hip.so, the gfx950 (MI355X) implementation of the MapNet
+ * training hot path of NVlabs/geomapnet.
+ *
+ * The reference has no FFI for this path (it is plain PyTorch 0.4.1 Python); the
+ * boundary a drop-in replaces is the Python surface that scripts/train.py, scripts/eval.py and
+ * common/train.py consume.  Each entry point below names the reference interface it stands
+ * behind (paths relative to /root/reference).  The Python mirror of that surface lives in
+ * geomapnet_amd/ and binds these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All tensor pointers are DEVICE pointers
+ *     (HBM) owned by the caller; the library never allocates device memory: the caller hands
+ *     it arenas sized by mn_model_layout() / mn_plan_bytes().
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); every call only
+ *     enqueues work on that stream and returns (asynchronous, like the reference until its
+ *     loss.item() at common/train.py:361).
+ *   - return value: 0 on success, non-zero on error; mn_last_error() gives the message.
+ *     No exceptions cross the ABI.
+ *   - one mn_handle per device per (mode, batch, H, W, dtype); not thread-safe per handle.
+ */
+#ifndef MAPNET_HIP_H
+#define MAPNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1 };
+/* criterion / batch-layout modes */
+enum {
+  MN_MODE_POSENET = 0,      /* PoseNetCriterion,        common/criterion.py:33-52   */
+  MN_MODE_MAPNET = 1,       /* MapNetCriterion,         common/criterion.py:54-109  */
+  MN_MODE_MAPNET_ONLINE = 2,/* MapNetOnlineCriterion,   common/criterion.py:111-184 */
+  MN_MODE_MAPNET_GPS = 3    /* ... with gps_mode=True,  common/criterion.py:166,173-180 */
+};
+
+const char* mn_last_error(void);
+/* "hip" for the product library; the test-only SIMT-emulator build reports "emu". */
+const char* mn_backend(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Model parameter layout.  Replaces: torchvision resnet34 + PoseNet.__init__ parameter
+ * registration (models/posenet.py:37-63) and the state_dict key set.
+ * Parameters live in ONE flat fp32 arena (conv weights stored OHWI, everything else in the
+ * reference's own layout) followed by the four criterion scalars sax,saq,srx,srq; buffers
+ * (BatchNorm running stats, num_batches_tracked as int64) live in a second arena.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mn_entry {
+  char name[96];      /* state_dict key, e.g. "feature_extractor.layer1.0.conv1.weight" */
+  int64_t offset;     /* element offset (fp32 elements; bytes/8 for int64 buffers) in its arena */
+  int64_t numel;
+  int32_t ndim;
+  int32_t shape[4];   /* reference (torch) shape, e.g. OIHW for conv weights */
+  int32_t is_buffer;  /* 0: parameter arena, 1: buffer arena */
+  int32_t is_int64;   /* num_batches_tracked */
+  int32_t ohwi;       /* 1: stored OHWI; the torch view is arena.view(O,H,W,I).permute(0,3,1,2) */
+  int32_t stage;      /* data-parallel gradient bucket: 0 stem+layer1, 1 layer2, 2 layer3, 3 layer4+head */
+} mn_entry;
+
+int mn_model_entries(int feat_dim);                       /* number of entries              */
+int mn_model_entry(int feat_dim, int idx, mn_entry* out); /* idx-th entry in state_dict order */
+int64_t mn_model_param_floats(int feat_dim);              /* parameter arena size incl. 4 criterion scalars */
+int64_t mn_model_buffer_bytes(int feat_dim);              /* buffer arena size in bytes       */
+
+/* ------------------------------------------------------------------------------------------
+ * Training / inference plan.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mn_config {
+  int32_t mode;        /* MN_MODE_* */
+  int32_t dtype;       /* MN_DTYPE_*: storage type of activations and conv operands */
+  int32_t windows;     /* N: windows per step on this device (PoseNet: images) */
+  int32_t T;           /* frames per window (PoseNet: 1; MapNet++: T, images per window = 2T) */
+  int32_t H, W;        /* image size */
+  int32_t feat_dim;    /* 2048 */
+  int32_t filter_nans; /* models/posenet.py:50-51 */
+  float loss_scale;    /* static loss scale for fp16 gradients (1 for fp32) */
+  int32_t eps_mode;    /* Adam epsilon placement: 0 torch>=1.0, 1 torch 0.4.1 */
+} mn_config;
+
+typedef struct mn_handle mn_handle;
+
+int64_t mn_plan_bytes(const mn_config* cfg); /* work arena bytes (activations, gradients, scratch) */
+
+/* params: fp32 [param_floats]; opt_state: fp32 [3*param_floats] = grads | exp_avg | exp_avg_sq;
+ * buffers: [buffer_bytes]; work: [plan_bytes].  Arenas must outlive the handle. */
+mn_handle* mn_create(const mn_config* cfg, float* params, float* opt_state, void* buffers, void* work,
+                     void* stream);
+void mn_destroy(mn_handle* h);
+
+/* Criterion log-weights live at params[param_floats-4 ..]; which of them Adam may update:
+ * replaces `learn_beta` / `learn_gamma` (common/criterion.py:39-40,71-74; scripts/train.py:104-112) */
+int mn_set_learn_flags(mn_handle* h, int learn_beta, int learn_gamma);
+
+/* replaces Optimizer(params, 'adam', base_lr, weight_decay, **kw) (common/optimizer.py:12-23)
+ * and max_grad_norm (common/train.py:357-358) */
+int mn_set_optim(mn_handle* h, float lr, float weight_decay, float beta1, float beta2, float eps,
+                 float max_grad_norm);
+int mn_set_step_count(mn_handle* h, int64_t step); /* Adam step counter (checkpoint resume) */
+int64_t mn_get_step_count(mn_handle* h);
+
+/* replaces model(data_var) in step_feedfwd (common/train.py:343) = MapNet.forward / PoseNet.forward
+ * (models/posenet.py:65-73,87-97).  images: fp32 NCHW [windows*frames][3][H][W] on device;
+ * poses_out: fp32 [windows*frames][6].  training!=0 uses batch statistics and updates running
+ * stats (model.train()), else running statistics (model.eval()). */
+int mn_forward(mn_handle* h, const float* images, float* poses_out, int training, void* stream);
+
+/* replaces criterion(output, target) (common/train.py:351): loss only, on given predictions */
+int mn_loss(mn_handle* h, const float* pred, const float* targ, float* loss_out, void* stream);
+
+/* replaces the train branch of step_feedfwd (common/train.py:343-361): forward, criterion,
+ * zero_grad, backward, clip, Adam step.  loss_out: device fp32[1]; poses_out: device fp32. */
+int mn_train_step(mn_handle* h, const float* images, const float* targets, float* loss_out, float* poses_out,
+                  void* stream);
+
+/* The same step in pieces, so a data-parallel host can all-reduce gradient bucket `stage`
+ * (RCCL) while the remaining backward stages run.  Order: forward_loss, backward stage 3,2,1,0,
+ * then optim_step(grad_mul = 1/world). */
+int mn_train_forward_loss(mn_handle* h, const float* images, const float* targets, float* loss_out,
+                          float* poses_out, void* stream);
+int mn_train_backward_stage(mn_handle* h, int stage, void* stream);
+int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t* count); /* range in the grads arena */
+int mn_optim_step(mn_handle* h, float grad_mul, void* stream);
+
+/* parameters changed behind the library's back (load_state_dict): refresh compute copies */
+int mn_params_changed(mn_handle* h);
+
+/* timing of the dominant kernel class inside the last mn_train_step (HIP events on `stream`).
+ * which: 0 = all conv MFMA kernels (forward + data-gradient + weight-gradient). */
+int mn_set_profiling(mn_handle* h, int enable);
+int mn_last_kernel_ms(mn_handle* h, int which, float* ms, int* launches);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points (used by the parity tests and usable on their own).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mn_gather_geom {
+  int32_t B, Hi, Wi, C, P, Q, R, S, mul_p, mul_q, rsign, ssign, off_h, off_w, div, M, N, K;
+} mn_gather_geom;
+
+/* out[m][n] = alpha * sum_k gather(A)[m][k] * Bw[n][k] (+bias, relu, residual): conv forward /
+ * data-gradient / linear.  stats: [mn_op_igemm_grid_m(M)][2][N] fp32 partial column sums or NULL */
+int mn_op_igemm(int dtype, const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
+                const float* bias, int relu, const void* res, const void* res_gate, float alpha, void* stream);
+int mn_op_igemm_grid_m(int M);
+/* dW[n][colmap(k)] += alpha * sum_m dY[m][n] * gather(X)[m][k]  (fp32 atomics into dW) */
+int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw,
+                const int32_t* colmap, float alpha, int target_blocks, void* stream);
+/* conv weight layout helpers: OIHW fp32 <-> OHWI fp32 */
+int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream);
+
+/* criteria: replaces PoseNetCriterion/MapNetCriterion/MapNetOnlineCriterion.forward + autograd
+ * backward (common/criterion.py).  s: device fp32[4].  dpred/ds/vos_out may be NULL. */
+int mn_op_criterion(int mode, int N, int T, const float* pred, const float* targ, const float* s, float* loss,
+                    float* dpred, float* ds, float* vos_out, float grad_scale, void* stream);
+/* replaces pose_utils.calc_vos (common/pose_utils.py:248-260) and its autograd VJP */
+int mn_op_calc_vos(const float* poses, int N, int T, float* vos, const float* cot, float* dposes, void* stream);
+
+/* fused Adam over a flat range; replaces torch.optim.Adam.step + clip_grad_norm */
+int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip, float lr, float wd,
+               float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm, double* sqnorm_scratch,
+               int eps_mode, void* stream);
+
+/* elementwise / reduction operators (NHWC, C multiple of 16 bytes) */
+int mn_op_bn_train_fwd(int dtype, const void* y, int64_t M, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* mean, float* invstd, const void* res,
+                       int relu, void* out, float eps, float momentum, double* accum_scratch, void* stream);
+int mn_op_bn_bwd(int dtype, const void* g, const void* gate, const void* y, int64_t M, int C, const float* gamma,
+                 const float* mean, const float* invstd, float* dgamma, float* dbeta, void* gy, float* coef_scratch,
+                 double* accum_scratch, float grad_unscale, void* stream);
+int mn_op_maxpool_fwd(int dtype, const void* in, void* out, int B, int H, int W, int C, void* stream);
+int mn_op_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int B, int H, int W, int C,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPNET_HIP_H */

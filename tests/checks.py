@@ -1,0 +1,419 @@
+"""Backend-agnostic parity checks.  Each takes a Binding (`lib`) and a torch device: the CPU suite
+runs them on the SIMT-emulator build of the kernels (tests/test_emu_*.py), the GPU suite runs the
+same checks on libmapnet_hip.so (tests/test_gpu_*.py, -m gpu).  References: torch CPU ops in fp64
+(for single operators), the oracle (for the criteria / train step) and the committed golden vectors.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import oracle
+from geomapnet_amd._binding import GatherGeom, ptr
+from geomapnet_amd.posenet import _view
+
+TD = {0: torch.float32, 1: torch.float16}
+# output rounding of the storage type relative to the largest output magnitude
+OUT_TOL = {0: 2e-5, 1: 2e-3}
+
+
+def f32(x):
+    return C.c_float(float(x))
+
+
+_KEEP = []
+
+
+def K(t):
+    """pointer of a (possibly temporary) tensor, kept alive until the next check starts"""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    return ptr(t)
+
+
+def _fresh():
+    del _KEEP[:]
+
+
+def dev_sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def fwd_geom(B, H, W, Cin, Cout, k, stride, pad):
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    g = GatherGeom(B=B, Hi=H, Wi=W, C=Cin, P=Ho, Q=Wo, R=k, S=k, mul_p=stride, mul_q=stride, rsign=1, ssign=1,
+                   off_h=-pad, off_w=-pad, div=1, M=B * Ho * Wo, N=Cout, K=k * k * Cin)
+    return g, Ho, Wo
+
+
+def dgrad_geom(B, H, W, Cin, Cout, k, stride, pad):
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return GatherGeom(B=B, Hi=Ho, Wi=Wo, C=Cout, P=H, Q=W, R=k, S=k, mul_p=1, mul_q=1, rsign=-1, ssign=-1, off_h=pad,
+                      off_w=pad, div=stride, M=B * H * W, N=Cin, K=k * k * Cout), Ho, Wo
+
+
+def _nhwc(x, td, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(td).to(dev)
+
+
+def check_conv_fwd(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, seed=0):
+    _fresh()
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(td).float()
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) * (2.0 / (Cin * k * k)) ** 0.5).to(td).float()
+    ref = F.conv2d(x.double(), w.double(), stride=stride, padding=pad)
+    g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, k, stride, pad)
+    xn, wn = _nhwc(x, td, dev), _nhwc(w, td, dev)
+    out = torch.zeros(B, Ho, Wo, Cout, dtype=td, device=dev)
+    gm = lib.op_igemm_grid_m(g.M)
+    st = torch.zeros(gm, 2, Cout, device=dev)
+    lib.check(lib.op_igemm(dtype, C.byref(g), K(xn), K(wn), K(out), Cout, K(st), None, 0, None, None, f32(1), None))
+    dev_sync(dev)
+    o = out.cpu().double().permute(0, 3, 1, 2)
+    scale = ref.abs().max().item()
+    assert (o - ref).abs().max().item() <= OUT_TOL[dtype] * scale + 1e-6
+    s1, s2 = st[:, 0].sum(0).cpu().double(), st[:, 1].sum(0).cpu().double()
+    n = B * Ho * Wo
+    assert (s1 - ref.sum((0, 2, 3))).abs().max().item() <= 1e-4 * scale * n ** 0.5 + 1e-4
+    assert ((s2 - (ref ** 2).sum((0, 2, 3))).abs() / (ref ** 2).sum((0, 2, 3))).max().item() <= 1e-4
+
+
+def check_conv_dgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, with_res=True, seed=1):
+    _fresh()
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(seed)
+    g, Ho, Wo = dgrad_geom(B, H, W, Cin, Cout, k, stride, pad)
+    gy = torch.randn(B, Cout, Ho, Wo, generator=gen).to(td).float()
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.1).to(td).float()
+    x = torch.zeros(B, Cin, H, W, dtype=torch.double, requires_grad=True)
+    F.conv2d(x, w.double(), stride=stride, padding=pad).backward(gy.double())
+    want = x.grad.permute(0, 2, 3, 1)
+    wt = w.permute(1, 2, 3, 0).contiguous().to(td).to(dev)  # [Cin][R][S][Cout]
+    res = gate = None
+    if with_res:
+        res = torch.randn(B, H, W, Cin, generator=gen).to(td)
+        gate = torch.randn(B, H, W, Cin, generator=gen).to(td)
+        want = want + torch.where(gate.double() > 0, res.double(), torch.zeros_like(res.double()))
+        res, gate = res.to(dev), gate.to(dev)
+    out = torch.zeros(B, H, W, Cin, dtype=td, device=dev)
+    lib.check(lib.op_igemm(dtype, C.byref(g), K(_nhwc(gy, td, dev)), K(wt), K(out), Cin, None, None, 0, K(res),
+                           K(gate), f32(1), None))
+    dev_sync(dev)
+    assert (out.cpu().double() - want).abs().max().item() <= OUT_TOL[dtype] * want.abs().max().item() + 1e-6
+
+
+def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target_blocks=8, seed=2):
+    _fresh()
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(seed)
+    g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, k, stride, pad)
+    gy = torch.randn(B, Cout, Ho, Wo, generator=gen).to(td).float()
+    x = torch.randn(B, Cin, H, W, generator=gen).to(td).float()
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), w, stride=stride, padding=pad).backward(gy.double())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)
+    dW = torch.zeros(Cout, k * k * Cin, device=dev)
+    lib.check(lib.op_wgrad(dtype, C.byref(g), K(_nhwc(gy, td, dev)), Cout, K(_nhwc(x, td, dev)), K(dW), k * k * Cin,
+                           None, f32(0.5), target_blocks, None))
+    dev_sync(dev)
+    assert (dW.cpu().double() - 0.5 * ref).abs().max().item() <= 2e-5 * ref.abs().max().item() * max(1, (B * Ho * Wo) ** 0.5 / 8)
+
+
+def stem_geom(B, H, W):
+    """the plan's stem: 7x7/2 pad 3 conv as a 7x4 conv over pixel pairs of the zero-padded NHWC4 image"""
+    Hp, Wp = H + 6, (W + 8) & ~1
+    H0, W0 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = GatherGeom(B=B, Hi=Hp, Wi=Wp // 2, C=8, P=H0, Q=W0, R=7, S=4, mul_p=2, mul_q=1, rsign=1, ssign=1, off_h=0, off_w=0,
+                   div=1, M=B * H0 * W0, N=64, K=224)
+    return g, Hp, Wp, H0, W0
+
+
+def check_stem(lib, dev, dtype, B, H, W, seed=3):
+    """stem forward + weight gradient through the padded pixel-pair formulation vs conv2d(7,2,3)"""
+    _fresh()
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, H, W, generator=gen).to(td).float()
+    w = (torch.randn(64, 3, 7, 7, generator=gen) * 0.1).to(td).float()
+    g, Hp, Wp, H0, W0 = stem_geom(B, H, W)
+    xp = torch.zeros(B, Hp, Wp, 4)
+    xp[:, 3:3 + H, 3:3 + W, :3] = x.permute(0, 2, 3, 1)
+    wc = torch.zeros(64, 7, 8, 4)
+    wc[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wd = w.double().clone().requires_grad_(True)
+    ref = F.conv2d(x.double(), wd, stride=2, padding=3)
+    assert ref.shape[2] == H0 and ref.shape[3] == W0
+    out = torch.zeros(B, H0, W0, 64, dtype=td, device=dev)
+    lib.check(lib.op_igemm(dtype, C.byref(g), K(xp.to(td).to(dev)), K(wc.reshape(64, 224).to(td).to(dev)), K(out), 64,
+                           None, None, 0, None, None, f32(1), None))
+    dev_sync(dev)
+    assert (out.cpu().double().permute(0, 3, 1, 2) - ref).abs().max().item() <= OUT_TOL[dtype] * ref.abs().max().item()
+    gy = torch.randn(B, 64, H0, W0, generator=gen).to(td).float()
+    ref.backward(gy.double())
+    cm = torch.full((224,), -1, dtype=torch.int32)
+    for r in range(7):
+        for s4 in range(4):
+            for e in range(8):
+                sp, ch = 2 * s4 + (e >> 2), e & 3
+                if sp < 7 and ch < 3:
+                    cm[(r * 4 + s4) * 8 + e] = (r * 7 + sp) * 3 + ch
+    dW = torch.zeros(64, 147, device=dev)
+    lib.check(lib.op_wgrad(dtype, C.byref(g), K(_nhwc(gy, td, dev)), 64, K(xp.to(td).to(dev)), K(dW), 147,
+                           K(cm.to(dev)), f32(1), 16, None))
+    dev_sync(dev)
+    want = wd.grad.permute(0, 2, 3, 1).reshape(64, 147)
+    assert (dW.cpu().double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+def check_bn(lib, dev, dtype, M, Cc, relu=True, with_res=True, gate=True, seed=4):
+    """training-mode BatchNorm forward (+residual, ReLU) and backward vs torch autograd in fp64"""
+    _fresh()
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(seed)
+    y = (torch.randn(M, Cc, generator=gen) * 1.5 + 0.3).to(td)
+    res = torch.randn(M, Cc, generator=gen).to(td) if with_res else None
+    gamma, beta = torch.rand(Cc, generator=gen) + 0.5, torch.randn(Cc, generator=gen)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    yd = y.double().clone().requires_grad_(True)
+    gd, bd = gamma.double().clone().requires_grad_(True), beta.double().clone().requires_grad_(True)
+    rmd, rvd = rm.double().clone(), rv.double().clone()
+    z = F.batch_norm(yd, rmd, rvd, gd, bd, training=True, momentum=0.1, eps=1e-5)
+    if with_res:
+        z = z + res.double()
+    o_ref = F.relu(z) if relu else z
+    mean, invstd = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    out = torch.zeros(M, Cc, dtype=td, device=dev)
+    scratch = torch.zeros(2 * Cc * 8 + 2 * Cc * 4, dtype=torch.uint8, device=dev)
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    yv = y.to(dev)
+    lib.check(lib.op_bn_train_fwd(dtype, K(yv), M, Cc, K(gamma.to(dev)), K(beta.to(dev)), K(rm_d), K(rv_d), K(mean),
+                                  K(invstd), K(res.to(dev)) if with_res else None, int(relu), K(out), f32(1e-5), f32(0.1),
+                                  K(scratch), None))
+    dev_sync(dev)
+    tol = OUT_TOL[dtype] * o_ref.abs().max().item() + 1e-5
+    assert (out.cpu().double() - o_ref).abs().max().item() <= tol
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rmd.numpy(), atol=1e-5)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rvd.numpy(), rtol=1e-5, atol=1e-5)
+    # backward with the device's own stored output as ReLU gate
+    g_out = torch.randn(M, Cc, generator=gen).to(td)
+    outq = out.cpu().double()
+    gm = g_out.double() * (outq > 0).double() if (relu and gate) else g_out.double()
+    z2 = F.batch_norm(yd, rmd.clone(), rvd.clone(), gd, bd, training=True, momentum=0.1, eps=1e-5)
+    z2.backward(gm)
+    dgamma, dbeta = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    gy = torch.zeros(M, Cc, dtype=td, device=dev)
+    coef = torch.zeros(3 * Cc, device=dev)
+    acc = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+    lib.check(lib.op_bn_bwd(dtype, K(g_out.to(dev)), K(out) if (relu and gate) else None, K(yv), M, Cc, K(gamma.to(dev)),
+                            K(mean), K(invstd), K(dgamma), K(dbeta), K(gy), K(coef), K(acc), f32(1.0), None))
+    dev_sync(dev)
+    assert (gy.cpu().double() - yd.grad).abs().max().item() <= OUT_TOL[dtype] * yd.grad.abs().max().item() * 2 + 1e-6
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gd.grad.numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), bd.grad.numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
+    assert float(acc.abs().max()) == 0.0  # accumulators are handed back zeroed
+
+
+def check_maxpool(lib, dev, dtype, B, H, W, Cc, seed=5, ties=False):
+    _fresh()
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cc, H, W, generator=gen)
+    if ties:
+        x = torch.relu(x).round()  # many equal values and zeros: first-max routing matters
+    x = x.to(td).float()
+    xd = x.double().clone().requires_grad_(True)
+    ref = F.max_pool2d(xd, 3, 2, 1)
+    Po, Qo = ref.shape[2], ref.shape[3]
+    xn = _nhwc(x, td, dev)
+    out = torch.zeros(B, Po, Qo, Cc, dtype=td, device=dev)
+    lib.check(lib.op_maxpool_fwd(dtype, K(xn), K(out), B, H, W, Cc, None))
+    dev_sync(dev)
+    assert torch.equal(out.cpu().double().permute(0, 3, 1, 2), ref.detach())
+    go = torch.randn(B, Cc, Po, Qo, generator=gen).to(td).float()
+    ref.backward(go.double())
+    gin = torch.zeros(B, H, W, Cc, dtype=td, device=dev)
+    lib.check(lib.op_maxpool_bwd(dtype, K(xn), K(_nhwc(go, td, dev)), K(gin), B, H, W, Cc, None))
+    dev_sync(dev)
+    want = xd.grad.permute(0, 2, 3, 1)
+    assert (gin.cpu().double() - want).abs().max().item() <= OUT_TOL[dtype] * max(1.0, want.abs().max().item())
+
+
+# ---- criteria ---------------------------------------------------------------------------------------
+def golden_cases(golden_dir, name="criteria.npz"):
+    z = np.load(os.path.join(golden_dir, name))
+    out = {}
+    for k in z.files:
+        c, f = k.split("/")
+        out.setdefault(c, {})[f] = z[k]
+    return out
+
+
+def run_criterion(lib, dev, mode, pred, targ, s4, grad_scale=1.0, want_vos=False):
+    pred, targ = pred.float().contiguous().to(dev), targ.float().contiguous().to(dev)
+    n = pred.shape[0]
+    T = 1 if mode == 0 else (pred.shape[1] if mode == 1 else pred.shape[1] // 2)
+    loss = torch.zeros(1, device=dev)
+    dp = torch.zeros_like(pred)
+    ds = torch.zeros(4, device=dev)
+    vos = torch.zeros(n, max(T - 1, 1), 6, device=dev) if want_vos else None
+    lib.check(lib.op_criterion(mode, n, T, K(pred), K(targ), K(torch.tensor(s4, dtype=torch.float32, device=dev)),
+                               K(loss), K(dp), K(ds), K(vos), f32(grad_scale), None))
+    dev_sync(dev)
+    return loss.item(), dp.cpu(), ds.cpu(), (vos.cpu() if want_vos else None)
+
+
+def check_criterion_golden(lib, dev, golden_dir):
+    _fresh()
+    cases = golden_cases(golden_dir)
+    for name, d in cases.items():
+        mode = 0 if name.startswith("posenet") else 1 if name.startswith("mapnet") else 3 if name.startswith("gps") else 2
+        s4 = [float(d.get("s_" + n, 0.0)) for n in ("sax", "saq", "srx", "srq")]
+        loss, dp, ds, _ = run_criterion(lib, dev, mode, torch.from_numpy(d["pred"]), torch.from_numpy(d["targ"]), s4)
+        assert abs(loss - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"]))), name
+        want = d["dpred"]
+        if name == "online_nan":
+            # same NaN pattern as the reference's autograd; finite entries agree
+            assert np.array_equal(np.isnan(dp.numpy()), np.isnan(want)), name
+            m = ~np.isnan(want)
+            np.testing.assert_allclose(dp.numpy()[m], want[m], rtol=1e-4, atol=1e-6, err_msg=name)
+            continue
+        np.testing.assert_allclose(dp.numpy(), want, rtol=2e-4, atol=2e-6, err_msg=name)
+        for i, n in enumerate(("sax", "saq", "srx", "srq")):
+            if "d_" + n in d:
+                assert abs(ds[i].item() - float(d["d_" + n])) <= 1e-4 * max(1.0, abs(float(d["d_" + n]))), (name, n)
+
+
+def check_calc_vos_golden(lib, dev, golden_dir):
+    _fresh()
+    z = np.load(os.path.join(golden_dir, "pose_algebra.npz"))
+    poses = torch.from_numpy(z["poses"]).float().to(dev)
+    cot = torch.from_numpy(z["cot"]).float().to(dev)
+    N, T = poses.shape[0], poses.shape[1]
+    vos = torch.zeros(N, T - 1, 6, device=dev)
+    dpo = torch.zeros_like(poses)
+    lib.check(lib.op_calc_vos(K(poses), N, T, K(vos), K(cot), K(dpo), None))
+    dev_sync(dev)
+    np.testing.assert_allclose(vos.cpu().numpy(), z["calc_vos"], atol=2e-6)
+    np.testing.assert_allclose(dpo.cpu().numpy(), z["calc_vos_vjp"], rtol=1e-4, atol=2e-5)
+    # identity: the relative pose of a pose w.r.t. itself is zero (pose_utils.calc_vo_logq(p, p))
+    same = poses[:, :1].repeat(1, 2, 1).contiguous()
+    v2 = torch.zeros(N, 1, 6, device=dev)
+    lib.check(lib.op_calc_vos(K(same), N, 2, K(v2), None, None, None))
+    dev_sync(dev)
+    assert float(v2.abs().max()) < 1e-6
+
+
+def check_adam(lib, dev, n=10007, steps=3, max_norm=0.0, wd=5e-4, seed=6):
+    _fresh()
+    gen = torch.Generator().manual_seed(seed)
+    p0 = torch.randn(n, generator=gen)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3, weight_decay=wd)
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    sq = torch.zeros(1, dtype=torch.float64, device=dev)
+    for step in range(1, steps + 1):
+        g = torch.randn(n, generator=gen) * (5.0 if step == 1 else 0.1)
+        pt.grad = g.clone()
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([pt], max_norm)
+        opt.step()
+        lib.check(lib.op_adam(K(p), K(g.to(dev)), K(m), K(v), n, n, f32(1e-3), f32(wd), f32(0.9), f32(0.999), f32(1e-8),
+                              step, f32(1.0), f32(max_norm), K(sq), 0, None))
+        dev_sync(dev)
+        np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), rtol=1e-5, atol=2e-6)
+
+
+# ---- whole network --------------------------------------------------------------------------------------
+def build_pair(lib, dev, seed=7, filter_nans=False):
+    import geomapnet_amd as G
+    torch.manual_seed(seed)
+    onet = oracle.MapNet(oracle.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False, filter_nans=filter_nans))
+    net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, filter_nans=filter_nans, _binding=lib))
+    net.load_state_dict(onet.state_dict())
+    if torch.device(dev).type == "cuda":
+        net.cuda()
+    return onet, net
+
+
+def grad_views(net):
+    eng = net.mapnet._engine
+    return {e.name.decode(): _view(eng.grads(), e) for e in eng.entries if not e.is_buffer}
+
+
+def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps=1, max_grad_norm=0.0, lr=1e-4, wd=5e-4,
+                     loss_rtol=1e-4, pose_atol=1e-3, grad_l2_rtol=2e-2, gps=False, filter_nans=False):
+    """one (or more) full training steps, HIP library vs the oracle on identical inputs and weights"""
+    _fresh()
+    import geomapnet_amd as G
+    G.set_compute_dtype(dtype_name)
+    onet, net = build_pair(lib, dev, filter_nans=filter_nans)
+    x, t = oracle.make_batch(mode, N, H, W, seed=7, gps_mode=gps)
+    if mode == "posenet":
+        onet, net = onet.mapnet, net.mapnet
+        oc = oracle.PoseNetCriterion(0.0, -3.0, True)
+        c = G.PoseNetCriterion(sax=0.0, saq=-3.0, learn_beta=True, _binding=lib)
+        og = [{"params": onet.parameters()}, {"params": [oc.sax, oc.saq]}]
+        gg = [{"params": net.parameters()}, {"params": [c.sax, c.saq]}]
+    else:
+        if mode == "mapnet":
+            oc = oracle.MapNetCriterion(0.0, -3.0, 0.0, -3.0, True, True)
+            c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+        else:
+            oc = oracle.MapNetOnlineCriterion(0.0, -3.0, 0.0, -3.0, True, True, gps_mode=gps)
+            c = G.MapNetOnlineCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, gps_mode=gps,
+                                        _binding=lib)
+        og = [{"params": onet.parameters()}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}]
+        gg = [{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}]
+    oopt = oracle.Optimizer(og, "adam", base_lr=lr, weight_decay=wd)
+    opt = G.Optimizer(gg, "adam", base_lr=lr, weight_decay=wd)
+    onet.train()
+    net.train()
+    report = []
+    for step in range(steps):
+        lo, po = oracle.step_feedfwd(x, onet, False, t, oc, oopt, True, max_grad_norm)
+        l, p = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True, max_grad_norm)
+        pose_err = (p.cpu() - po.detach()).abs().max().item()
+        report.append((l, lo, pose_err))
+        assert abs(l - lo) <= loss_rtol * max(1.0, abs(lo)), (step, l, lo)
+        assert pose_err <= pose_atol * max(1.0, po.abs().max().item()), (step, pose_err)
+        if step == 0 and grad_l2_rtol is not None and max_grad_norm == 0.0:
+            eng = (net.mapnet if hasattr(net, "mapnet") else net)._engine
+            prefix = "mapnet." if hasattr(onet, "mapnet") else ""
+            og_ = dict(onet.named_parameters())
+            worst = 0.0
+            for e in eng.entries:
+                if e.is_buffer:
+                    continue
+                name = e.name.decode()
+                g = _view(eng.grads(), e).cpu().double()
+                r = og_[prefix + name].grad.double()
+                if r.norm() < 1e-8:
+                    continue
+                worst = max(worst, ((g - r).norm() / r.norm()).item())
+            assert worst <= grad_l2_rtol, worst
+            cg = eng.grads()[-4:].cpu().numpy()
+            names = ("sax", "saq", "srx", "srq")
+            for i, nm in enumerate(names):
+                if hasattr(oc, nm):
+                    assert abs(cg[i] - getattr(oc, nm).grad.item()) <= 1e-3 * max(1.0, abs(getattr(oc, nm).grad.item()))
+    return report
+
+
+def check_eval_forward(lib, dev, dtype_name, B=3, H=64, W=85, atol=1e-3):
+    _fresh()
+    import geomapnet_amd as G
+    G.set_compute_dtype(dtype_name)
+    onet, net = build_pair(lib, dev)
+    onet, net = onet.mapnet, net.mapnet
+    x, _ = oracle.make_batch("posenet", B, H, W, seed=11)
+    onet.eval()
+    net.eval()
+    with torch.no_grad():
+        ref = onet(x)
+    out = net(x.to(dev))
+    assert (out.cpu() - ref).abs().max().item() <= atol * max(1.0, ref.abs().max().item())

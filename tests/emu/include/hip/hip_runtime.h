@@ -276,3 +276,9 @@ inline emu_floatx4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_fl
 
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+
+// integer min/max exist as device overloads in HIP
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
+inline long min(long a, long b) { return a < b ? a : b; }
+inline long max(long a, long b) { return a > b ? a : b; }

@@ -1,0 +1,81 @@
+"""CPU suite: every kernel of geomapnet_amd/csrc executed through the SIMT emulator build and
+checked against torch fp64 / the oracle / the golden vectors (tests/checks.py)."""
+import pytest
+
+import checks
+import emu_lib
+
+DEV = "cpu"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib.load()
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [
+    (2, 9, 11, 64, 64, 3, 1, 1),     # layer1-like, BN=64 tile
+    (2, 9, 11, 64, 128, 3, 2, 1),    # stride-2 3x3
+    (1, 8, 10, 64, 128, 1, 2, 0),    # 1x1 projection
+    (3, 5, 6, 128, 192, 3, 1, 1),    # N not a multiple of the 128 tile
+])
+def test_conv_forward(lib, dtype, shape):
+    checks.check_conv_fwd(lib, DEV, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [
+    (2, 9, 11, 64, 64, 3, 1, 1),
+    (2, 9, 11, 64, 128, 3, 2, 1),    # stride-2 data gradient (div = 2 gather)
+    (2, 8, 10, 64, 128, 1, 2, 0),
+    (2, 7, 9, 64, 128, 1, 2, 0),     # odd input size
+])
+def test_conv_data_gradient(lib, dtype, shape):
+    checks.check_conv_dgrad(lib, DEV, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape,blocks", [
+    ((2, 9, 11, 64, 64, 3, 1, 1), 8),
+    ((3, 9, 11, 64, 128, 3, 2, 1), 8),
+    ((2, 8, 10, 64, 128, 1, 2, 0), 1),
+    ((5, 5, 6, 128, 128, 3, 1, 1), 40),   # many splits of the reduction
+])
+def test_conv_weight_gradient(lib, dtype, shape, blocks):
+    checks.check_conv_wgrad(lib, DEV, dtype, *shape, target_blocks=blocks)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("hw", [(20, 27), (21, 26)])
+def test_stem_conv(lib, dtype, hw):
+    checks.check_stem(lib, DEV, dtype, 2, *hw)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("M,C,kw", [
+    (300, 64, dict()),
+    (77, 128, dict(with_res=False)),
+    (130, 512, dict(relu=False, with_res=False)),
+])
+def test_batchnorm(lib, dtype, M, C, kw):
+    checks.check_bn(lib, DEV, dtype, M, C, **kw)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("hw,ties", [((8, 11), False), ((9, 10), True)])
+def test_maxpool(lib, dtype, hw, ties):
+    checks.check_maxpool(lib, DEV, dtype, 2, hw[0], hw[1], 64, ties=ties)
+
+
+def test_criteria_against_reference_golden(lib, golden_dir):
+    checks.check_criterion_golden(lib, DEV, golden_dir)
+
+
+def test_calc_vos_against_reference_golden(lib, golden_dir):
+    checks.check_calc_vos_golden(lib, DEV, golden_dir)
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 5.0])
+def test_fused_adam(lib, max_norm):
+    checks.check_adam(lib, DEV, max_norm=max_norm)

@@ -3,7 +3,7 @@
 `hip()` loads geomapnet_amd/libmapnet_hip.so -- the gfx950 build -- and is the only loader the
 product uses.  There is no CPU fallback: if the library is missing or no GPU is visible the
 product raises.  (`Binding(cdll)` can wrap any library exporting the same ABI; the test-suite
-uses that to drive the SIMT-emulator build of the same kernel sources, tests/emu_lib.py.)
+uses that to drive its SIMT-emulator build of the same kernel sources.)
 """
 import ctypes as C
 import os

@@ -11,7 +11,7 @@
  * Conventions
  *   - plain pointers and sizes only; no torch types.  All tensor pointers are DEVICE pointers
  *     (HBM) owned by the caller; the library never allocates device memory: the caller hands
- *     it arenas sized by mn_model_layout() / mn_plan_bytes().
+ *     it arenas sized by the mn_model_* queries and mn_plan_bytes.
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); every call only
  *     enqueues work on that stream and returns (asynchronous, like the reference until its
  *     loss.item() at common/train.py:361).

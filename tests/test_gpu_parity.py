@@ -1,0 +1,175 @@
+"""GPU suite (-m gpu): the same checks as the CPU emulator suite, on libmapnet_hip.so through the C
+ABI on a real MI355X, at small sizes against the oracle / torch fp64 and at BASELINE.json's full
+sizes through size-independent properties (adjoint identities, finite decreasing loss)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import checks
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from geomapnet_amd import _binding
+    assert torch.cuda.is_available()
+    b = _binding.hip()
+    assert b.backend_name == "hip"
+    return b
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [
+    (2, 9, 11, 64, 64, 3, 1, 1), (2, 9, 11, 64, 128, 3, 2, 1), (1, 8, 10, 64, 128, 1, 2, 0), (3, 5, 6, 128, 192, 3, 1, 1),
+    (2, 64, 86, 64, 64, 3, 1, 1),      # layer1 geometry at 256x341
+    (2, 32, 43, 128, 256, 3, 2, 1),    # layer3.0.conv1
+    (4, 8, 11, 512, 512, 3, 1, 1),     # layer4
+])
+def test_conv_forward(lib, dtype, shape):
+    checks.check_conv_fwd(lib, DEV, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [
+    (2, 9, 11, 64, 64, 3, 1, 1), (2, 9, 11, 64, 128, 3, 2, 1), (2, 8, 10, 64, 128, 1, 2, 0), (2, 7, 9, 64, 128, 1, 2, 0),
+    (2, 64, 86, 64, 128, 3, 2, 1), (2, 16, 22, 256, 512, 1, 2, 0), (4, 8, 11, 512, 512, 3, 1, 1),
+])
+def test_conv_data_gradient(lib, dtype, shape):
+    checks.check_conv_dgrad(lib, DEV, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape,blocks", [
+    ((2, 9, 11, 64, 64, 3, 1, 1), 8), ((3, 9, 11, 64, 128, 3, 2, 1), 8), ((2, 8, 10, 64, 128, 1, 2, 0), 1),
+    ((5, 5, 6, 128, 128, 3, 1, 1), 40), ((2, 64, 86, 64, 64, 3, 1, 1), 1024), ((4, 8, 11, 512, 512, 3, 1, 1), 1024),
+])
+def test_conv_weight_gradient(lib, dtype, shape, blocks):
+    checks.check_conv_wgrad(lib, DEV, dtype, *shape, target_blocks=blocks)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("hw", [(20, 27), (21, 26), (256, 341)])
+def test_stem_conv(lib, dtype, hw):
+    checks.check_stem(lib, DEV, dtype, 2, *hw)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("M,C,kw", [(300, 64, dict()), (77, 128, dict(with_res=False)), (130, 512, dict(relu=False, with_res=False)),
+                                    (2 * 64 * 86, 64, dict())])
+def test_batchnorm(lib, dtype, M, C, kw):
+    checks.check_bn(lib, DEV, dtype, M, C, **kw)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("hw,ties", [((8, 11), False), ((9, 10), True), ((128, 171), True)])
+def test_maxpool(lib, dtype, hw, ties):
+    checks.check_maxpool(lib, DEV, dtype, 2, hw[0], hw[1], 64, ties=ties)
+
+
+def test_criteria_against_reference_golden(lib, golden_dir):
+    checks.check_criterion_golden(lib, DEV, golden_dir)
+
+
+def test_calc_vos_against_reference_golden(lib, golden_dir):
+    checks.check_calc_vos_golden(lib, DEV, golden_dir)
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 5.0])
+def test_fused_adam(lib, max_norm):
+    checks.check_adam(lib, DEV, n=1000003, max_norm=max_norm)
+
+
+# ---- whole training step vs the oracle, identical synthetic batches and weights -----------------------
+def test_mapnet_train_step_fp32_parity_small(lib):
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+
+
+def test_mapnet_train_step_fp32_parity_full_resolution(lib):
+    """(N=2, T=3, 3, 256, 341): north-star tolerances 1e-4 on loss (relative, |loss| > 1) and 1e-3 on pose"""
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3)
+
+
+def test_posenet_train_step_fp32_parity(lib):
+    checks.check_train_step(lib, DEV, "fp32", mode="posenet", N=5, H=96, W=128, steps=1)
+
+
+def test_mapnet_online_train_step_fp32_parity_clip_and_nan_filter(lib):
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet++", N=2, H=64, W=85, steps=1, max_grad_norm=5.0, lr=1e-5, wd=0.0,
+                            filter_nans=True, grad_l2_rtol=None)
+
+
+def test_mapnet_online_gradients_fp32(lib):
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet++", N=2, H=64, W=85, steps=1, lr=1e-5, wd=0.0)
+
+
+def test_mapnet_gps_train_step_fp32(lib):
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet++", N=2, H=64, W=85, steps=1, gps=True, lr=1e-5, wd=0.0)
+
+
+def test_mapnet_train_step_fp16_close(lib):
+    checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=2e-2, pose_atol=5e-2,
+                            grad_l2_rtol=None)
+
+
+def test_eval_forward_parity(lib):
+    checks.check_eval_forward(lib, DEV, "fp32", B=3, H=128, W=171)
+    checks.check_eval_forward(lib, DEV, "fp16", B=3, H=128, W=171, atol=3e-2)
+
+
+# ---- BASELINE full size: size-independent properties -----------------------------------------------------
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_conv_adjoint_identity_full_size(lib, dtype):
+    """<conv(x, w), gy> = <x, dgrad(gy, w)> = <w, wgrad(gy, x)> at B=192, layer2 geometry (32x43, 128 ch)"""
+    from geomapnet_amd._binding import ptr
+    td = checks.TD[dtype]
+    B, H, W, Ci, Co, k = 192, 32, 43, 128, 128, 3
+    g, Ho, Wo = checks.fwd_geom(B, H, W, Ci, Co, k, 1, 1)
+    gd, _, _ = checks.dgrad_geom(B, H, W, Ci, Co, k, 1, 1)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(B, H, W, Ci, device=DEV, generator=gen).to(td)
+    w = (torch.randn(Co, k, k, Ci, device=DEV, generator=gen) * 0.05).to(td)
+    gy = torch.randn(B, Ho, Wo, Co, device=DEV, generator=gen).to(td)
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    y = torch.zeros(B, Ho, Wo, Co, dtype=td, device=DEV)
+    gx = torch.zeros(B, H, W, Ci, dtype=td, device=DEV)
+    gw = torch.zeros(Co, k * k * Ci, device=DEV)
+    one = C.c_float(1.0)
+    lib.check(lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, 0, None, None, one, None))
+    lib.check(lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, None))
+    lib.check(lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, None))
+    torch.cuda.synchronize()
+    a = (y.double() * gy.double()).sum().item()
+    b = (x.double() * gx.double()).sum().item()
+    c = (w.double().reshape(Co, -1) * gw.double()).sum().item()
+    scale = (y.double().norm() * gy.double().norm()).item()
+    tol = 3e-3 if dtype == 1 else 3e-6
+    assert abs(a - b) <= tol * scale and abs(a - c) <= tol * scale, (a, b, c, scale)
+
+
+def test_full_size_training_is_finite_and_learns(lib):
+    """BASELINE configs[2] shape (64 windows x T=3, 256x341, fp16): 6 steps on one fixed batch"""
+    import geomapnet_amd as G
+    G.set_compute_dtype("fp16")
+    torch.manual_seed(7)
+    net = G.MapNet(G.PoseNet(G.resnet34(), droprate=0.0, pretrained=False)).cuda()
+    crit = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True).cuda()
+    opt = G.Optimizer([{"params": net.parameters()}, {"params": [crit.sax, crit.saq]}, {"params": [crit.srx, crit.srq]}],
+                      "adam", base_lr=1e-4, weight_decay=5e-4)
+    net.train()
+    import oracle
+    x, t = oracle.make_batch("mapnet", 64, 256, 341, seed=7)
+    x, t = x.cuda(), t.cuda()
+    losses = []
+    for _ in range(6):
+        l, out = G.step_feedfwd(x, net, True, t, crit, opt, True)
+        assert np.isfinite(l) and torch.isfinite(out).all()
+        losses.append(l)
+    assert out.shape == (64, 3, 6)
+    assert losses[-1] < losses[0], losses
+    sd = net.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype == torch.float32)
+    assert int(sd["mapnet.feature_extractor.bn1.num_batches_tracked"]) == 6

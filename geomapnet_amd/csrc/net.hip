@@ -4,6 +4,7 @@
 #include "../../include/mapnet_hip.h"
 
 #include <cmath>
+#include <deque>
 #include <memory>
 #include <string>
 #include <vector>
@@ -54,7 +55,7 @@ struct KernelTimer {
     hipEvent_t a, b;
     int cat;
   };
-  std::vector<Pair> pool;
+  std::deque<Pair> pool;  // stable addresses: callers hold Pair* across later begin() calls
   size_t used = 0;
   float ms[4] = {0, 0, 0, 0};
   int launches[4] = {0, 0, 0, 0};
@@ -591,6 +592,7 @@ extern "C" mn_handle* mn_create(const mn_config* cfg, float* params, float* opt_
     return nullptr;
   }
   mn_handle* h = new mn_handle();
+  begin_call();
   int rc;
   if (cfg->dtype == MN_DTYPE_F16) {
     auto* p = new Plan<half>(*cfg);
@@ -609,8 +611,9 @@ extern "C" mn_handle* mn_create(const mn_config* cfg, float* params, float* opt_
 }
 extern "C" void mn_destroy(mn_handle* h) { delete h; }
 
-#define MN_H(h)                      \
+#define MN_H(h)                                       \
   if (!(h) || !(h)->plan) return fail("null handle"); \
+  begin_call();                                       \
   PlanBase& P = *(h)->plan;
 
 extern "C" int mn_set_learn_flags(mn_handle* h, int learn_beta, int learn_gamma) {

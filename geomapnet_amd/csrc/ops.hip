@@ -48,6 +48,7 @@ extern "C" int mn_op_igemm_grid_m(int M) { return igemm_grid_m(M); }
 extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc,
                            float* stats, const float* bias, int relu, const void* res, const void* res_gate, float alpha,
                            void* stream) {
+  begin_call();
   GatherGeom g = to_geom(gg);
   if (int e = check_geom(g, dtype)) return e;
   Epilogue ep;
@@ -62,6 +63,7 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
 
 extern "C" int mn_op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
                            const int32_t* colmap, float alpha, int target_blocks, void* stream) {
+  begin_call();
   WgradArgs a;
   a.g = to_geom(gg);
   int vec = dtype == MN_F16 ? 8 : 4;
@@ -75,6 +77,7 @@ extern "C" int mn_op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, 
 }
 
 extern "C" int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream) {
+  begin_call();
   hipLaunchKernelGGL(oihw_ohwi_kernel, dim3(ew_grid((long)O * I * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, O,
                      I, H, W, to_ohwi);
   return check_launch("oihw_ohwi");
@@ -82,6 +85,7 @@ extern "C" int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, in
 
 extern "C" int mn_op_criterion(int mode, int N, int T, const float* pred, const float* targ, const float* s, float* loss,
                                float* dpred, float* ds, float* vos_out, float grad_scale, void* stream) {
+  begin_call();
   if (T < 1 || T > kMaxT) return fail("criterion: T out of range");
   if (mode < 0 || mode > 3) return fail("criterion: bad mode");
   CriterionArgs a;
@@ -93,6 +97,7 @@ extern "C" int mn_op_criterion(int mode, int N, int T, const float* pred, const 
 
 extern "C" int mn_op_calc_vos(const float* poses, int N, int T, float* vos, const float* cot, float* dposes,
                               void* stream) {
+  begin_call();
   if (T < 2 || T > kMaxT) return fail("calc_vos: T out of range");
   hipLaunchKernelGGL(calc_vos_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, poses, N, T, vos, cot,
                      dposes);
@@ -102,6 +107,7 @@ extern "C" int mn_op_calc_vos(const float* poses, int N, int T, float* vos, cons
 extern "C" int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip, float lr, float wd,
                           float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm,
                           double* sqnorm_scratch, int eps_mode, void* stream) {
+  begin_call();
   hipStream_t s = (hipStream_t)stream;
   if (max_norm > 0.f) {
     if (!sqnorm_scratch) return fail("adam: clipping needs a scratch double");
@@ -143,6 +149,7 @@ static int bn_train_fwd_t(const void* y, int64_t M, int C, const float* gamma, c
 extern "C" int mn_op_bn_train_fwd(int dtype, const void* y, int64_t M, int C, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, float* mean, float* invstd, const void* res,
                                   int relu, void* out, float eps, float momentum, double* accum_scratch, void* stream) {
+  begin_call();
   if (dtype == MN_F16)
     return bn_train_fwd_t<half>(y, M, C, gamma, beta, running_mean, running_var, mean, invstd, res, relu, out, eps,
                                 momentum, accum_scratch, (hipStream_t)stream);
@@ -162,6 +169,7 @@ static int bn_bwd_t(const void* g, const void* gate, const void* y, int64_t M, i
 extern "C" int mn_op_bn_bwd(int dtype, const void* g, const void* gate, const void* y, int64_t M, int C, const float* gamma,
                             const float* mean, const float* invstd, float* dgamma, float* dbeta, void* gy,
                             float* coef_scratch, double* accum_scratch, float grad_unscale, void* stream) {
+  begin_call();
   hipMemsetAsync(accum_scratch, 0, 2 * C * sizeof(double), (hipStream_t)stream);
   if (dtype == MN_F16)
     return bn_bwd_t<half>(g, gate, y, M, C, gamma, mean, invstd, dgamma, dbeta, gy, coef_scratch, accum_scratch,
@@ -171,6 +179,7 @@ extern "C" int mn_op_bn_bwd(int dtype, const void* g, const void* gate, const vo
 }
 
 extern "C" int mn_op_maxpool_fwd(int dtype, const void* in, void* out, int B, int H, int W, int C, void* stream) {
+  begin_call();
   int Po = (H + 2 - 3) / 2 + 1, Qo = (W + 2 - 3) / 2 + 1;
   if (dtype == MN_F16)
     hipLaunchKernelGGL((maxpool_fwd_kernel<half>), dim3(ew_grid((long)B * Po * Qo * C / 8)), dim3(256), 0,
@@ -183,6 +192,7 @@ extern "C" int mn_op_maxpool_fwd(int dtype, const void* in, void* out, int B, in
 
 extern "C" int mn_op_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int B, int H, int W, int C,
                                  void* stream) {
+  begin_call();
   int Po = (H + 2 - 3) / 2 + 1, Qo = (W + 2 - 3) / 2 + 1;
   if (dtype == MN_F16)
     hipLaunchKernelGGL((maxpool_bwd_kernel<half>), dim3(ew_grid((long)B * H * W * C / 8)), dim3(256), 0,

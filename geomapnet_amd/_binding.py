@@ -59,7 +59,7 @@ _PROTOS = {
     "mn_set_profiling": (c_i, [c_void, c_i]),
     "mn_last_kernel_ms": (c_i, [c_void, c_i, C.POINTER(c_f), C.POINTER(c_i)]),
     "mn_op_igemm": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_void, c_i, c_void, c_void,
-                          c_f, c_void]),
+                          c_f, c_void, c_void]),
     "mn_op_igemm_grid_m": (c_i, [c_i]),
     "mn_op_wgrad": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_i, c_void, c_void, c_i, c_void, c_f, c_i, c_void]),
     "mn_op_oihw_to_ohwi": (c_i, [c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),
@@ -71,7 +71,7 @@ _PROTOS = {
                                  c_void, c_f, c_f, c_void, c_void]),
     "mn_op_bn_bwd": (c_i, [c_i, c_void, c_void, c_void, c_i64, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
                            c_void, c_f, c_void]),
-    "mn_op_maxpool_fwd": (c_i, [c_i, c_void, c_void, c_i, c_i, c_i, c_i, c_void]),
+    "mn_op_maxpool_fwd": (c_i, [c_i, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_void]),
     "mn_op_maxpool_bwd": (c_i, [c_i, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_void]),
 }
 

@@ -282,8 +282,12 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
                           const float* invstd, float* dgamma, float* dbeta, T* gy, float* coef, double* accum,
                           float grad_unscale, hipStream_t s) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  int rows_per_block = 128 * (256 / (C / VEC));
-  if (rows_per_block < 256) rows_per_block = 256;
+  // ~4096 workgroups in flight: the reduction is HBM-bound and needs the whole chip
+  const int rlanes = 256 / (C / VEC);
+  long rows = (M + 4095) / 4096;
+  rows = ((rows + rlanes - 1) / rlanes) * rlanes;
+  if (rows < 4L * rlanes) rows = 4L * rlanes;
+  int rows_per_block = (int)rows;
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(cdiv(M, rows_per_block)), dim3(256), 0, s, g, gate, y, mean, invstd, M,
                      C, accum, rows_per_block);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, accum, C, (double)M, gamma, invstd,
@@ -291,104 +295,6 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   long np = M * C / VEC;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
                      (const float*)coef, (const float*)(coef + C), (const float*)(coef + 2 * C), gy, np, C);
-}
-
-// ---- max-pool 3x3 stride 2 pad 1 (NHWC) --------------------------------------------------------------
-template <typename T>
-static __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H,
-                                                           int W, int C, int Po, int Qo) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  const int cpr = C / VEC;
-  long total = (long)B * Po * Qo * cpr;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int cp = (int)(i % cpr);
-    long tmp = i / cpr;
-    int qo = (int)(tmp % Qo);
-    tmp /= Qo;
-    int po = (int)(tmp % Po);
-    int b = (int)(tmp / Po);
-    float best[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) best[e] = -INFINITY;
-    for (int r = 0; r < 3; ++r) {
-      int h = po * 2 - 1 + r;
-      if ((unsigned)h >= (unsigned)H) continue;
-      for (int s = 0; s < 3; ++s) {
-        int w = qo * 2 - 1 + s;
-        if ((unsigned)w >= (unsigned)W) continue;
-        PieceView<T> v;
-        v.p = reinterpret_cast<const piece_t*>(in)[((long)(b * H + h) * W + w) * cpr + cp];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) best[e] = fmaxf(best[e], (float)v.e[e]);
-      }
-    }
-    PieceView<T> o;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) o.e[e] = (T)best[e];
-    reinterpret_cast<piece_t*>(out)[i] = o.p;
-  }
-}
-
-// gradient routed to the FIRST maximum of each window in (r, s) scan order, as torch does.
-// Gather form: each input position sums the windows for which it is that first maximum.
-template <typename T>
-static __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ in, const T* __restrict__ gout,
-                                                           T* __restrict__ gin, int B, int H, int W, int C, int Po,
-                                                           int Qo) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  const int cpr = C / VEC;
-  long total = (long)B * H * W * cpr;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int cp = (int)(i % cpr);
-    long tmp = i / cpr;
-    int w = (int)(tmp % W);
-    tmp /= W;
-    int h = (int)(tmp % H);
-    int b = (int)(tmp / H);
-    PieceView<T> self;
-    self.p = reinterpret_cast<const piece_t*>(in)[i];
-    float acc[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-    // windows po with po*2-1 <= h <= po*2+1
-    int po_lo = h / 2, po_hi = (h + 1) / 2;  // ceil((h-1)/2) == h/2 for h>=0
-    int qo_lo = w / 2, qo_hi = (w + 1) / 2;
-    for (int po = po_lo; po <= po_hi && po < Po; ++po)
-      for (int qo = qo_lo; qo <= qo_hi && qo < Qo; ++qo) {
-        bool first[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) first[e] = true;
-        bool before = true;
-        for (int r = 0; r < 3; ++r) {
-          int hh = po * 2 - 1 + r;
-          if ((unsigned)hh >= (unsigned)H) continue;
-          for (int s = 0; s < 3; ++s) {
-            int ww = qo * 2 - 1 + s;
-            if ((unsigned)ww >= (unsigned)W) continue;
-            if (hh == h && ww == w) {
-              before = false;
-              continue;
-            }
-            PieceView<T> v;
-            v.p = reinterpret_cast<const piece_t*>(in)[((long)(b * H + hh) * W + ww) * cpr + cp];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              float o = (float)v.e[e], me = (float)self.e[e];
-              if (before ? (o >= me) : (o > me)) first[e] = false;
-            }
-          }
-        }
-        PieceView<T> gv;
-        gv.p = reinterpret_cast<const piece_t*>(gout)[((long)(b * Po + po) * Qo + qo) * cpr + cp];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if (first[e]) acc[e] += (float)gv.e[e];
-      }
-    PieceView<T> o;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) o.e[e] = (T)acc[e];
-    reinterpret_cast<piece_t*>(gin)[i] = o.p;
-  }
 }
 
 // ---- global average pool --------------------------------------------------------------------------

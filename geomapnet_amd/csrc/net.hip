@@ -16,6 +16,7 @@
 #include "igemm.h"
 #include "layout.h"
 #include "optim.h"
+#include "pool.h"
 #include "util.h"
 #include "wgrad.h"
 
@@ -163,6 +164,8 @@ struct Plan : PlanBase {
   double* sqnorm;
   unsigned char* frozen;
   int* stem_colmap;
+  unsigned char* pool_idx;  // winning tap of every max-pool window
+  void* zero_page;          // 256 zero bytes: source of out-of-image taps for the DMA conv pipeline
   const float* cur_targets = nullptr;
   float* cur_loss = nullptr;
 
@@ -190,6 +193,7 @@ struct Plan : PlanBase {
     ga0 = (T*)A(n0 * sizeof(T));
     p0 = (T*)A(n1 * sizeof(T));
     gp0 = (T*)A(n1 * sizeof(T));
+    pool_idx = (unsigned char*)A(n1);
     const T* x = p0;
     T* gx = gp0;
     size_t max_partial = (size_t)igemm_grid_m((int)stem.M) * 2 * 64;
@@ -231,6 +235,7 @@ struct Plan : PlanBase {
     sqnorm = (double*)A(256);
     frozen = (unsigned char*)A(256);
     stem_colmap = (int*)A(224 * 4);
+    zero_page = (void*)A(256);
     return b.cur;
   }
 
@@ -375,7 +380,7 @@ struct Plan : PlanBase {
     ep.out = u.y; ep.ldc = u.cp.cout; ep.stats = training ? stats_partial : nullptr; ep.bias = nullptr; ep.relu = 0;
     ep.res = nullptr; ep.res_gate = nullptr; ep.alpha = 1.f;
     auto* tp = timer.begin(0, s);
-    launch_igemm<T>(u.gf, x, u.wf, ep, s);
+    launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
     timer.end(tp, s);
     int N = u.cp.cout;
     if (training) {
@@ -399,7 +404,7 @@ struct Plan : PlanBase {
     conv_bn_stats(stem, xpad, training, s);
     bn_act(stem, nullptr, 1, a0, s);
     hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
-                       (const T*)a0, p0, B, H0, W0, 64, H1, W1);
+                       (const T*)a0, p0, pool_idx, B, H0, W0, 64, H1, W1);
     for (auto& blk : blocks) {
       conv_bn_stats(blk.u1, blk.x, training, s);
       bn_act(blk.u1, nullptr, 1, blk.a1, s);
@@ -467,7 +472,7 @@ struct Plan : PlanBase {
     ep.out = gx; ep.ldc = u.cp.cin; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = res; ep.res_gate = gate;
     ep.alpha = 1.f;
     auto* tp = timer.begin(0, s);
-    launch_igemm<T>(u.gd, (const T*)u.gy, (const T*)u.wd, ep, s);
+    launch_igemm<T>(u.gd, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page);
     timer.end(tp, s);
   }
   void block_backward(Block& blk, hipStream_t s) {
@@ -517,8 +522,8 @@ struct Plan : PlanBase {
                        (const float*)dpooled, last.gout, B, Hl * Wl, 512);
   }
   void stem_backward(hipStream_t s) {
-    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s, (const T*)a0,
-                       (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s,
+                       (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
     bn_bwd(stem, ga0, a0, s);
     conv_wgrad(stem, xpad, s);  // the input gradient of the stem is not needed (nothing consumes it)
   }

@@ -9,6 +9,7 @@
 #include "head.h"
 #include "igemm.h"
 #include "optim.h"
+#include "pool.h"
 #include "wgrad.h"
 #include "util.h"
 
@@ -40,6 +41,9 @@ static int check_geom(const GatherGeom& g, int dtype) {
   if (g.K % (4 * vec) != 0) return fail("igemm: K must be a multiple of the 64-byte K-step");
   if (g.M != g.B * g.P * g.Q) return fail("igemm: M != B*P*Q");
   if (g.div != 1 && g.div != 2) return fail("igemm: div must be 1 or 2");
+  if (g.div == 2 && (g.rsign != -1 || g.ssign != -1)) return fail("igemm: div = 2 requires rsign = ssign = -1");
+  if (g.R * g.S > 32) return fail("igemm: at most 32 taps");
+  if ((long)g.B * g.Hi * g.Wi * g.C >= (1L << 31)) return fail("igemm: A tensor exceeds 2^31 elements");
   return 0;
 }
 
@@ -47,7 +51,7 @@ extern "C" int mn_op_igemm_grid_m(int M) { return igemm_grid_m(M); }
 
 extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc,
                            float* stats, const float* bias, int relu, const void* res, const void* res_gate, float alpha,
-                           void* stream) {
+                           const void* zero_page, void* stream) {
   begin_call();
   GatherGeom g = to_geom(gg);
   if (int e = check_geom(g, dtype)) return e;
@@ -55,9 +59,9 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
   ep.alpha = alpha;
   if (dtype == MN_F16)
-    launch_igemm<half>(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream);
+    launch_igemm<half>(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, (const half*)zero_page);
   else
-    launch_igemm<float>(g, (const float*)A, (const float*)Bw, ep, (hipStream_t)stream);
+    launch_igemm<float>(g, (const float*)A, (const float*)Bw, ep, (hipStream_t)stream, (const float*)zero_page);
   return check_launch("igemm");
 }
 
@@ -132,7 +136,6 @@ static int bn_train_fwd_t(const void* y, int64_t M, int C, const float* gamma, c
   float* scale = reinterpret_cast<float*>(accum + 2 * C);
   float* shift = scale + C;
   int rows_per_block = 256;
-  // reuse the backward reducer with g = y, y = 0-mean trick is not applicable; use a dedicated pass:
   hipLaunchKernelGGL((bn_fwd_stats_kernel<T>), dim3(cdiv(M, rows_per_block)), dim3(256), 0, s, (const T*)y, (long)M, C,
                      accum, rows_per_block);
   BnParams p;
@@ -178,27 +181,28 @@ extern "C" int mn_op_bn_bwd(int dtype, const void* g, const void* gate, const vo
                          grad_unscale, (hipStream_t)stream);
 }
 
-extern "C" int mn_op_maxpool_fwd(int dtype, const void* in, void* out, int B, int H, int W, int C, void* stream) {
-  begin_call();
-  int Po = (H + 2 - 3) / 2 + 1, Qo = (W + 2 - 3) / 2 + 1;
-  if (dtype == MN_F16)
-    hipLaunchKernelGGL((maxpool_fwd_kernel<half>), dim3(ew_grid((long)B * Po * Qo * C / 8)), dim3(256), 0,
-                       (hipStream_t)stream, (const half*)in, (half*)out, B, H, W, C, Po, Qo);
-  else
-    hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid((long)B * Po * Qo * C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)in, (float*)out, B, H, W, C, Po, Qo);
-  return check_launch("maxpool_fwd");
-}
-
-extern "C" int mn_op_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int B, int H, int W, int C,
+extern "C" int mn_op_maxpool_fwd(int dtype, const void* in, void* out, unsigned char* idx, int B, int H, int W, int C,
                                  void* stream) {
   begin_call();
   int Po = (H + 2 - 3) / 2 + 1, Qo = (W + 2 - 3) / 2 + 1;
   if (dtype == MN_F16)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<half>), dim3(ew_grid((long)B * Po * Qo * C / 8)), dim3(256), 0,
+                       (hipStream_t)stream, (const half*)in, (half*)out, idx, B, H, W, C, Po, Qo);
+  else
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid((long)B * Po * Qo * C / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)in, (float*)out, idx, B, H, W, C, Po, Qo);
+  return check_launch("maxpool_fwd");
+}
+
+extern "C" int mn_op_maxpool_bwd(int dtype, const unsigned char* idx, const void* gout, void* gin, int B, int H, int W,
+                                 int C, void* stream) {
+  begin_call();
+  int Po = (H + 2 - 3) / 2 + 1, Qo = (W + 2 - 3) / 2 + 1;
+  if (dtype == MN_F16)
     hipLaunchKernelGGL((maxpool_bwd_kernel<half>), dim3(ew_grid((long)B * H * W * C / 8)), dim3(256), 0,
-                       (hipStream_t)stream, (const half*)in, (const half*)gout, (half*)gin, B, H, W, C, Po, Qo);
+                       (hipStream_t)stream, idx, (const half*)gout, (half*)gin, B, H, W, C, Po, Qo);
   else
     hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid((long)B * H * W * C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)in, (const float*)gout, (float*)gin, B, H, W, C, Po, Qo);
+                       (hipStream_t)stream, idx, (const float*)gout, (float*)gin, B, H, W, C, Po, Qo);
   return check_launch("maxpool_bwd");
 }

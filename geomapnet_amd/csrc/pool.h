@@ -1,0 +1,108 @@
+// Max-pool 3x3 / stride 2 / pad 1 on NHWC activations, with the torch routing rule (the gradient
+// of a window goes to its FIRST maximum in (r, s) scan order).  The forward pass records the winning
+// tap (0..8) per output element as one byte, so the backward pass is a pure gather over at most four
+// windows per input position and never re-reads the activation: traffic = indices + output gradient
+// (each read ~2.25x through L2) + one write of the input gradient.
+#pragma once
+#include "common.h"
+
+namespace mn {
+
+template <typename T>
+static __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                                  unsigned char* __restrict__ idx, int B, int H, int W,
+                                                                  int C, int Po, int Qo) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  long total = (long)B * Po * Qo * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int cp = (int)(i % cpr);
+    long tmp = i / cpr;
+    int qo = (int)(tmp % Qo);
+    tmp /= Qo;
+    int po = (int)(tmp % Po);
+    int b = (int)(tmp / Po);
+    float best[VEC];
+    unsigned char arg[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      best[e] = -INFINITY;
+      arg[e] = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int h = po * 2 - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        int w = qo * 2 - 1 + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        PieceView<T> v;
+        v.p = reinterpret_cast<const piece_t*>(in)[((long)(b * H + h) * W + w) * cpr + cp];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float f = (float)v.e[e];
+          if (f > best[e]) {  // strict: the first maximum wins
+            best[e] = f;
+            arg[e] = (unsigned char)(r * 3 + s);
+          }
+        }
+      }
+    }
+    PieceView<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.e[e] = (T)best[e];
+    reinterpret_cast<piece_t*>(out)[i] = o.p;
+    if (idx) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) idx[i * VEC + e] = arg[e];
+    }
+  }
+}
+
+template <typename T>
+static __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const unsigned char* __restrict__ idx,
+                                                                  const T* __restrict__ gout, T* __restrict__ gin, int B,
+                                                                  int H, int W, int C, int Po, int Qo) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  long total = (long)B * H * W * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int cp = (int)(i % cpr);
+    long tmp = i / cpr;
+    int w = (int)(tmp % W);
+    tmp /= W;
+    int h = (int)(tmp % H);
+    int b = (int)(tmp / H);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    // windows (po, qo) with po*2-1 <= h <= po*2+1: po in [h/2, (h+1)/2]
+    for (int po = h / 2; po <= (h + 1) / 2 && po < Po; ++po)
+      for (int qo = w / 2; qo <= (w + 1) / 2 && qo < Qo; ++qo) {
+        const unsigned char mytap = (unsigned char)((h - (po * 2 - 1)) * 3 + (w - (qo * 2 - 1)));
+        const long o = ((long)(b * Po + po) * Qo + qo) * cpr + cp;
+        unsigned char a[VEC];
+        if (VEC == 8) {
+          unsigned long long packed = reinterpret_cast<const unsigned long long*>(idx)[o];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) a[e] = (unsigned char)(packed >> (8 * e));
+        } else {
+          unsigned packed = reinterpret_cast<const unsigned*>(idx)[o];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) a[e] = (unsigned char)(packed >> (8 * e));
+        }
+        PieceView<T> gv;
+        gv.p = reinterpret_cast<const piece_t*>(gout)[o];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (a[e] == mytap) acc[e] += (float)gv.e[e];
+      }
+    PieceView<T> ov;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ov.e[e] = (T)acc[e];
+    reinterpret_cast<piece_t*>(gin)[i] = ov.p;
+  }
+}
+
+}  // namespace mn

@@ -140,9 +140,12 @@ typedef struct mn_gather_geom {
 } mn_gather_geom;
 
 /* out[m][n] = alpha * sum_k gather(A)[m][k] * Bw[n][k] (+bias, relu, residual): conv forward /
- * data-gradient / linear.  stats: [mn_op_igemm_grid_m(M)][2][N] fp32 partial column sums or NULL */
+ * data-gradient / linear.  stats: [mn_op_igemm_grid_m(M)][2][N] fp32 partial column sums or NULL.
+ * zero_page: >= 16 zero bytes in device memory, 16-byte aligned (source of the taps that fall outside
+ * the image for the LDS-DMA pipeline), or NULL to use the register-staged kernel. */
 int mn_op_igemm(int dtype, const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
-                const float* bias, int relu, const void* res, const void* res_gate, float alpha, void* stream);
+                const float* bias, int relu, const void* res, const void* res_gate, float alpha, const void* zero_page,
+                void* stream);
 int mn_op_igemm_grid_m(int M);
 /* dW[n][colmap(k)] += alpha * sum_m dY[m][n] * gather(X)[m][k]  (fp32 atomics into dW) */
 int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw,
@@ -169,8 +172,10 @@ int mn_op_bn_train_fwd(int dtype, const void* y, int64_t M, int C, const float* 
 int mn_op_bn_bwd(int dtype, const void* g, const void* gate, const void* y, int64_t M, int C, const float* gamma,
                  const float* mean, const float* invstd, float* dgamma, float* dbeta, void* gy, float* coef_scratch,
                  double* accum_scratch, float grad_unscale, void* stream);
-int mn_op_maxpool_fwd(int dtype, const void* in, void* out, int B, int H, int W, int C, void* stream);
-int mn_op_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int B, int H, int W, int C,
+/* 3x3/2 pad 1 max-pool; idx (optional, uint8 per output element) records the winning tap for the backward */
+int mn_op_maxpool_fwd(int dtype, const void* in, void* out, unsigned char* idx, int B, int H, int W, int C,
+                      void* stream);
+int mn_op_maxpool_bwd(int dtype, const unsigned char* idx, const void* gout, void* gin, int B, int H, int W, int C,
                       void* stream);
 
 #ifdef __cplusplus

@@ -34,6 +34,17 @@ def K(t):
     return ptr(t)
 
 
+_ZP = {}
+
+
+def zero_page(dev):
+    """256 zero bytes on `dev` (the conv kernels' source for out-of-image taps)"""
+    key = str(dev)
+    if key not in _ZP:
+        _ZP[key] = torch.zeros(64, dtype=torch.float32, device=dev)
+    return _ZP[key]
+
+
 def _fresh():
     del _KEEP[:]
 
@@ -72,7 +83,7 @@ def check_conv_fwd(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, seed=0):
     out = torch.zeros(B, Ho, Wo, Cout, dtype=td, device=dev)
     gm = lib.op_igemm_grid_m(g.M)
     st = torch.zeros(gm, 2, Cout, device=dev)
-    lib.check(lib.op_igemm(dtype, C.byref(g), K(xn), K(wn), K(out), Cout, K(st), None, 0, None, None, f32(1), None))
+    lib.check(lib.op_igemm(dtype, C.byref(g), K(xn), K(wn), K(out), Cout, K(st), None, 0, None, None, f32(1), K(zero_page(dev)), None))
     dev_sync(dev)
     o = out.cpu().double().permute(0, 3, 1, 2)
     scale = ref.abs().max().item()
@@ -102,7 +113,7 @@ def check_conv_dgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, with_r
         res, gate = res.to(dev), gate.to(dev)
     out = torch.zeros(B, H, W, Cin, dtype=td, device=dev)
     lib.check(lib.op_igemm(dtype, C.byref(g), K(_nhwc(gy, td, dev)), K(wt), K(out), Cin, None, None, 0, K(res),
-                           K(gate), f32(1), None))
+                           K(gate), f32(1), K(zero_page(dev)), None))
     dev_sync(dev)
     assert (out.cpu().double() - want).abs().max().item() <= OUT_TOL[dtype] * want.abs().max().item() + 1e-6
 
@@ -150,7 +161,7 @@ def check_stem(lib, dev, dtype, B, H, W, seed=3):
     assert ref.shape[2] == H0 and ref.shape[3] == W0
     out = torch.zeros(B, H0, W0, 64, dtype=td, device=dev)
     lib.check(lib.op_igemm(dtype, C.byref(g), K(xp.to(td).to(dev)), K(wc.reshape(64, 224).to(td).to(dev)), K(out), 64,
-                           None, None, 0, None, None, f32(1), None))
+                           None, None, 0, None, None, f32(1), K(zero_page(dev)), None))
     dev_sync(dev)
     assert (out.cpu().double().permute(0, 3, 1, 2) - ref).abs().max().item() <= OUT_TOL[dtype] * ref.abs().max().item()
     gy = torch.randn(B, 64, H0, W0, generator=gen).to(td).float()
@@ -231,13 +242,14 @@ def check_maxpool(lib, dev, dtype, B, H, W, Cc, seed=5, ties=False):
     Po, Qo = ref.shape[2], ref.shape[3]
     xn = _nhwc(x, td, dev)
     out = torch.zeros(B, Po, Qo, Cc, dtype=td, device=dev)
-    lib.check(lib.op_maxpool_fwd(dtype, K(xn), K(out), B, H, W, Cc, None))
+    idx = torch.zeros(B, Po, Qo, Cc, dtype=torch.uint8, device=dev)
+    lib.check(lib.op_maxpool_fwd(dtype, K(xn), K(out), K(idx), B, H, W, Cc, None))
     dev_sync(dev)
     assert torch.equal(out.cpu().double().permute(0, 3, 1, 2), ref.detach())
     go = torch.randn(B, Cc, Po, Qo, generator=gen).to(td).float()
     ref.backward(go.double())
     gin = torch.zeros(B, H, W, Cc, dtype=td, device=dev)
-    lib.check(lib.op_maxpool_bwd(dtype, K(xn), K(_nhwc(go, td, dev)), K(gin), B, H, W, Cc, None))
+    lib.check(lib.op_maxpool_bwd(dtype, K(idx), K(_nhwc(go, td, dev)), K(gin), B, H, W, Cc, None))
     dev_sync(dev)
     want = xd.grad.permute(0, 2, 3, 1)
     assert (gin.cpu().double() - want).abs().max().item() <= OUT_TOL[dtype] * max(1.0, want.abs().max().item())

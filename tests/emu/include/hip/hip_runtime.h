@@ -282,3 +282,14 @@ inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 inline long min(long a, long b) { return a < b ? a : b; }
 inline long max(long a, long b) { return a > b ? a : b; }
+
+// ---- LDS-DMA and explicit synchronisation builtins used by the pipelined conv kernel ------------
+// global_load_lds: each lane copies `size` bytes from its own global address to
+// (wave-uniform LDS base) + lane*size + offset.  The emulator performs the copy immediately, so it
+// validates addressing only; the vmcnt/barrier discipline is validated on hardware.
+inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(1))) void* g,
+                                             __attribute__((address_space(3))) void* l, unsigned size, int offset, int) {
+  memcpy((char*)(uintptr_t)l + (size_t)emu::cur->lane * size + offset, (const void*)(uintptr_t)g, size);
+}
+inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline void __builtin_amdgcn_s_barrier() { emu::block_sync(); }

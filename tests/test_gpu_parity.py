@@ -138,8 +138,8 @@ def test_conv_adjoint_identity_full_size(lib, dtype):
     gx = torch.zeros(B, H, W, Ci, dtype=td, device=DEV)
     gw = torch.zeros(Co, k * k * Ci, device=DEV)
     one = C.c_float(1.0)
-    lib.check(lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, 0, None, None, one, None))
-    lib.check(lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, None))
+    lib.check(lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
+    lib.check(lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     lib.check(lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, None))
     torch.cuda.synchronize()
     a = (y.double() * gy.double()).sum().item()

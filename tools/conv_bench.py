@@ -1,0 +1,77 @@
+"""GPU micro-benchmark of the conv MFMA kernels at the BASELINE layer shapes (B=192, fp16 by default).
+usage: python tools/conv_bench.py [fp16|fp32] [B]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import checks  # noqa: E402
+from geomapnet_amd import _binding  # noqa: E402
+from geomapnet_amd._binding import ptr  # noqa: E402
+
+lib = _binding.hip()
+dtype = 1 if (len(sys.argv) < 2 or sys.argv[1] == "fp16") else 0
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+td = checks.TD[dtype]
+one = C.c_float(1.0)
+
+
+def timeit(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3  # us
+
+
+def bench(name, H, W, Ci, Co, k, stride, pad):
+    g, Ho, Wo = checks.fwd_geom(B, H, W, Ci, Co, k, stride, pad)
+    gd, _, _ = checks.dgrad_geom(B, H, W, Ci, Co, k, stride, pad)
+    x = torch.randn(B, H, W, Ci, device="cuda").to(td)
+    w = (torch.randn(Co, k, k, Ci, device="cuda") * 0.05).to(td)
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    gy = torch.randn(B, Ho, Wo, Co, device="cuda").to(td)
+    y = torch.empty(B, Ho, Wo, Co, dtype=td, device="cuda")
+    gx = torch.empty(B, H, W, Ci, dtype=td, device="cuda")
+    res, gate = torch.randn_like(gx), torch.randn_like(gx)
+    gw = torch.zeros(Co, k * k * Ci, device="cuda")
+    st = torch.zeros(lib.op_igemm_grid_m(g.M), 2, Co, device="cuda")
+    flops = 2.0 * g.M * Co * k * k * Ci
+    t_f = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, ptr(st), None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
+    t_d = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
+    t_r = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), ptr(gate), one, ptr(checks.zero_page("cuda")), None))
+    t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, None))
+    io = (x.numel() + y.numel()) * x.element_size()
+    print("%-22s M=%8d N=%4d K=%5d  fwd %7.1f us %6.0f TF (io %5.2f TB/s) | dgrad %7.1f us %6.0f TF | +res %7.1f us | wgrad %7.1f us %6.0f TF"
+          % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, io / t_f / 1e6, t_d, flops / t_d / 1e6, t_r, t_w, flops / t_w / 1e6), flush=True)
+
+
+print("dtype", "fp16" if dtype else "fp32", "B", B)
+bench("layer1 3x3 64->64", 64, 86, 64, 64, 3, 1, 1)
+bench("layer2.0 3x3/2 64->128", 64, 86, 64, 128, 3, 2, 1)
+bench("layer2 3x3 128->128", 32, 43, 128, 128, 3, 1, 1)
+bench("layer2.0 1x1/2 64->128", 64, 86, 64, 128, 1, 2, 0)
+bench("layer3 3x3 256->256", 16, 22, 256, 256, 3, 1, 1)
+bench("layer4 3x3 512->512", 8, 11, 512, 512, 3, 1, 1)
+# stem through the pixel-pair formulation
+g, Hp, Wp, H0, W0 = checks.stem_geom(B, 256, 341)
+xp = torch.randn(B, Hp, Wp, 4, device="cuda").to(td)
+wc = (torch.randn(64, 224, device="cuda") * 0.05).to(td)
+y = torch.empty(B, H0, W0, 64, dtype=td, device="cuda")
+st = torch.zeros(lib.op_igemm_grid_m(g.M), 2, 64, device="cuda")
+t_f = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(xp), ptr(wc), ptr(y), 64, ptr(st), None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
+gy = torch.randn_like(y)
+gw = torch.zeros(64, 147, device="cuda")
+cm = torch.arange(224, dtype=torch.int32, device="cuda") % 147
+t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), 64, ptr(xp), ptr(gw), 147, ptr(cm), one, 1024, None))
+fl = 2.0 * g.M * 64 * 147
+print("stem 7x7/2 3->64        M=%8d  fwd %7.1f us %6.0f TF(real) out %5.2f TB/s | wgrad %7.1f us %6.0f TF(real)"
+      % (g.M, t_f, fl / t_f / 1e6, y.numel() * 2 / t_f / 1e6, t_w, fl / t_w / 1e6))

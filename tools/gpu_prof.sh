@@ -1,0 +1,25 @@
+#!/bin/bash
+# bench + rocprofv3 kernel stats (+ optional PMC passes with PMC=1); summaries land in gpurun_out/prof_$TAG
+cd "$GRAFT_REPO_ROOT" || exit 1
+TAG=${TAG:-cur}; R=$GRAFT_REPO_ROOT
+mkdir -p gpurun_out/prof_$TAG; export TMPDIR=/tmp
+timeout 600 python bench.py --steps 20 --warmup 5 ${BENCH_ARGS} > gpurun_out/prof_$TAG/bench.json 2> gpurun_out/prof_$TAG/bench.err; tail -1 gpurun_out/prof_$TAG/bench.json
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
+cp /tmp/prof_stats/r_kernel_stats.csv $R/gpurun_out/prof_$TAG/kernel_stats.csv
+python3 - <<PY
+import csv
+rows=list(csv.DictReader(open('/tmp/prof_stats/r_kernel_trace.csv')))
+names=[r['Kernel_Name'] for r in rows]
+st=[i for i,n in enumerate(names) if 'nchw_to_padded' in n]
+s,e=st[-2],st[-1]
+with open('$R/gpurun_out/prof_$TAG/one_step_trace.csv','w') as f:
+    w=csv.writer(f); w.writerow(['start_us','dur_us','grid','kernel'])
+    t0=int(rows[s]['Start_Timestamp'])
+    for r in rows[s:e]:
+        w.writerow([round((int(r['Start_Timestamp'])-t0)/1e3,1), round((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3,1), r['Grid_Size_X'], r['Kernel_Name'][:110]])
+print('step wall us', (int(rows[e]['Start_Timestamp'])-int(rows[s]['Start_Timestamp']))/1e3)
+PY
+if [ -n "$PMC" ]; then for c in FETCH_SIZE WRITE_SIZE; do
+  cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-events > /dev/null 2>&1
+  cp /tmp/prof_$c/r_counter_collection.csv $R/gpurun_out/prof_$TAG/pmc_$c.csv
+done; fi

@@ -154,18 +154,28 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
   }
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  for (long r = r0 + rl; r < r1; r += rlanes) {
-    PieceView<T> vg, vy, vm;
-    vg.p = reinterpret_cast<const piece_t*>(g)[r * cpr + cp];
-    vy.p = reinterpret_cast<const piece_t*>(y)[r * cpr + cp];
-    if (gate) vm.p = reinterpret_cast<const piece_t*>(gate)[r * cpr + cp];
+  // four rows per iteration, all loads issued before the arithmetic (memory-level parallelism)
+  constexpr int U = 4;
+  for (long r = r0 + rl; r < r1; r += (long)U * rlanes) {
+    PieceView<T> vg[U], vy[U], vm[U];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float gv = (float)vg.e[e];
-      if (gate && !((float)vm.e[e] > 0.f)) gv = 0.f;
-      s1[e] += gv;
-      s2[e] += gv * ((float)vy.e[e] - mu[e]) * is[e];
+    for (int u = 0; u < U; ++u) {
+      const long rr = r + (long)u * rlanes;
+      const bool in = rr < r1;
+      const long idx = (in ? rr : r) * cpr + cp;
+      vg[u].p = in ? reinterpret_cast<const piece_t*>(g)[idx] : zero_piece();
+      vy[u].p = reinterpret_cast<const piece_t*>(y)[idx];
+      if (gate) vm[u].p = reinterpret_cast<const piece_t*>(gate)[idx];
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float gv = (float)vg[u].e[e];
+        if (gate && !((float)vm[u].e[e] > 0.f)) gv = 0.f;
+        s1[e] += gv;
+        s2[e] += gv * ((float)vy[u].e[e] - mu[e]) * is[e];
+      }
   }
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {

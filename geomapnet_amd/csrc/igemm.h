@@ -8,23 +8,26 @@
 // Bw is the weight matrix with K contiguous per output channel ("OHWI" for forward,
 // [Cin][R][S][Cout] for the data gradient).
 //
-// Tiling: 256 threads = 4 waves (2x2); block tile 128 x BN; each wave owns a 64 x (BN/2) sub-tile
-// made of 32x32 MFMA tiles (v_mfma_f32_32x32x16_f16 for half, v_mfma_f32_32x32x2_f32 for float;
-// fp32 accumulate).  K advances NP 16-byte pieces per row per step (NP = 8: 128 B, one full cache
-// line per gathered pixel; NP = 4 for the stem whose K is not a multiple of 128 B).  Tiles are
-// staged global -> registers -> LDS (double buffered, one barrier per K-step) with the next tile's
-// global loads in flight during the MFMAs.  The 16-byte slot index inside an LDS row is
-// XOR-swizzled with the row so the 16-lane groups of ds_read_b128 hit 16 distinct slots
-// (MI355X_MICROARCH.md "LDS").
-//
-// Gather cost: each thread precomputes, once, the pixel offset of its rows and a bit mask of the
-// taps that fall inside the image; a K-step then costs one shift/and/add per row.
-// Workgroup ids are remapped so each XCD (private L2) walks a contiguous range of output tiles with
-// the N tiles of one M tile adjacent (they share the gathered A rows).
-//
-// Epilogue: alpha, bias, ReLU and the BatchNorm column partial sums in registers; the tile is then
-// staged through LDS (fp32) so that global stores -- and the residual / ReLU-gate loads of the
-// data-gradient path -- are full 16-byte pieces along channels.
+// Structure (one kernel template, several tile configurations):
+//   * WM x WN waves (64 lanes each); every wave owns a 64 x (TN*32) sub-tile made of 32x32 MFMA tiles
+//     (v_mfma_f32_32x32x16_f16 for half, v_mfma_f32_32x32x2_f32 for float; fp32 accumulate);
+//     block tile BM x BN = (WM*64) x (WN*TN*32).
+//   * Tiles go global -> LDS directly with global_load_lds_dwordx4 (LDS-DMA: no VGPR staging, no ds_write
+//     pass) into an NBUF-deep ring with NBUF-1 tiles in flight, one raw s_barrier per K-step and counted
+//     s_waitcnt vmcnt (cdna_hip_programming.md section 5, "glds").  K advances NP 16-byte pieces per row
+//     per step.  The DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle that keeps
+//     ds_read_b128 conflict-free is applied to the SOURCE piece a lane fetches and to the slot a fragment
+//     read addresses (same involution on both sides).  Taps outside the image fetch from `zero_page`.
+//   * Gather cost: each thread precomputes, once, the element offset of its rows and a bit mask of the taps
+//     that fall inside the image; a K-step then costs one shift/and/add per row.
+//   * Workgroup ids are remapped so each XCD (private L2) walks a contiguous range of output tiles with the N
+//     tiles of one M tile adjacent (they share the gathered A rows).
+//   * Why large tiles: a 128x128 tile moves 64 B of L1->LDS traffic per 4096 MACs and saturates the CU's
+//     64 B/clk vector-memory path at ~27 % of the MFMA peak (measured); 256-row tiles
+//     cut the bytes per MAC by 25-50 %.
+//   * Epilogue: alpha, bias, ReLU and the BatchNorm column partial sums in registers; the tile is then staged
+//     through LDS (fp32, 64x128 sub-blocks) so that global stores -- and the residual / ReLU-gate loads of the
+//     data-gradient path -- are full 16-byte pieces along channels.
 #pragma once
 #include <stdlib.h>
 
@@ -83,252 +86,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// Shared epilogue: acc -> (alpha, bias, ReLU, BN partial sums) -> fp32 staging in LDS -> 16-byte stores
-// with optional residual / ReLU-gate.  `stage` must hold 64*BN floats, `red` 2*BN*2 floats; all waves
-// must be past their last read of the LDS tiles.
-template <typename T, int BN>
-__device__ __forceinline__ void igemm_epilogue(const GatherGeom& g, const Epilogue& ep, floatx16 (&acc)[2][BN / 64],
-                                               float* stage, float (*red)[BN][2], int m0, int n0, int tile_m) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  constexpr int WN = 2, WTM = 64, WTN = BN / WN, TM = 2, TN = WTN / 32;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  T* out = reinterpret_cast<T*>(ep.out);
-  const T* res = reinterpret_cast<const T*>(ep.res);
-  const T* gate = reinterpret_cast<const T*>(ep.res_gate);
-  float s1[TN], s2[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
-  constexpr int CPR = BN / VEC;         // output pieces per tile row
-  constexpr int PASSES = 64 * CPR / 256;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int lc = wn * WTN + j * 32 + (lane & 31);
-      const float bias = (ep.bias && n0 + lc < g.N) ? ep.bias[n0 + lc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] * ep.alpha + bias;
-        if (ep.relu) v = fmaxf(v, 0.f);
-        s1[j] += v;
-        s2[j] += v * v;
-        const int lr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        stage[lr * BN + lc] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int id = t + ps * 256;
-      const int lr = id / CPR, cpi = id % CPR;
-      const int row = m0 + (lr >> 5) * WTM + i * 32 + (lr & 31);
-      const int col = n0 + cpi * VEC;
-      if (row < g.M && col < g.N) {
-        float v[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; e += 4) {
-          floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * BN + cpi * VEC + e]);
-          v[e] = f[0];
-          v[e + 1] = f[1];
-          v[e + 2] = f[2];
-          v[e + 3] = f[3];
-        }
-        const long idx = (long)row * ep.ldc + col;
-        if (res) {
-          PieceView<T> rv, gv;
-          rv.p = *reinterpret_cast<const piece_t*>(res + idx);
-          if (gate) gv.p = *reinterpret_cast<const piece_t*>(gate + idx);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            float x = (float)rv.e[e];
-            if (gate && !((float)gv.e[e] > 0.f)) x = 0.f;
-            v[e] += x;
-          }
-        }
-        PieceView<T> o;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) o.e[e] = (T)v[e];
-        *reinterpret_cast<piece_t*>(out + idx) = o.p;
-      }
-    }
-    __syncthreads();
-  }
-  if (ep.stats) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      s1[j] += __shfl_xor(s1[j], 32);
-      s2[j] += __shfl_xor(s2[j], 32);
-      if (lane < 32) {
-        red[wm][wn * WTN + j * 32 + lane][0] = s1[j];
-        red[wm][wn * WTN + j * 32 + lane][1] = s2[j];
-      }
-    }
-    __syncthreads();
-    if (t < BN && n0 + t < g.N) {
-      ep.stats[((long)tile_m * 2 + 0) * g.N + n0 + t] = red[0][t][0] + red[1][t][0];
-      ep.stats[((long)tile_m * 2 + 1) * g.N + n0 + t] = red[0][t][1] + red[1][t][1];
-    }
-  }
-}
-
-template <typename T, int BN, int NP>
-static __global__ void __launch_bounds__(256) igemm_kernel(GatherGeom g, const T* __restrict__ A, const T* __restrict__ Bw,
-                                                            Epilogue ep, int grid_n) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  constexpr int BM = 128;
-  constexpr int WN = 2;
-  constexpr int WTM = 64, WTN = BN / WN;
-  constexpr int TM = 2, TN = WTN / 32;
-  constexpr int RPP = 256 / NP;            // rows covered by one pass of the 256 loader threads
-  constexpr int APT = BM / RPP, BPT = BN / RPP;
-  static_assert(APT >= 1 && BPT >= 1 && TN >= 1, "tile too small");
-  constexpr int LDS_PIECES = (BM + BN) * NP;
-  static_assert(2 * LDS_PIECES * 16 >= 64 * BN * 4, "epilogue staging does not fit");
-
-  __shared__ piece_t lds[2][LDS_PIECES];
-  __shared__ float red[2][BN][2];
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = tile / grid_n, tile_n = tile - tile_m * grid_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int pc = t % NP, lrow = t / NP;
-
-  // ---- per-row gather state: pixel offset of tap (0,0) and validity mask over taps ---------
-  const int dsh = g.div == 2 ? 1 : 0;
-  const int ntaps = g.R * g.S;
-  int a_pix[APT];
-  unsigned a_mask[APT];
-#pragma unroll
-  for (int i = 0; i < APT; ++i) {
-    const int m = m0 + lrow + i * RPP;
-    a_pix[i] = 0;
-    a_mask[i] = 0u;
-    if (m < g.M) {
-      const int q = m % g.Q, tmp = m / g.Q;
-      const int p = tmp % g.P, b = tmp / g.P;
-      const int h0 = p * g.mul_p + g.off_h, w0 = q * g.mul_q + g.off_w;
-      a_pix[i] = (b * g.Hi + (h0 >> dsh)) * g.Wi + (w0 >> dsh);
-      int tap = 0;
-      for (int r = 0; r < g.R; ++r)
-        for (int s = 0; s < g.S; ++s, ++tap) {
-          int hn = h0 + g.rsign * r, wn_ = w0 + g.ssign * s;
-          bool ok = true;
-          if (dsh) {
-            ok = ((hn | wn_) & 1) == 0;
-            hn >>= 1;
-            wn_ >>= 1;
-          }
-          ok = ok && (unsigned)hn < (unsigned)g.Hi && (unsigned)wn_ < (unsigned)g.Wi;
-          a_mask[i] |= (ok ? 1u : 0u) << tap;
-        }
-    }
-  }
-  (void)ntaps;
-  long b_off[BPT];
-#pragma unroll
-  for (int i = 0; i < BPT; ++i) {
-    const int n = n0 + lrow + i * RPP;
-    b_off[i] = n < g.N ? (long)n * g.K + pc * VEC : -1;
-  }
-  const int CP = g.C / VEC;  // pieces per tap
-  int cp = pc, tr = 0, ts = 0;
-  while (cp >= CP) {
-    cp -= CP;
-    if (++ts == g.S) {
-      ts = 0;
-      ++tr;
-    }
-  }
-
-  piece_t ra[APT], rb[BPT];
-  auto load_tile = [&](int kt) {
-    const int tap = tr * g.S + ts;
-    // tap offset in pixels; with div = 2 (rsign = ssign = -1) valid taps sit at -(r/2), -(s/2)
-    const int toff = (g.rsign * (tr >> dsh) * g.Wi + g.ssign * (ts >> dsh)) * g.C + cp * VEC;
-#pragma unroll
-    for (int i = 0; i < APT; ++i) {
-      const bool ok = (a_mask[i] >> tap) & 1u;
-      const int off = a_pix[i] * g.C + toff;
-      ra[i] = ok ? *reinterpret_cast<const piece_t*>(A + off) : zero_piece();
-    }
-#pragma unroll
-    for (int i = 0; i < BPT; ++i)
-      rb[i] = b_off[i] >= 0 ? *reinterpret_cast<const piece_t*>(Bw + b_off[i] + (long)kt * (NP * VEC)) : zero_piece();
-    cp += NP;
-    while (cp >= CP) {
-      cp -= CP;
-      if (++ts == g.S) {
-        ts = 0;
-        ++tr;
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < APT; ++i) {
-      const int row = lrow + i * RPP;
-      lds[buf][row * NP + (pc ^ lds_swz<NP>(row))] = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int row = lrow + i * RPP;
-      lds[buf][(BM + row) * NP + (pc ^ lds_swz<NP>(row))] = rb[i];
-    }
-  };
-
-  floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int KT = g.K / (NP * VEC);
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    const bool more = kt + 1 < KT;
-    if (more) load_tile(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < NP / 2; ++ks) {
-      PieceView<T> fa[TM], fb[TN];
-      const int piece = ks * 2 + (lane >> 5);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * WTM + i * 32 + (lane & 31);
-        fa[i].p = lds[cur][row * NP + (piece ^ lds_swz<NP>(row))];
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * WTN + j * 32 + (lane & 31);
-        fb[j].p = lds[cur][(BM + row) * NP + (piece ^ lds_swz<NP>(row))];
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) mma_piece<T>(fa[i], fb[j], acc[i][j]);
-    }
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  igemm_epilogue<T, BN>(g, ep, acc, reinterpret_cast<float*>(&lds[0][0]), red, m0, n0, tile_m);
-}
-
-// ---- LDS-DMA pipelined variant ----------------------------------------------------------------
-// Same tiling and epilogue, but tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPR
-// staging, no ds_write pass) into an NBUF-deep ring with NBUF-1 tiles in flight, one raw s_barrier
-// per K-step and counted s_waitcnt vmcnt (cdna_hip_programming.md section 5, "glds").  The DMA writes
-// LDS linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the SOURCE piece a lane
-// fetches and, as before, to the slot a fragment read addresses (same involution on both sides).
-// Taps that fall outside the image fetch from `zero_page` (>= 16 zero bytes in HBM).
 typedef const void __attribute__((address_space(1)))* gas_ptr_t;
 typedef void __attribute__((address_space(3)))* las_ptr_t;
 __device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
@@ -340,26 +97,27 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <typename T, int BN, int NP, int NBUF>
-static __global__ void __launch_bounds__(256) igemm_dma_kernel(GatherGeom g, const T* __restrict__ A,
-                                                                const T* __restrict__ Bw, Epilogue ep, int grid_n,
-                                                                const T* __restrict__ zero_page) {
+template <typename T, int WM, int WN, int TN, int NP, int NBUF, int MINW>
+static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
+                                                                         const T* __restrict__ Bw, Epilogue ep, int grid_n,
+                                                                         const T* __restrict__ zero_page) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  constexpr int BM = 128;
-  constexpr int WN = 2;
-  constexpr int WTM = 64, WTN = BN / WN;
-  constexpr int TM = 2, TN = WTN / 32;
-  constexpr int RPP = 256 / NP;
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * 64, BN = WN * TN * 32;
+  constexpr int WTM = 64, WTN = TN * 32, TM = 2;
+  constexpr int RPP = NT / NP;  // rows covered by one DMA pass of all threads
   constexpr int APT = BM / RPP, BPT = BN / RPP;
   constexpr int IPT = APT + BPT;  // DMA instructions per wave per tile
   constexpr int TILE_PIECES = (BM + BN) * NP;
-  constexpr int D = NBUF - 1;     // tiles in flight
+  constexpr int D = NBUF - 1;  // tiles in flight
+  static_assert(APT >= 1 && BPT >= 1, "tile too small for the thread count");
   static_assert(D >= 1 && D <= 3, "ring depth");
-  static_assert(NBUF * TILE_PIECES * 16 >= 64 * BN * 4, "epilogue staging does not fit");
+  static_assert(RPP % 16 == 0, "swizzle must not see the per-thread row stride");
+  static_assert(NBUF * TILE_PIECES * 16 >= 64 * 128 * 4, "epilogue staging does not fit");
   // ONE LDS object (a second one makes hipcc drain vmcnt before every fragment read):
-  // [ring of tiles][BatchNorm partial reduction: 2*BN*2 floats]
-  __shared__ piece_t smem[NBUF * TILE_PIECES + BN];
-  float(*red)[BN][2] = reinterpret_cast<float(*)[BN][2]>(&smem[NBUF * TILE_PIECES]);
+  // [ring of tiles][BatchNorm partial reduction: WM*BN*2 floats]
+  __shared__ piece_t smem[NBUF * TILE_PIECES + WM * BN / 2];
+  float* red = reinterpret_cast<float*>(&smem[NBUF * TILE_PIECES]);  // [WM][BN][2]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -404,7 +162,7 @@ static __global__ void __launch_bounds__(256) igemm_dma_kernel(GatherGeom g, con
   }
   const int CP = g.C / VEC;  // pieces per tap
   // Source piece of this lane inside a K-step: the XOR swizzle is applied on the source side.  Rows of
-  // one lane differ by multiples of RPP (>= 32), which the swizzle ignores, so one value serves all rows.
+  // one lane differ by multiples of RPP (a multiple of 16), which the swizzle ignores.
   const int src_piece = pc ^ lds_swz<NP>(lrow);
   // running decomposition of piece index q = kt*NP + src_piece into (tap = (tr, ts), channel piece cpi)
   int cpi = src_piece, tr = 0, ts = 0, tap = 0;
@@ -432,7 +190,6 @@ static __global__ void __launch_bounds__(256) igemm_dma_kernel(GatherGeom g, con
       const T* src = b_row[i] >= 0 ? Bw + b_row[i] + b_src : zero_page;
       dma16(src, base + (BM + i * RPP) * NP);
     }
-    // advance to the next K-step
     b_src += NP * VEC;
     cpi += NP;
     while (cpi >= CP) {
@@ -470,85 +227,182 @@ static __global__ void __launch_bounds__(256) igemm_dma_kernel(GatherGeom g, con
     __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everyone is done reading buffer `nxt`
     if (kt + D < KT) issue_tile(nxt);  // tiles are issued strictly in K order
     const piece_t* ta = &smem[cur * TILE_PIECES];
-#pragma unroll
-    for (int ks = 0; ks < NP / 2; ++ks) {
-      PieceView<T> fa[TM], fb[TN];
+    // fragments are register double-buffered: the ds_reads of sub-step ks+1 are issued before the MFMAs
+    // of sub-step ks so LDS latency hides under the matrix pipe
+    PieceView<T> fa[2][TM], fb[2][TN];
+    auto load_frags = [&](int ks, int slot) {
       const int piece = ks * 2 + (lane >> 5);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * WTM + i * 32 + (lane & 31);
-        fa[i].p = ta[row * NP + (piece ^ lds_swz<NP>(row))];
+        fa[slot][i].p = ta[row * NP + (piece ^ lds_swz<NP>(row))];
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WTN + j * 32 + (lane & 31);
-        fb[j].p = ta[(BM + row) * NP + (piece ^ lds_swz<NP>(row))];
+        fb[slot][j].p = ta[(BM + row) * NP + (piece ^ lds_swz<NP>(row))];
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < NP / 2; ++ks) {
+      if (ks + 1 < NP / 2) load_frags(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the next sub-step's ds_reads ahead of these MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma_piece<T>(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) mma_piece<T>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     cur = cur + 1 == NBUF ? 0 : cur + 1;
     nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
   }
   __syncthreads();  // all fragment reads done before the ring is reused as epilogue staging
-  igemm_epilogue<T, BN>(g, ep, acc, reinterpret_cast<float*>(&smem[0]), red, m0, n0, tile_m);
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  T* out = reinterpret_cast<T*>(ep.out);
+  const T* res = reinterpret_cast<const T*>(ep.res);
+  const T* gate = reinterpret_cast<const T*>(ep.res_gate);
+  float* stage = reinterpret_cast<float*>(&smem[0]);  // [64][SC] fp32 sub-block
+  constexpr int SC = BN < 128 ? BN : 128;             // columns staged per round
+  constexpr int CPR = SC / VEC;                       // output pieces per staged row
+  constexpr int PASSES = (64 * CPR + NT - 1) / NT;
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+  // rounds: (tile row i of each wave) x (pairs of wave rows) x (128-column blocks)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+    for (int mh = 0; mh < WM / 2; ++mh)
+      for (int nh = 0; nh < BN / SC; ++nh) {
+        if ((wm >> 1) == mh) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int lc = wn * WTN + j * 32 + (lane & 31);  // column inside the block tile
+            if (lc / SC == nh) {
+              const float bias = (ep.bias && n0 + lc < g.N) ? ep.bias[n0 + lc] : 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] * ep.alpha + bias;
+                if (ep.relu) v = fmaxf(v, 0.f);
+                s1[j] += v;
+                s2[j] += v * v;
+                const int lr = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                stage[lr * SC + (lc - nh * SC)] = v;
+              }
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int id = t + ps * NT;
+          const int lr = id / CPR, cpc = id % CPR;
+          const int row = m0 + (2 * mh + (lr >> 5)) * WTM + i * 32 + (lr & 31);
+          const int col = n0 + nh * SC + cpc * VEC;
+          if (lr < 64 && row < g.M && col < g.N) {
+            float v[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+              floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * SC + cpc * VEC + e]);
+              v[e] = f[0];
+              v[e + 1] = f[1];
+              v[e + 2] = f[2];
+              v[e + 3] = f[3];
+            }
+            const long idx = (long)row * ep.ldc + col;
+            if (res) {
+              PieceView<T> rv, gv;
+              rv.p = *reinterpret_cast<const piece_t*>(res + idx);
+              if (gate) gv.p = *reinterpret_cast<const piece_t*>(gate + idx);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                float x = (float)rv.e[e];
+                if (gate && !((float)gv.e[e] > 0.f)) x = 0.f;
+                v[e] += x;
+              }
+            }
+            PieceView<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.e[e] = (T)v[e];
+            *reinterpret_cast<piece_t*>(out + idx) = o.p;
+          }
+        }
+        __syncthreads();
+      }
+  if (ep.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+      if (lane < 32) {
+        const int lc = wn * WTN + j * 32 + lane;
+        red[(wm * BN + lc) * 2 + 0] = s1[j];
+        red[(wm * BN + lc) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    for (int c = t; c < BN; c += NT)
+      if (n0 + c < g.N) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          a += red[(w * BN + c) * 2 + 0];
+          b += red[(w * BN + c) * 2 + 1];
+        }
+        ep.stats[((long)tile_m * 2 + 0) * g.N + n0 + c] = a;
+        ep.stats[((long)tile_m * 2 + 1) * g.N + n0 + c] = b;
+      }
+  }
 }
 
-// number of M-blocks the launcher will use (needed to size the stats partial buffer)
+// upper bound of the number of M-blocks a launch uses (sizes the BatchNorm partial buffer)
 inline int igemm_grid_m(int M) { return cdiv(M, 128); }
 
-// Variant selection.  MN_IGEMM_VARIANT (tuning knob, read once): 0 register-staged double buffer;
-// 1 DMA 128-B steps x2 buffers; 2 DMA 128-B x3; 3 DMA 64-B x4; 4 DMA 64-B x3.  DMA variants need a zero page.
-inline int igemm_variant() {
+// Tile configuration.  MN_IGEMM_CONFIG (tuning knob, read once) overrides the per-shape choice:
+//   1: 128x128 / 128x64, 4 waves, 128-byte steps, 2 buffers          (2 blocks/CU)
+//   2: 256x128, 8 waves, 64-byte steps, 2 buffers, registers capped   (2 blocks/CU)
+//   3: 256x128, 8 waves, 128-byte steps, 2 buffers                    (1 block/CU)
+//   4: 256x256, 8 waves, 64-byte steps, 2 buffers                     (1 block/CU)
+//   5: as 1, but 256x64 (4x1 waves) for N <= 64
+inline int igemm_config() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("MN_IGEMM_VARIANT");
-    v = e ? atoi(e) : 1;  // measured best on MI355X (tools/conv_bench.py): DMA, 128-byte steps, 2 buffers
+    const char* e = getenv("MN_IGEMM_CONFIG");
+    v = e ? atoi(e) : 0;
   }
   return v;
 }
 
-template <typename T, int BN>
-inline void launch_igemm_bn(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
-                            const T* zero_page, int gm, int gn) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  dim3 block(256), grid(gm * gn);
-  const bool wide_k = (g.K % (8 * VEC)) == 0;
-  const int cp = g.C / VEC;
-  const bool dma_ok = zero_page != nullptr && (cp & (cp - 1)) == 0;
-  int v = dma_ok ? igemm_variant() : 0;
-  if (!wide_k && (v == 1 || v == 2)) v = 3;
-  switch (v) {
-    case 1:
-      hipLaunchKernelGGL((igemm_dma_kernel<T, BN, 8, 2>), grid, block, 0, stream, g, A, Bw, ep, gn, zero_page);
-      break;
-    case 2:
-      hipLaunchKernelGGL((igemm_dma_kernel<T, BN, 8, 3>), grid, block, 0, stream, g, A, Bw, ep, gn, zero_page);
-      break;
-    case 3:
-      hipLaunchKernelGGL((igemm_dma_kernel<T, BN, 4, 4>), grid, block, 0, stream, g, A, Bw, ep, gn, zero_page);
-      break;
-    case 4:
-      hipLaunchKernelGGL((igemm_dma_kernel<T, BN, 4, 3>), grid, block, 0, stream, g, A, Bw, ep, gn, zero_page);
-      break;
-    default:
-      if (wide_k)
-        hipLaunchKernelGGL((igemm_kernel<T, BN, 8>), grid, block, 0, stream, g, A, Bw, ep, gn);
-      else
-        hipLaunchKernelGGL((igemm_kernel<T, BN, 4>), grid, block, 0, stream, g, A, Bw, ep, gn);
-  }
+template <typename T, int WM, int WN, int TN, int NP, int NBUF, int MINW>
+inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
+                            const T* zero_page) {
+  constexpr int BM = WM * 64, BN = WN * TN * 32;
+  const int gm = cdiv(g.M, BM), gn = cdiv(g.N, BN);
+  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TN, NP, NBUF, MINW>), dim3(gm * gn), dim3(WM * WN * 64), 0, stream, g, A, Bw,
+                     ep, gn, zero_page);
+  return gm;
 }
 
+// returns the number of M-blocks used (= rows of the stats partial buffer that were written)
 template <typename T>
-inline void launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
-                         const T* zero_page = nullptr) {
-  const int gm = cdiv(g.M, 128);
-  if (g.N <= 64)
-    launch_igemm_bn<T, 64>(g, A, Bw, ep, stream, zero_page, gm, cdiv(g.N, 64));
-  else
-    launch_igemm_bn<T, 128>(g, A, Bw, ep, stream, zero_page, gm, cdiv(g.N, 128));
+inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
+                        const T* zero_page) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const bool wide_k = (g.K % (8 * VEC)) == 0;
+  int cfg = igemm_config();
+  if (cfg == 0) cfg = 1;  // default until per-shape tuning says otherwise
+  if (g.N <= 64) {
+    if (cfg != 1) return launch_igemm_cfg<T, 4, 1, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);
+    if (wide_k) return launch_igemm_cfg<T, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
+    return launch_igemm_cfg<T, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
+  }
+  if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 3 && wide_k) return launch_igemm_cfg<T, 4, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 4 && g.N >= 256) return launch_igemm_cfg<T, 4, 2, 4, 4, 2, 2>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 4) return launch_igemm_cfg<T, 4, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
+  if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
+  return launch_igemm_cfg<T, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
 }
 
 }  // namespace mn

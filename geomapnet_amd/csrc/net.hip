@@ -380,11 +380,10 @@ struct Plan : PlanBase {
     ep.out = u.y; ep.ldc = u.cp.cout; ep.stats = training ? stats_partial : nullptr; ep.bias = nullptr; ep.relu = 0;
     ep.res = nullptr; ep.res_gate = nullptr; ep.alpha = 1.f;
     auto* tp = timer.begin(0, s);
-    launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
+    const int GM = launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
     timer.end(tp, s);
     int N = u.cp.cout;
     if (training) {
-      int GM = igemm_grid_m((int)u.M);
       hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(GM, 64), cdiv(N, 64)), dim3(256), 0, s,
                          (const float*)stats_partial, GM, N, u.accum, 64);
     }
@@ -429,7 +428,7 @@ struct Plan : PlanBase {
     Epilogue ep;
     ep.out = feat; ep.ldc = F; ep.stats = nullptr; ep.bias = params + L.fc_b; ep.relu = 1; ep.res = nullptr;
     ep.res_gate = nullptr; ep.alpha = 1.f;
-    launch_igemm<float>(g, (const float*)pooled, (const float*)(params + L.fc_w), ep, s);
+    launch_igemm<float>(g, (const float*)pooled, (const float*)(params + L.fc_w), ep, s, (const float*)zero_page);
     hipLaunchKernelGGL(head_fwd_kernel, dim3(cdiv((long)B * 6 * 64, 256)), dim3(256), 0, s, (const float*)feat,
                        (const float*)(params + L.xyz_w), (const float*)(params + L.xyz_b),
                        (const float*)(params + L.wpqr_w), (const float*)(params + L.wpqr_b), poses, B, F);
@@ -464,7 +463,7 @@ struct Plan : PlanBase {
     a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
     a.alpha = 1.f / cfg.loss_scale; a.rows_per_split = 0;
     auto* tp = timer.begin(1, s);
-    launch_wgrad<T>(a, 1024, s);
+    launch_wgrad<T>(a, 1024, s, zero_page);
     timer.end(tp, s);
   }
   void conv_dgrad(Unit& u, T* gx, const T* res, const T* gate, hipStream_t s) {
@@ -516,7 +515,7 @@ struct Plan : PlanBase {
     Epilogue ep;
     ep.out = dpooled; ep.ldc = 512; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = nullptr;
     ep.res_gate = nullptr; ep.alpha = 1.f;
-    launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s);
+    launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s, (const float*)zero_page);
     Block& last = blocks.back();
     hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
                        (const float*)dpooled, last.gout, B, Hl * Wl, 512);

@@ -55,6 +55,7 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   begin_call();
   GatherGeom g = to_geom(gg);
   if (int e = check_geom(g, dtype)) return e;
+  if (!zero_page) return fail("igemm: zero_page (>= 16 zero bytes of device memory) is required");
   Epilogue ep;
   ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
   ep.alpha = alpha;
@@ -66,7 +67,7 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
 }
 
 extern "C" int mn_op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
-                           const int32_t* colmap, float alpha, int target_blocks, void* stream) {
+                           const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream) {
   begin_call();
   WgradArgs a;
   a.g = to_geom(gg);
@@ -74,7 +75,7 @@ extern "C" int mn_op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, 
   if (a.g.C % vec != 0 || a.g.N % vec != 0) return fail("wgrad: channel counts must be multiples of the piece");
   a.dY = dY; a.ldy = ldy; a.X = X; a.dW = dW; a.ldw = ldw; a.colmap = colmap; a.alpha = alpha; a.rows_per_split = 0;
   if (dtype == MN_F16)
-    launch_wgrad<half>(a, target_blocks, (hipStream_t)stream);
+    launch_wgrad<half>(a, target_blocks, (hipStream_t)stream, zero_page);
   else
     launch_wgrad<float>(a, target_blocks, (hipStream_t)stream);
   return check_launch("wgrad");

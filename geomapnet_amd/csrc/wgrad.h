@@ -175,20 +175,222 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---- fp16 weight gradient: LDS-DMA staging + hardware transpose reads ---------------------------------
+// Tiles are DMA'd as stored ([m][channel], 16-byte pieces, double-buffered, 64 rows of m per step) and the
+// MFMA fragments (8 consecutive m for one channel) come from two ds_read_b64_tr_b16 each instead of eight
+// 16-bit LDS reads.  Transpose-read semantics (measured, tools/probes/tr_probe.hip): in every group of 16
+// lanes, result lane i / element e is element i%4 of the 8-byte chunk addressed by source lane 4e + i/4;
+// so source lane 4e+j addresses row (k0 + e), channels [c0 + 4j, c0 + 4j + 4) and lane i receives
+// k0..k0+3 of channel c0 + i.  The 16-byte piece index of a row is XOR-swizzled with the row (on the DMA
+// source side and in the read address) so the four rows of a transpose read fall in distinct bank groups.
+typedef short v4s16 __attribute__((__vector_size__(8)));
+__device__ __forceinline__ v4s16 ds_read_tr16(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)p);
+}
+union TrFrag {
+  v4s16 h[2];
+  half8 v;
+};
+template <int PIECES_PER_ROW>
+__device__ __forceinline__ int wg_swz(int row) {
+  return (row & 3) << (PIECES_PER_ROW == 16 ? 2 : 1);
+}
+
+template <int BMO, int BNO, int BKM, int MINW>
+static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a, const half* __restrict__ zero_page) {
+  constexpr int VEC = 8;  // BKM = m rows per step (32 or 64)
+  constexpr int YCP = BMO / VEC, XCP = BNO / VEC;
+  constexpr int YPT = BKM * YCP / 256, XPT = BKM * XCP / 256;  // DMA instructions per thread per tile
+  constexpr int YRS = 256 / YCP, XRS = 256 / XCP;              // rows covered per DMA pass
+  constexpr int TM = BMO / 64, TN = BNO / 64;
+  constexpr int TILE_Y = BKM * BMO, TILE_X = BKM * BNO;        // halves
+  __shared__ half smem[2 * (TILE_Y + TILE_X)] __attribute__((aligned(16)));
+
+  const GatherGeom& g = a.g;
+  const GatherGeom& g_ = a.g;
+  const half* dY = reinterpret_cast<const half*>(a.dY);
+  const half* X = reinterpret_cast<const half*>(a.X);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware order over a 1-D grid: tiles of one m-range (same split) are adjacent on one XCD, so the
+  // dY / X rows they share are fetched into that XCD's L2 once
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int gx = ceil_div(g_.N, BMO), gy = ceil_div(g_.K, BNO);
+  const int bx = logical % gx, by = (logical / gx) % gy, bz = logical / (gx * gy);
+  const int n0 = bx * BMO, k0 = by * BNO;
+  const int m_begin = bz * a.rows_per_split;
+  const int m_end = min(g.M, m_begin + a.rows_per_split);
+
+  // dY loader: LDS position (row, slot) holds source piece slot ^ swz(row); rows of one thread differ by
+  // multiples of YRS (>= 16), invisible to the swizzle, so the source piece is fixed per thread
+  const int yslot = t % YCP, yrow = t / YCP;
+  const int ypiece = yslot ^ wg_swz<YCP>(yrow);
+  const bool y_ok = n0 + ypiece * VEC < g.N;
+  const int xslot = t % XCP, xrow = t / XCP;
+  const int xpiece = xslot ^ wg_swz<XCP>(xrow);
+  const int kcol = k0 + xpiece * VEC;
+  const bool x_ok = kcol < g.K;
+  const int tap = x_ok ? kcol / g.C : 0;
+  const int c0 = x_ok ? kcol % g.C : 0;
+  const int dh = g.rsign * (tap / g.S), dw = g.ssign * (tap % g.S);
+  int xb[XPT], xp[XPT], xq[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    int m = m_begin + xrow + i * XRS;
+    xq[i] = m % g.Q;
+    int tmp = m / g.Q;
+    xp[i] = tmp % g.P;
+    xb[i] = tmp / g.P;
+  }
+
+  auto issue_tile = [&](int mt, int buf) {
+    half* ty = &smem[buf * (TILE_Y + TILE_X)];
+    half* tx = ty + TILE_Y;
+#pragma unroll
+    for (int i = 0; i < YPT; ++i) {
+      const int m = mt + yrow + i * YRS;
+      const half* src = (y_ok && m < m_end) ? dY + ((long)m * a.ldy + n0 + ypiece * VEC) : zero_page;
+      dma16(src, ty + (i * YRS * YCP + wave * 64) * VEC);
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int m = mt + xrow + i * XRS;
+      int hn = xp[i] * g.mul_p + g.off_h + dh, wn_ = xq[i] * g.mul_q + g.off_w + dw;
+      bool ok = x_ok && m < m_end;
+      if (g.div == 2) {
+        ok = ok && ((hn | wn_) & 1) == 0;
+        hn >>= 1;
+        wn_ >>= 1;
+      }
+      ok = ok && (unsigned)hn < (unsigned)g.Hi && (unsigned)wn_ < (unsigned)g.Wi;
+      const half* src = ok ? X + ((long)((xb[i] * g.Hi + hn) * g.Wi + wn_) * g.C + c0) : zero_page;
+      dma16(src, tx + (i * XRS * XCP + wave * 64) * VEC);
+      xq[i] += BKM;
+      while (xq[i] >= g.Q) {
+        xq[i] -= g.Q;
+        if (++xp[i] == g.P) {
+          xp[i] = 0;
+          ++xb[i];
+        }
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transpose-read lane geometry: 16-lane group gq = lane/16 -> column block (gq&1)*16, k half (gq>>1)*8;
+  // as SOURCE lane 4e+j this lane addresses row e = (lane&15)/4, chunk j = lane&3
+  const int gq = lane >> 4, i16 = lane & 15;
+  const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
+  const int kgrp = (gq >> 1) * 8;
+
+  if (m_begin < m_end) issue_tile(m_begin, 0);
+  int cur = 0;
+  for (int mt = m_begin; mt < m_end; mt += BKM) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // tile landed for everyone; everyone is done with the other buffer
+    if (mt + BKM < m_end) issue_tile(mt + BKM, cur ^ 1);
+    const half* ty = &smem[cur * (TILE_Y + TILE_X)];
+    const half* tx = ty + TILE_Y;
+#pragma unroll
+    for (int ks = 0; ks < BKM / 16; ++ks) {
+      TrFrag fa[TM], fb[TN];
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const int row = ks * 16 + kgrp + hlf * 4 + src_row;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int col = wm * (BMO / 2) + i * 32 + src_chunk;
+          const int piece = (col >> 3) ^ wg_swz<YCP>(row);
+          fa[i].h[hlf] = ds_read_tr16(ty + row * BMO + piece * 8 + (col & 7));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * (BNO / 2) + j * 32 + src_chunk;
+          const int piece = (col >> 3) ^ wg_swz<XCP>(row);
+          fb[j].h[hlf] = ds_read_tr16(tx + row * BNO + piece * 8 + (col & 7));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i].v, fb[j].v, acc[i][j], 0, 0, 0);
+    }
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int kc = k0 + wn * (BNO / 2) + j * 32 + (lane & 31);
+      int dst = kc < g.K ? (a.colmap ? a.colmap[kc] : kc) : -1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int n = n0 + wm * (BMO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < g.N && dst >= 0) unsafeAtomicAdd(a.dW + (long)n * a.ldw + dst, acc[i][j][r] * a.alpha);
+      }
+    }
+}
+
 template <typename T>
-inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream) {
+struct WgradDma {
+  static bool launch(const WgradArgs&, dim3, int, int, hipStream_t, const void*) { return false; }
+};
+template <>
+struct WgradDma<half> {
+  template <int BKM, int MINW>
+  static void go(const WgradArgs& a, dim3 grid, int bmo, int bno, hipStream_t stream, const half* zp) {
+    dim3 block(256);
+    if (bmo == 64 && bno == 64)
+      hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW>), grid, block, 0, stream, a, zp);
+    else if (bmo == 64)
+      hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW>), grid, block, 0, stream, a, zp);
+    else if (bno == 64)
+      hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW>), grid, block, 0, stream, a, zp);
+    else
+      hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW>), grid, block, 0, stream, a, zp);
+  }
+  static bool launch(const WgradArgs& a, dim3 grid3, int bmo, int bno, hipStream_t stream, const void* zero_page) {
+    const half* zp = reinterpret_cast<const half*>(zero_page);
+    if (!zp || (a.rows_per_split % 64) != 0) return false;
+    dim3 grid(grid3.x * grid3.y * grid3.z);  // 1-D: the kernel derives (cout tile, k tile, split) itself
+    // measured on MI355X (tools/conv_bench.py): 32-row steps with registers capped for 4 blocks/CU beat
+    // 64-row steps at 2 blocks/CU on every 3x3 layer; MN_WGRAD_VARIANT=0 selects the latter (tuning knob)
+    static const int variant = getenv("MN_WGRAD_VARIANT") ? atoi(getenv("MN_WGRAD_VARIANT")) : 1;
+    if (variant == 0)
+      go<64, 2>(a, grid, bmo, bno, stream, zp);
+    else
+      go<32, 4>(a, grid, bmo, bno, stream, zp);
+    return true;
+  }
+};
+
+template <typename T>
+inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, const void* zero_page = nullptr) {
   const GatherGeom& g = a.g;
   const bool narrow_n = g.N <= 64, narrow_k = g.K <= 64 || (g.K % 128 != 0 && g.K < 256);
   int bmo = narrow_n ? 64 : 128, bno = narrow_k ? 64 : 128;
   int tiles = cdiv(g.N, bmo) * cdiv(g.K, bno);
+  static const int env_blocks = getenv("MN_WGRAD_BLOCKS") ? atoi(getenv("MN_WGRAD_BLOCKS")) : 0;  // tuning knob
+  if (env_blocks > 0) target_blocks = env_blocks;
   int splits = cdiv(target_blocks, tiles);
-  int max_splits = cdiv(g.M, 256);  // at least 8 steps per block
+  int max_splits = cdiv(g.M, 512);  // at least 8 steps of 64 rows per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  int rows = cdiv(cdiv(g.M, splits), 32) * 32;
+  int rows = cdiv(cdiv(g.M, splits), 64) * 64;
   splits = cdiv(g.M, rows);
   a.rows_per_split = rows;
   dim3 grid(cdiv(g.N, bmo), cdiv(g.K, bno), splits), block(256);
+  static const bool use_dma = !(getenv("MN_WGRAD_DMA") && atoi(getenv("MN_WGRAD_DMA")) == 0);
+  if (use_dma && WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) return;
   if (bmo == 64 && bno == 64)
     hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, block, 0, stream, a);
   else if (bmo == 64)

@@ -149,7 +149,7 @@ int mn_op_igemm(int dtype, const mn_gather_geom* g, const void* A, const void* B
 int mn_op_igemm_grid_m(int M);
 /* dW[n][colmap(k)] += alpha * sum_m dY[m][n] * gather(X)[m][k]  (fp32 atomics into dW) */
 int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw,
-                const int32_t* colmap, float alpha, int target_blocks, void* stream);
+                const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream);
 /* conv weight layout helpers: OIHW fp32 <-> OHWI fp32 */
 int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream);
 

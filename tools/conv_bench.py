@@ -48,7 +48,7 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
     t_f = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, ptr(st), None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_d = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_r = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), ptr(gate), one, ptr(checks.zero_page("cuda")), None))
-    t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, None))
+    t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, ptr(checks.zero_page("cuda")), None))
     io = (x.numel() + y.numel()) * x.element_size()
     print("%-22s M=%8d N=%4d K=%5d  fwd %7.1f us %6.0f TF (io %5.2f TB/s) | dgrad %7.1f us %6.0f TF | +res %7.1f us | wgrad %7.1f us %6.0f TF"
           % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, io / t_f / 1e6, t_d, flops / t_d / 1e6, t_r, t_w, flops / t_w / 1e6), flush=True)
@@ -71,7 +71,7 @@ t_f = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(xp), ptr(wc), ptr(y), 6
 gy = torch.randn_like(y)
 gw = torch.zeros(64, 147, device="cuda")
 cm = torch.arange(224, dtype=torch.int32, device="cuda") % 147
-t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), 64, ptr(xp), ptr(gw), 147, ptr(cm), one, 1024, None))
+t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), 64, ptr(xp), ptr(gw), 147, ptr(cm), one, 1024, ptr(checks.zero_page("cuda")), None))
 fl = 2.0 * g.M * 64 * 147
 print("stem 7x7/2 3->64        M=%8d  fwd %7.1f us %6.0f TF(real) out %5.2f TB/s | wgrad %7.1f us %6.0f TF(real)"
       % (g.M, t_f, fl / t_f / 1e6, y.numel() * 2 / t_f / 1e6, t_w, fl / t_w / 1e6))

@@ -74,47 +74,49 @@ struct BnParams {
   long long* num_batches_tracked;  // may be null
   float* mean;     // saved batch mean
   float* invstd;   // saved 1/sqrt(var+eps)
-  float* scale;    // gamma * invstd
-  float* shift;    // beta - mean * scale
   float eps, momentum;
 };
 
-// stage 2: statistics -> (mean, invstd, scale, shift), running-stat update, accumulator reset
-static __global__ void __launch_bounds__(256) bn_finalize_kernel(double* __restrict__ accum, int N, double count, BnParams p,
-                                                           int training) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float mean, var;
-  if (training) {
-    double m = accum[c] / count;
-    double v = accum[N + c] / count - m * m;
-    if (v < 0) v = 0;
-    accum[c] = 0;
-    accum[N + c] = 0;
-    mean = (float)m;
-    var = (float)v;
-    double unbiased = count > 1 ? v * count / (count - 1) : v;
-    p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
-    p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
-    if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
-  } else {
-    mean = p.running_mean[c];
-    var = p.running_var[c];
-  }
-  float invstd = 1.0f / sqrtf(var + p.eps);
-  p.mean[c] = mean;
-  p.invstd[c] = invstd;
-  float sc = p.gamma[c] * invstd;
-  p.scale[c] = sc;
-  p.shift[c] = p.beta[c] - mean * sc;
-}
-
-// out = [relu]( y * scale[c] + shift[c] [+ res] ), one piece per thread-iteration
+// Statistics -> per-channel (scale, shift) in the prologue of every workgroup (C <= 512 values, from the
+// fp64 accumulators), then out = [relu]( y * scale[c] + shift[c] [+ res] ), one 16-byte piece per lane.
+// Workgroup 0 also publishes mean / invstd (needed by the backward pass) and updates the running stats.
+// The accumulators are read-only here; the caller zeroes them before the next accumulation.
 template <typename T>
-static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, const T* __restrict__ res,
-                                                        T* __restrict__ out, long npieces, int C, int relu) {
+static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, const double* __restrict__ accum,
+                                                        double count, BnParams p, int training,
+                                                        const T* __restrict__ res, T* __restrict__ out, long npieces,
+                                                        int C, int relu) {
   constexpr int VEC = ElemTraits<T>::VEC;
+  __shared__ float s_scale[512], s_shift[512];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mean, var;
+    double unbiased = 0;
+    if (training) {
+      double m = accum[c] / count;
+      double v = accum[C + c] / count - m * m;
+      if (v < 0) v = 0;
+      mean = (float)m;
+      var = (float)v;
+      unbiased = count > 1 ? v * count / (count - 1) : v;
+    } else {
+      mean = p.running_mean[c];
+      var = p.running_var[c];
+    }
+    const float invstd = 1.0f / sqrtf(var + p.eps);
+    const float sc = p.gamma[c] * invstd;
+    s_scale[c] = sc;
+    s_shift[c] = p.beta[c] - mean * sc;
+    if (blockIdx.x == 0) {
+      p.mean[c] = mean;
+      p.invstd[c] = invstd;
+      if (training) {
+        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+        p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+        if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
+      }
+    }
+  }
+  __syncthreads();
   const int cpr = C / VEC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
     int c0 = (int)(i % cpr) * VEC;
@@ -123,7 +125,7 @@ static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restric
     if (res) r.p = reinterpret_cast<const piece_t*>(res)[i];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float f = (float)v.e[e] * scale[c0 + e] + shift[c0 + e];
+      float f = (float)v.e[e] * s_scale[c0 + e] + s_shift[c0 + e];
       if (res) f += (float)r.e[e];
       if (relu) f = fmaxf(f, 0.f);
       o.e[e] = (T)f;
@@ -138,7 +140,8 @@ template <typename T>
 static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ gate,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long M, int C,
-                                                             double* __restrict__ accum, int rows_per_block) {
+                                                             double* __restrict__ accum, int rows_per_block,
+                                                             float* __restrict__ partial) {
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ float red[2][256][VEC];
   const int cpr = C / VEC;           // pieces per row (power of two, <= 256)
@@ -191,38 +194,41 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
       a += red[0][l * cpr + p][e];
       b += red[1][l * cpr + p][e];
     }
-    atomicAdd(accum + idx, a);
-    atomicAdd(accum + C + idx, b);
+    if (partial) {  // [gridDim.x][2][C] fp32 partials, folded by bn_reduce_partials_kernel (few atomics)
+      partial[((long)blockIdx.x * 2 + 0) * C + idx] = (float)a;
+      partial[((long)blockIdx.x * 2 + 1) * C + idx] = (float)b;
+    } else {
+      atomicAdd(accum + idx, a);
+      atomicAdd(accum + C + idx, b);
+    }
   }
 }
 
-// finalize: dgamma, dbeta (unscaled by 1/loss_scale), per-channel coefficients; reset accumulators
-static __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(double* __restrict__ accum, int C, double count,
-                                                               const float* __restrict__ gamma,
-                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, float* __restrict__ k1,
-                                                               float* __restrict__ mg, float* __restrict__ mgx,
-                                                               float grad_unscale) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sg = accum[c], sgx = accum[C + c];
-  accum[c] = 0;
-  accum[C + c] = 0;
-  dgamma[c] += (float)(sgx * grad_unscale);
-  dbeta[c] += (float)(sg * grad_unscale);
-  k1[c] = gamma[c] * invstd[c];
-  mg[c] = (float)(sg / count);
-  mgx[c] = (float)(sgx / count);
-}
-
-// apply: gy = k1 * (gm - mg - xhat * mgx)
+// apply: gy = k1 * (gm - mg - xhat * mgx) with k1 = gamma*invstd, mg = sum(gm)/M, mgx = sum(gm*xhat)/M derived
+// from the fp64 accumulators in every workgroup's prologue; workgroup 0 adds dgamma / dbeta (times
+// grad_unscale = 1/loss_scale) into the gradient arena.
 template <typename T>
 static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ gate,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, const float* __restrict__ k1,
-                                                            const float* __restrict__ mg, const float* __restrict__ mgx,
-                                                            T* __restrict__ gy, long npieces, int C) {
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const double* __restrict__ accum, double count,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float grad_unscale, T* __restrict__ gy, long npieces, int C) {
   constexpr int VEC = ElemTraits<T>::VEC;
+  __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double sg = accum[c], sgx = accum[C + c];
+    s_k1[c] = gamma[c] * invstd[c];
+    s_mg[c] = (float)(sg / count);
+    s_mgx[c] = (float)(sgx / count);
+    s_mean[c] = mean[c];
+    s_is[c] = invstd[c];
+    if (blockIdx.x == 0) {
+      dgamma[c] += (float)(sgx * grad_unscale);
+      dbeta[c] += (float)(sg * grad_unscale);
+    }
+  }
+  __syncthreads();
   const int cpr = C / VEC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
     int c0 = (int)(i % cpr) * VEC;
@@ -235,8 +241,8 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
       int c = c0 + e;
       float gv = (float)vg.e[e];
       if (gate && !((float)vm.e[e] > 0.f)) gv = 0.f;
-      float xh = ((float)vy.e[e] - mean[c]) * invstd[c];
-      o.e[e] = (T)(k1[c] * (gv - mg[c] - xh * mgx[c]));
+      float xh = ((float)vy.e[e] - s_mean[c]) * s_is[c];
+      o.e[e] = (T)(s_k1[c] * (gv - s_mg[c] - xh * s_mgx[c]));
     }
     reinterpret_cast<piece_t*>(gy)[i] = o.p;
   }
@@ -285,12 +291,11 @@ static __global__ void __launch_bounds__(256) bn_fwd_stats_kernel(const T* __res
   }
 }
 
-// BatchNorm backward = reduce -> finalize -> apply.  coef: [3][C] floats (k1, mg, mgx);
-// accum: [2][C] doubles, zero on entry, zero again on exit.
+// BatchNorm backward = reduce -> apply.  accum: [2][C] doubles, zero on entry (left holding the sums).
 template <typename T>
 inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, const float* gamma, const float* mean,
-                          const float* invstd, float* dgamma, float* dbeta, T* gy, float* coef, double* accum,
-                          float grad_unscale, hipStream_t s) {
+                          const float* invstd, float* dgamma, float* dbeta, T* gy, double* accum, float grad_unscale,
+                          hipStream_t s, float* partial = nullptr) {
   constexpr int VEC = ElemTraits<T>::VEC;
   // ~4096 workgroups in flight: the reduction is HBM-bound and needs the whole chip
   const int rlanes = 256 / (C / VEC);
@@ -298,13 +303,15 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   rows = ((rows + rlanes - 1) / rlanes) * rlanes;
   if (rows < 4L * rlanes) rows = 4L * rlanes;
   int rows_per_block = (int)rows;
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(cdiv(M, rows_per_block)), dim3(256), 0, s, g, gate, y, mean, invstd, M,
-                     C, accum, rows_per_block);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, accum, C, (double)M, gamma, invstd,
-                     dgamma, dbeta, coef, coef + C, coef + 2 * C, grad_unscale);
+  const int nblk = cdiv(M, rows_per_block);
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
+                     rows_per_block, partial);
+  if (partial)
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(nblk, 64), cdiv(C, 64)), dim3(256), 0, s,
+                       (const float*)partial, nblk, C, accum, 64);
   long np = M * C / VEC;
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
-                     (const float*)coef, (const float*)(coef + C), (const float*)(coef + 2 * C), gy, np, C);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd, gamma,
+                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C);
 }
 
 // ---- global average pool --------------------------------------------------------------------------

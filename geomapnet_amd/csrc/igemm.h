@@ -284,7 +284,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r] * ep.alpha + bias;
-                if (ep.relu) v = fmaxf(v, 0.f);
+                if (ep.relu & 1) v = fmaxf(v, 0.f);
                 s1[j] += v;
                 s2[j] += v * v;
                 const int lr = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -391,13 +391,17 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
   constexpr int VEC = ElemTraits<T>::VEC;
   const bool wide_k = (g.K % (8 * VEC)) == 0;
   int cfg = igemm_config();
-  if (cfg == 0) cfg = 1;  // default until per-shape tuning says otherwise
+  // per-shape default (tools/conv_bench.py on MI355X, B = 192): 256x128 8-wave tiles win for N = 128 with many
+  // M tiles (layer2: 120 vs 130 us); 128x128 wins where 256-row tiles would leave CUs idle (layers 3-4)
+  if (cfg == 0) cfg = (g.N == 128 && g.M >= 128 * 1024) ? 2 : 1;
   if (g.N <= 64) {
     if (cfg != 1) return launch_igemm_cfg<T, 4, 1, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);
     if (wide_k) return launch_igemm_cfg<T, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
     return launch_igemm_cfg<T, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
   }
   if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 6) return launch_igemm_cfg<T, 4, 2, 2, 4, 3, 4>(g, A, Bw, ep, stream, zero_page);  // 2 tiles in flight
+  if (cfg == 7) return launch_igemm_cfg<T, 4, 2, 2, 4, 4, 4>(g, A, Bw, ep, stream, zero_page);  // 3 tiles in flight
   if (cfg == 3 && wide_k) return launch_igemm_cfg<T, 4, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
   if (cfg == 4 && g.N >= 256) return launch_igemm_cfg<T, 4, 2, 4, 4, 2, 2>(g, A, Bw, ep, stream, zero_page);
   if (cfg == 4) return launch_igemm_cfg<T, 4, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);

@@ -4,6 +4,7 @@
 #include "../../include/mapnet_hip.h"
 
 #include <cmath>
+#include <cstring>
 #include <deque>
 #include <memory>
 #include <string>
@@ -98,8 +99,66 @@ struct KernelTimer {
   }
 };
 
+// One captured hipGraph per API segment (whole training step, or forward / backward stage / optimiser
+// when the host interleaves all-reduces).  The graph is keyed by everything the enqueued work bakes in
+// (data pointers, hyper-parameters); a key change re-captures, repeated changes fall back to eager launches.
+struct GraphSeg {
+  hipGraphExec_t exec = nullptr;
+  unsigned long long key = 0;
+  int captures = 0;
+};
+
 struct PlanBase {
-  virtual ~PlanBase() {}
+  virtual ~PlanBase() {
+    for (auto& g : segs)
+      if (g.exec) hipGraphExecDestroy(g.exec);
+  }
+  GraphSeg segs[8];
+  bool graphs_ok = !(getenv("MN_GRAPHS") && atoi(getenv("MN_GRAPHS")) == 0);
+  unsigned long long fwd_key = 0;  // identity of the buffers the last training forward was issued on
+  unsigned long long hyper_version = 1;
+  template <typename F>
+  int run_segment(int seg, unsigned long long key, hipStream_t s, F&& body) {
+    // the legacy (null) stream cannot be captured; event-pair profiling needs eager launches
+    if (!graphs_ok || s == nullptr || timer.enabled) return body();
+    GraphSeg& gs = segs[seg];
+    key = key * 1099511628211ull + hyper_version;
+    if (gs.exec && gs.key == key) {
+      if (hipGraphLaunch(gs.exec, s) != hipSuccess) return fail("hipGraphLaunch failed");
+      return 0;
+    }
+    if (gs.captures >= 8) return body();  // arguments keep changing: stay eager
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      graphs_ok = false;
+      (void)hipGetLastError();
+      return body();
+    }
+    int rc = body();
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != 0 || e != hipSuccess || !graph) {
+      if (graph) hipGraphDestroy(graph);
+      graphs_ok = false;
+      (void)hipGetLastError();
+      return rc != 0 ? rc : body();
+    }
+    if (gs.exec) hipGraphExecDestroy(gs.exec);
+    gs.exec = nullptr;
+    e = hipGraphInstantiate(&gs.exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+      gs.exec = nullptr;
+      graphs_ok = false;
+      (void)hipGetLastError();
+      return body();
+    }
+    gs.key = key;
+    gs.captures++;
+    if (hipGraphLaunch(gs.exec, s) != hipSuccess) return fail("hipGraphLaunch failed");
+    return 0;
+  }
+  virtual void after_optim_host() = 0;
+  virtual int sync_step_to_device(hipStream_t s) = 0;
   virtual int forward(const float* images, float* poses_out, int training, hipStream_t s) = 0;
   virtual int loss_only(const float* pred, const float* targ, float* loss_out, hipStream_t s) = 0;
   virtual int forward_loss(const float* images, const float* targets, float* loss_out, float* poses_out,
@@ -130,8 +189,8 @@ struct Plan : PlanBase {
     T* wd = nullptr;  // data-gradient operand [Cin][R*S*Cout]
     T* y = nullptr;   // raw conv output [M][Cout]
     T* gy = nullptr;  // its gradient
-    float *mean, *invstd, *scale, *shift, *coef;
-    double* accum;
+    float *mean, *invstd;
+    double *accum_f, *accum_b;  // fp64 sums of the forward statistics / backward reductions, [2][C] each
     int ldw;           // row pitch of the master weight gradient
     const int* colmap = nullptr;
   };
@@ -161,11 +220,19 @@ struct Plan : PlanBase {
   int Hl, Wl;  // last feature map
   float *pooled, *feat, *poses, *dposes, *dz, *dpooled, *fcT, *loss_dev;
   float* stats_partial;
+  double* acc_region = nullptr;
+  size_t acc_bytes = 0;
+  int cur_training = 1;
+  float* bwd_partial;  // [<= 4200][2][C] partial sums of the BatchNorm backward reduction
   double* sqnorm;
   unsigned char* frozen;
   int* stem_colmap;
+  RepackJob* repack_jobs;
+  int repack_njobs = 0, repack_blocks = 0;
   unsigned char* pool_idx;  // winning tap of every max-pool window
   void* zero_page;          // 256 zero bytes: source of out-of-image taps for the DMA conv pipeline
+  long long* step_dev;      // device-resident Adam step counter
+  float* bc_dev;            // {1 - beta1^t, 1 - beta2^t}, derived on device from step_dev
   const float* cur_targets = nullptr;
   float* cur_loss = nullptr;
 
@@ -173,16 +240,21 @@ struct Plan : PlanBase {
   size_t carve(char* base) {
     Bump b;
     auto A = [&](size_t bytes) { return base ? base + b.take(bytes) : (b.take(bytes), (char*)nullptr); };
+    // all BatchNorm accumulators live in one region so a single memset per step clears them
+    size_t acc_doubles = 4 * 64;
+    for (auto& blk : blocks) acc_doubles += (size_t)4 * blk.u1.cp.cout * (blk.down ? 3 : 2);
+    acc_bytes = acc_doubles * 8;
+    acc_region = (double*)A(acc_bytes);
+    double* acc_cursor = acc_region;
     auto unit_bufs = [&](Unit& u) {
       int C = u.cp.cout;
       u.y = (T*)A((size_t)u.M * C * sizeof(T));
       u.gy = (T*)A((size_t)u.M * C * sizeof(T));
       u.mean = (float*)A(C * 4);
       u.invstd = (float*)A(C * 4);
-      u.scale = (float*)A(C * 4);
-      u.shift = (float*)A(C * 4);
-      u.coef = (float*)A(3 * C * 4);
-      u.accum = (double*)A(2 * C * 8);
+      u.accum_f = acc_cursor;
+      u.accum_b = acc_cursor ? acc_cursor + 2 * C : nullptr;
+      if (acc_cursor) acc_cursor += 4 * C;
     };
     xpad = (T*)A((size_t)B * Hp * Wp * 4 * sizeof(T));
     // stem
@@ -232,10 +304,14 @@ struct Plan : PlanBase {
     fcT = (float*)A((size_t)512 * F * 4);
     loss_dev = (float*)A(256);
     stats_partial = (float*)A(max_partial * 4);
+    bwd_partial = (float*)A((size_t)4200 * 2 * 512 * 4);
     sqnorm = (double*)A(256);
     frozen = (unsigned char*)A(256);
     stem_colmap = (int*)A(224 * 4);
+    repack_jobs = (RepackJob*)A(64 * sizeof(RepackJob));
     zero_page = (void*)A(256);
+    step_dev = (long long*)A(256);
+    bc_dev = (float*)A(256);
     return b.cur;
   }
 
@@ -326,6 +402,7 @@ struct Plan : PlanBase {
     hipMemcpyAsync(stem_colmap, cm.data(), 224 * 4, hipMemcpyHostToDevice, s);
     hipStreamSynchronize(s);  // cm is a host temporary
     stem.colmap = stem_colmap;
+    build_repack_table(s);
     update_frozen(s);
     weights_dirty = true;
     return check_launch("attach");
@@ -339,23 +416,36 @@ struct Plan : PlanBase {
   }
 
   // ---- weights: fp32 master -> compute layouts ------------------------------------------------
-  void repack(hipStream_t s) {
-    hipLaunchKernelGGL((repack_kernel<T>), dim3(ew_grid(64 * 224)), dim3(256), 0, s, (const float*)(params + stem.cp.w),
-                       stem.wf, 64, 7, 7, 3, 2);
-    for (auto& blk : blocks) {
-      Unit* us[3] = {&blk.u1, &blk.u2, blk.down ? &blk.ud : nullptr};
+  void build_repack_table(hipStream_t s) {
+    std::vector<RepackJob> jobs;
+    int blk = 0;
+    auto add = [&](long src, void* a, void* b2, int O, int R, int S, int I, int mode) {
+      RepackJob j;
+      j.src_off = src; j.dst_a = a; j.dst_b = b2; j.O = O; j.R = R; j.S = S; j.I = I; j.mode = mode;
+      long total = mode == 2 ? (long)O * R * 32 : (long)O * R * S * I;
+      j.blk0 = blk;
+      j.nblk = (int)((total + 4095) / 4096);
+      blk += j.nblk;
+      jobs.push_back(j);
+    };
+    add(stem.cp.w, stem.wf, nullptr, 64, 7, 7, 3, 2);
+    for (auto& bk : blocks) {
+      Unit* us[3] = {&bk.u1, &bk.u2, bk.down ? &bk.ud : nullptr};
       for (Unit* u : us) {
         if (!u) continue;
         const ConvP& c = u->cp;
-        long n = (long)c.cout * c.cin * c.k * c.k;
-        const float* src = params + c.w;
-        if (DT == MN_F16)
-          hipLaunchKernelGGL((repack_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, src, u->wf, c.cout, c.k, c.k, c.cin, 0);
-        hipLaunchKernelGGL((repack_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, s, src, u->wd, c.cout, c.k, c.k, c.cin, 1);
+        add(c.w, DT == MN_F16 ? (void*)u->wf : nullptr, u->wd, c.cout, c.k, c.k, c.cin, 0);
       }
     }
-    hipLaunchKernelGGL(transpose_kernel, dim3(ew_grid((long)512 * cfg.feat_dim)), dim3(256), 0, s,
-                       (const float*)(params + L.fc_w), fcT, cfg.feat_dim, 512);
+    add(L.fc_w, fcT, nullptr, cfg.feat_dim, 1, 1, 512, 3);
+    repack_njobs = (int)jobs.size();
+    repack_blocks = blk;
+    hipMemcpyAsync(repack_jobs, jobs.data(), jobs.size() * sizeof(RepackJob), hipMemcpyHostToDevice, s);
+    hipStreamSynchronize(s);  // `jobs` is a host temporary
+  }
+  void repack(hipStream_t s) {
+    hipLaunchKernelGGL((repack_all_kernel<T>), dim3(repack_blocks), dim3(256), 0, s, (const RepackJob*)repack_jobs,
+                       repack_njobs, (const float*)params);
     weights_dirty = false;
   }
 
@@ -369,8 +459,6 @@ struct Plan : PlanBase {
     p.num_batches_tracked = (long long*)(buffers + u.bp.nbt);
     p.mean = u.mean;
     p.invstd = u.invstd;
-    p.scale = u.scale;
-    p.shift = u.shift;
     p.eps = 1e-5f;
     p.momentum = 0.1f;
     return p;
@@ -383,21 +471,20 @@ struct Plan : PlanBase {
     const int GM = launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
     timer.end(tp, s);
     int N = u.cp.cout;
-    if (training) {
+    if (training)
       hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(GM, 64), cdiv(N, 64)), dim3(256), 0, s,
-                         (const float*)stats_partial, GM, N, u.accum, 64);
-    }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, u.accum, N, (double)u.M, bn_params(u),
-                       training);
+                         (const float*)stats_partial, GM, N, u.accum_f, 64);
   }
   void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s) {
     long np = u.M * u.cp.cout / VEC;
-    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const float*)u.scale,
-                       (const float*)u.shift, res, out, np, u.cp.cout, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const double*)u.accum_f,
+                       (double)u.M, bn_params(u), cur_training, res, out, np, u.cp.cout, relu);
   }
 
   int forward(const float* images, float* poses_out, int training, hipStream_t s) override {
     if (weights_dirty) repack(s);
+    cur_training = training;
+    if (training) hipMemsetAsync(acc_region, 0, acc_bytes, s);  // forward statistics + backward reduction sums
     hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s, images, xpad, B,
                        H, W, Hp, Wp);
     conv_bn_stats(stem, xpad, training, s);
@@ -456,7 +543,7 @@ struct Plan : PlanBase {
   // ---- backward -------------------------------------------------------------------------------------
   void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s) {
     launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
-                     grads + u.bp.beta, u.gy, u.coef, u.accum, 1.f / cfg.loss_scale, s);
+                     grads + u.bp.beta, u.gy, u.accum_b, 1.f / cfg.loss_scale, s, bwd_partial);
   }
   void conv_wgrad(Unit& u, const T* x, hipStream_t s) {
     WgradArgs a;
@@ -534,14 +621,24 @@ struct Plan : PlanBase {
       if (blocks[i].stage == stage) block_backward(blocks[i], s);
     if (stage == 0) {
       stem_backward(s);
-      cur_targets = nullptr;
     }
     return check_launch("backward_stage");
   }
 
   // ---- optimiser -----------------------------------------------------------------------------------
-  int optim_step(float grad_mul, hipStream_t s) override {
+  // host-side effects of an optimiser step (also applied when the step was replayed from a graph)
+  void after_optim_host() override {
     step += 1;
+    weights_dirty = true;
+  }
+  int sync_step_to_device(hipStream_t s) override {
+    long long v = step;
+    hipMemcpyAsync(step_dev, &v, sizeof(v), hipMemcpyHostToDevice, s);
+    hipStreamSynchronize(s);
+    return check_launch("sync_step");
+  }
+  int optim_step(float grad_mul, hipStream_t s) override {
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, step_dev, beta1, beta2, bc_dev);
     if (max_grad_norm > 0.f) {
       hipMemsetAsync(sqnorm, 0, sizeof(double), s);
       hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(ew_grid(L.model_floats)), dim3(256), 0, s, (const float*)grads,
@@ -550,11 +647,9 @@ struct Plan : PlanBase {
     AdamArgs a;
     a.p = params; a.g = grads; a.m = m1; a.v = m2; a.n = L.param_floats; a.n_clip = L.model_floats; a.lr = lr; a.wd = wd;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
-    a.bc2 = (float)(1.0 - std::pow((double)beta2, (double)step));
+    a.bc1 = 1.f; a.bc2 = 1.f; a.bc_dev = bc_dev;
     a.grad_mul = grad_mul; a.max_norm = max_grad_norm; a.sqnorm = sqnorm; a.frozen = frozen; a.eps_mode = cfg.eps_mode;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(L.param_floats)), dim3(256), 0, s, a);
-    weights_dirty = true;
     return check_launch("optim_step");
   }
 };
@@ -633,12 +728,18 @@ extern "C" int mn_set_learn_flags(mn_handle* h, int learn_beta, int learn_gamma)
 extern "C" int mn_set_optim(mn_handle* h, float lr, float weight_decay, float beta1, float beta2, float eps,
                             float max_grad_norm) {
   MN_H(h);
+  if (P.lr != lr || P.wd != weight_decay || P.beta1 != beta1 || P.beta2 != beta2 || P.eps != eps ||
+      P.max_grad_norm != max_grad_norm)
+    P.hyper_version++;  // captured graphs bake these in
   P.lr = lr; P.wd = weight_decay; P.beta1 = beta1; P.beta2 = beta2; P.eps = eps; P.max_grad_norm = max_grad_norm;
   return 0;
 }
 extern "C" int mn_set_step_count(mn_handle* h, int64_t step) {
   MN_H(h);
-  P.step = step;
+  if (P.step != step) {
+    P.step = step;
+    return P.sync_step_to_device(nullptr);
+  }
   return 0;
 }
 extern "C" int64_t mn_get_step_count(mn_handle* h) { return (h && h->plan) ? h->plan->step : -1; }
@@ -654,11 +755,18 @@ extern "C" int mn_train_forward_loss(mn_handle* h, const float* images, const fl
                                      float* poses_out, void* stream) {
   MN_H(h);
   P.timer.reset();
-  return P.forward_loss(images, targets, loss_out, poses_out, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long key = (unsigned long long)(uintptr_t)images * 31 + (unsigned long long)(uintptr_t)targets * 17 +
+                           (unsigned long long)(uintptr_t)loss_out * 13 + (unsigned long long)(uintptr_t)poses_out;
+  P.weights_dirty = true;  // a training forward always follows an optimiser step or a parameter load
+  P.fwd_key = key;
+  return P.run_segment(1, key, s, [&] { return P.forward_loss(images, targets, loss_out, poses_out, s); });
 }
 extern "C" int mn_train_backward_stage(mn_handle* h, int stage, void* stream) {
   MN_H(h);
-  return P.backward_stage(stage, (hipStream_t)stream);
+  if (stage < 0 || stage > 3) return fail("backward_stage: stage must be 0..3");
+  hipStream_t s = (hipStream_t)stream;
+  return P.run_segment(2 + stage, P.fwd_key, s, [&] { return P.backward_stage(stage, s); });
 }
 extern "C" int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t* count) {
   MN_H(h);
@@ -669,19 +777,31 @@ extern "C" int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t*
 }
 extern "C" int mn_optim_step(mn_handle* h, float grad_mul, void* stream) {
   MN_H(h);
-  return P.optim_step(grad_mul, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned key;
+  memcpy(&key, &grad_mul, sizeof(key));
+  int rc = P.run_segment(6, key, s, [&] { return P.optim_step(grad_mul, s); });
+  if (rc == 0) P.after_optim_host();
+  return rc;
 }
 extern "C" int mn_train_step(mn_handle* h, const float* images, const float* targets, float* loss_out, float* poses_out,
                              void* stream) {
   MN_H(h);
   hipStream_t s = (hipStream_t)stream;
   P.timer.reset();
-  auto* tp = P.timer.begin(3, s);
-  if (int e = P.forward_loss(images, targets, loss_out, poses_out, s)) return e;
-  for (int st = 3; st >= 0; --st)
-    if (int e = P.backward_stage(st, s)) return e;
-  int rc = P.optim_step(1.f, s);
-  P.timer.end(tp, s);
+  unsigned long long key = (unsigned long long)(uintptr_t)images * 31 + (unsigned long long)(uintptr_t)targets * 17 +
+                           (unsigned long long)(uintptr_t)loss_out * 13 + (unsigned long long)(uintptr_t)poses_out;
+  P.weights_dirty = true;  // a training step always follows an optimiser step or a parameter load
+  int rc = P.run_segment(0, key, s, [&]() -> int {
+    auto* tp = P.timer.begin(3, s);
+    if (int e = P.forward_loss(images, targets, loss_out, poses_out, s)) return e;
+    for (int st = 3; st >= 0; --st)
+      if (int e = P.backward_stage(st, s)) return e;
+    int r = P.optim_step(1.f, s);
+    P.timer.end(tp, s);
+    return r;
+  });
+  if (rc == 0) P.after_optim_host();
   return rc;
 }
 extern "C" int mn_params_changed(mn_handle* h) {

@@ -35,7 +35,19 @@ struct AdamArgs {
   const double* sqnorm;  // accumulated by grad_sqnorm_kernel over the clipped range (after grad_mul)
   const unsigned char* frozen;  // optional per-element freeze mask for the tail [n_clip, n) (criterion scalars)
   int eps_mode;      // 0: torch>=1.0  denom = sqrt(v)/sqrt(bc2)+eps ; 1: torch 0.4.1  denom = sqrt(v)+eps
+  const float* bc_dev;  // optional device copy of {bc1, bc2} (written by adam_prep_kernel); overrides bc1/bc2
 };
+
+// Advances the device-resident step counter and derives the bias corrections from it, so a captured
+// (hipGraph) training step needs no per-step host arguments.
+static __global__ void adam_prep_kernel(long long* step, float beta1, float beta2, float* bc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long t = *step + 1;
+    *step = t;
+    bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
+    bc[1] = (float)(1.0 - pow((double)beta2, (double)t));
+  }
+}
 
 static __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
   float coef = 1.f;
@@ -44,7 +56,8 @@ static __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
     float c = a.max_norm / (total + 1e-6f);
     if (c < 1.f) coef = c;
   }
-  const float sq2 = sqrtf(a.bc2);
+  const float bc1 = a.bc_dev ? a.bc_dev[0] : a.bc1, bc2 = a.bc_dev ? a.bc_dev[1] : a.bc2;
+  const float sq2 = sqrtf(bc2);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
     if (a.frozen && i >= a.n_clip && a.frozen[i - a.n_clip]) continue;
     float p = a.p[i];
@@ -58,9 +71,9 @@ static __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
     a.v[i] = v;
     float upd;
     if (a.eps_mode == 0)
-      upd = (a.lr / a.bc1) * (m / (sqrtf(v) / sq2 + a.eps));
+      upd = (a.lr / bc1) * (m / (sqrtf(v) / sq2 + a.eps));
     else
-      upd = (a.lr * sq2 / a.bc1) * (m / (sqrtf(v) + a.eps));
+      upd = (a.lr * sq2 / bc1) * (m / (sqrtf(v) + a.eps));
     a.p[i] = p - upd;
   }
 }
@@ -94,6 +107,59 @@ static __global__ void __launch_bounds__(256) repack_kernel(const float* __restr
       int sp = 2 * s4 + (e >> 2), ch = e & 3;
       float v = (sp < S && ch < I) ? src[(((long)o * R + r) * S + sp) * I + ch] : 0.f;
       dst[idx] = (T)v;
+    }
+  }
+}
+
+// All compute-layout copies of one optimiser step in ONE launch: a device-resident job table maps
+// workgroup ranges to (conv weight -> forward copy, data-gradient copy | stem layout | fc transpose).
+struct RepackJob {
+  long src_off;   // offset of the fp32 master in the parameter arena
+  void* dst_a;    // mode 0: forward copy (same layout, cast) or null; mode 2: stem layout; mode 3: transpose
+  void* dst_b;    // mode 0: data-gradient layout [I][R][S][O] or null
+  int O, R, S, I;
+  int mode;       // 0 conv, 2 stem, 3 fp32 transpose [O][I] -> [I][O]
+  int blk0, nblk; // workgroup range; each workgroup covers 4096 elements
+};
+
+template <typename T>
+static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob* __restrict__ jobs, int njobs,
+                                                                const float* __restrict__ params) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  const RepackJob job = jobs[j];
+  const float* src = params + job.src_off;
+  const int O = job.O, R = job.R, S = job.S, I = job.I;
+  const long total = job.mode == 2 ? (long)O * R * 32 : (long)O * R * S * I;
+  const long base = (long)((int)blockIdx.x - job.blk0) * 4096;
+  for (int k = 0; k < 16; ++k) {
+    const long idx = base + k * 256 + threadIdx.x;
+    if (idx >= total) break;
+    if (job.mode == 0) {
+      const float v = src[idx];
+      if (job.dst_a) reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
+      // idx = ((o*R + r)*S + s)*I + i  ->  ((i*R + r)*S + s)*O + o
+      const int i = (int)(idx % I);
+      long t = idx / I;
+      const int s = (int)(t % S);
+      t /= S;
+      const int r = (int)(t % R);
+      const int o = (int)(t / R);
+      reinterpret_cast<T*>(job.dst_b)[(((long)i * R + r) * S + s) * O + o] = (T)v;
+    } else if (job.mode == 2) {
+      const int e = (int)(idx % 8);
+      long t = idx / 8;
+      const int s4 = (int)(t % 4);
+      t /= 4;
+      const int r = (int)(t % R);
+      const int o = (int)(t / R);
+      const int sp = 2 * s4 + (e >> 2), ch = e & 3;
+      const float v = (sp < S && ch < I) ? src[(((long)o * R + r) * S + sp) * I + ch] : 0.f;
+      reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
+    } else {
+      const int i = (int)(idx % I);
+      const int o = (int)(idx / I);
+      reinterpret_cast<float*>(job.dst_a)[(long)i * O + o] = src[idx];
     }
   }
 }

@@ -26,13 +26,35 @@ def world_size():
 
 
 def train_step(engine, plan, images, targets):
+    import ctypes as C
+    import contextlib
     lib, h = engine.lib, plan["handle"]
-    s = _stream(images)
-    poses = torch.empty(plan["images"], 6, dtype=torch.float32, device=engine.device)
+    if "poses" not in plan:
+        plan["poses"] = torch.empty(plan["images"], 6, dtype=torch.float32, device=engine.device)
+    side = engine.step_stream()
+    if side is not None:  # side stream: lets the library capture each stage into a hipGraph
+        cur = torch.cuda.current_stream(engine.device)
+        side.wait_stream(cur)
+        ctx = torch.cuda.stream(side)
+        s = C.c_void_p(side.cuda_stream)
+    else:
+        ctx = contextlib.nullcontext()
+        s = None
+    with ctx:
+        loss, poses = _staged_step(engine, plan, images, targets, lib, h, s)
+    if side is not None:
+        cur.wait_stream(side)
+    return loss, poses
+
+
+def _staged_step(engine, plan, images, targets, lib, h, s):
+    import ctypes as C
+    if s is not None:
+        images, targets = engine.stable_inputs(plan, images, targets)
+    poses = plan["poses"]
     lib.check(lib.train_forward_loss(h, ptr(images), ptr(targets), ptr(plan["loss"]), ptr(poses), s))
     grads = engine.grads()
     works = []
-    import ctypes as C
     for stage in (3, 2, 1, 0):
         lib.check(lib.train_backward_stage(h, stage, s))
         off, cnt = C.c_int64(), C.c_int64()
@@ -48,4 +70,4 @@ def train_step(engine, plan, images, targets):
     loss = plan["loss"].clone()
     dist.all_reduce(loss, op=dist.ReduceOp.SUM)
     loss /= world_size()
-    return loss, poses
+    return loss, poses.clone()

@@ -315,3 +315,14 @@ inline emu_v4s __builtin_amdgcn_ds_read_tr16_b64_v4i16(__attribute__((address_sp
   emu::wave_sync();
   return r;
 }
+
+// ---- hipGraph subset: the emulator does not capture (BeginCapture fails, callers fall back to eager) ----
+typedef struct emu_graph* hipGraph_t;
+typedef struct emu_graph_exec* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorUnknown; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorUnknown; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, void*, void*, size_t) { *e = nullptr; return hipErrorUnknown; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorUnknown; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }

@@ -75,3 +75,13 @@ t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), 64, ptr(xp), ptr(g
 fl = 2.0 * g.M * 64 * 147
 print("stem 7x7/2 3->64        M=%8d  fwd %7.1f us %6.0f TF(real) out %5.2f TB/s | wgrad %7.1f us %6.0f TF(real)"
       % (g.M, t_f, fl / t_f / 1e6, y.numel() * 2 / t_f / 1e6, t_w, fl / t_w / 1e6))
+
+# asymptotic GEMM rate of the same kernel: 1x1 conv with a long K loop (no taps, 64+ K-steps)
+for (Ci, Co) in ((2048, 1024), (4096, 512)):
+    Bq, Hq = 32, 32
+    g, Ho, Wo = checks.fwd_geom(Bq, Hq, Hq, Ci, Co, 1, 1, 0)
+    x = torch.randn(Bq, Hq, Hq, Ci, device="cuda").to(td)
+    w = (torch.randn(Co, Ci, device="cuda") * 0.02).to(td)
+    y = torch.empty(Bq, Hq, Hq, Co, dtype=td, device="cuda")
+    t = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, int(os.environ.get("MN_PRIO", "0")) * 256, None, None, one, ptr(checks.zero_page("cuda")), None))
+    print("plain GEMM M=%d N=%d K=%d: %7.1f us %6.0f TF" % (g.M, Co, Ci, t, 2.0 * g.M * Co * Ci / t / 1e6))

@@ -97,14 +97,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <typename T, int WM, int WN, int TN, int NP, int NBUF, int MINW>
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                          const T* __restrict__ zero_page) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int NT = WM * WN * 64;
-  constexpr int BM = WM * 64, BN = WN * TN * 32;
-  constexpr int WTM = 64, WTN = TN * 32, TM = 2;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int WTM = TM * 32, WTN = TN * 32;
   constexpr int RPP = NT / NP;  // rows covered by one DMA pass of all threads
   constexpr int APT = BM / RPP, BPT = BN / RPP;
   constexpr int IPT = APT + BPT;  // DMA instructions per wave per tile
@@ -374,12 +374,12 @@ inline int igemm_config() {
   return v;
 }
 
-template <typename T, int WM, int WN, int TN, int NP, int NBUF, int MINW>
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW>
 inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
                             const T* zero_page) {
-  constexpr int BM = WM * 64, BN = WN * TN * 32;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int gm = cdiv(g.M, BM), gn = cdiv(g.N, BN);
-  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TN, NP, NBUF, MINW>), dim3(gm * gn), dim3(WM * WN * 64), 0, stream, g, A, Bw,
+  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW>), dim3(gm * gn), dim3(WM * WN * 64), 0, stream, g, A, Bw,
                      ep, gn, zero_page);
   return gm;
 }
@@ -394,19 +394,32 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
   // per-shape default (tools/conv_bench.py on MI355X, B = 192): 256x128 8-wave tiles win for N = 128 with many
   // M tiles (layer2: 120 vs 130 us); 128x128 wins where 256-row tiles would leave CUs idle (layers 3-4)
   if (cfg == 0) cfg = (g.N == 128 && g.M >= 128 * 1024) ? 2 : 1;
-  if (g.N <= 64) {
-    if (cfg != 1) return launch_igemm_cfg<T, 4, 1, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);
-    if (wide_k) return launch_igemm_cfg<T, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
-    return launch_igemm_cfg<T, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
+  if (cfg >= 8 && cfg <= 13 && (g.N % 64 == 0) && g.N >= 128) {  // 128-row wave tiles (4 waves)
+    if (cfg == 8) return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);   // 256x128, ring 3
+    if (cfg == 9) return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 2, 2>(g, A, Bw, ep, stream, zero_page);   // 256x128, ring 2
+    if (cfg == 10 && g.N >= 256) return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 3, 1>(g, A, Bw, ep, stream, zero_page);  // 256x256
+    if (cfg == 11 && g.N >= 256) return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 2, 1>(g, A, Bw, ep, stream, zero_page);
+    if (cfg == 12 && g.N >= 256) return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 4, 1>(g, A, Bw, ep, stream, zero_page);
+    return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);
   }
-  if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
-  if (cfg == 6) return launch_igemm_cfg<T, 4, 2, 2, 4, 3, 4>(g, A, Bw, ep, stream, zero_page);  // 2 tiles in flight
-  if (cfg == 7) return launch_igemm_cfg<T, 4, 2, 2, 4, 4, 4>(g, A, Bw, ep, stream, zero_page);  // 3 tiles in flight
-  if (cfg == 3 && wide_k) return launch_igemm_cfg<T, 4, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
-  if (cfg == 4 && g.N >= 256) return launch_igemm_cfg<T, 4, 2, 4, 4, 2, 2>(g, A, Bw, ep, stream, zero_page);
-  if (cfg == 4) return launch_igemm_cfg<T, 4, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
-  if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
-  return launch_igemm_cfg<T, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
+  if (cfg >= 8 && g.N <= 64) {
+    if (cfg == 8 || cfg == 10) return launch_igemm_cfg<T, 2, 1, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 256x64, 2 waves
+    if (cfg == 9 || cfg == 11) return launch_igemm_cfg<T, 2, 2, 4, 1, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 256x64, 4 waves
+    return launch_igemm_cfg<T, 4, 1, 2, 2, 4, 3, 3>(g, A, Bw, ep, stream, zero_page);
+  }
+  if (g.N <= 64) {
+    if (cfg != 1) return launch_igemm_cfg<T, 4, 1, 2, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);
+    if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
+    return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
+  }
+  if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 6) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 3, 4>(g, A, Bw, ep, stream, zero_page);  // 2 tiles in flight
+  if (cfg == 7) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 4, 4>(g, A, Bw, ep, stream, zero_page);  // 3 tiles in flight
+  if (cfg == 3 && wide_k) return launch_igemm_cfg<T, 4, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 4 && g.N >= 256) return launch_igemm_cfg<T, 4, 2, 2, 4, 4, 2, 2>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 4) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
+  if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
+  return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
 }
 
 }  // namespace mn

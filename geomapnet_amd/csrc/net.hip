@@ -112,6 +112,46 @@ struct PlanBase {
   virtual ~PlanBase() {
     for (auto& g : segs)
       if (g.exec) hipGraphExecDestroy(g.exec);
+    for (hipEvent_t e : fork_events) hipEventDestroy(e);
+    if (wstream) hipStreamDestroy(wstream);
+  }
+  // Weight-gradient launches do not feed the data-gradient chain, so they run on a second stream: their
+  // workgroups fill the CUs the tail of each data-gradient launch leaves idle (layers 3-4 at B = 192 have
+  // 1056 / 528 tiles for 512 resident slots).  fork: wstream waits for everything enqueued on s so far;
+  // join: s waits for wstream.  Inside a stream capture the same calls become graph edges.
+  hipStream_t wstream = nullptr;
+  std::vector<hipEvent_t> fork_events;
+  size_t fork_next = 0;
+  bool wgrad_pending = false;
+  bool overlap_wgrad = !(getenv("MN_WGRAD_STREAM") && atoi(getenv("MN_WGRAD_STREAM")) == 0);
+  hipEvent_t next_fork_event() {
+    if (fork_events.size() < 64) {
+      hipEvent_t e = nullptr;
+      hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      fork_events.push_back(e);
+      return e;
+    }
+    return fork_events[fork_next++ % fork_events.size()];
+  }
+  hipStream_t fork_wgrad(hipStream_t s) {
+    if (!overlap_wgrad || s == nullptr || timer.enabled) return s;
+    if (!wstream && hipStreamCreateWithFlags(&wstream, hipStreamNonBlocking) != hipSuccess) {
+      overlap_wgrad = false;
+      (void)hipGetLastError();
+      return s;
+    }
+    hipEvent_t e = next_fork_event();
+    hipEventRecord(e, s);
+    hipStreamWaitEvent(wstream, e, 0);
+    wgrad_pending = true;
+    return wstream;
+  }
+  void join_wgrad(hipStream_t s) {
+    if (!wgrad_pending) return;
+    hipEvent_t e = next_fork_event();
+    hipEventRecord(e, wstream);
+    hipStreamWaitEvent(s, e, 0);
+    wgrad_pending = false;
   }
   GraphSeg segs[8];
   bool graphs_ok = !(getenv("MN_GRAPHS") && atoi(getenv("MN_GRAPHS")) == 0);
@@ -549,9 +589,10 @@ struct Plan : PlanBase {
     WgradArgs a;
     a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
     a.alpha = 1.f / cfg.loss_scale; a.rows_per_split = 0;
-    auto* tp = timer.begin(1, s);
-    launch_wgrad<T>(a, 1024, s, zero_page);
-    timer.end(tp, s);
+    hipStream_t ws = fork_wgrad(s);
+    auto* tp = timer.begin(1, ws);
+    launch_wgrad<T>(a, 1024, ws, zero_page);
+    timer.end(tp, ws);
   }
   void conv_dgrad(Unit& u, T* gx, const T* res, const T* gate, hipStream_t s) {
     Epilogue ep;
@@ -622,6 +663,7 @@ struct Plan : PlanBase {
     if (stage == 0) {
       stem_backward(s);
     }
+    join_wgrad(s);  // the stage's gradient bucket is complete when this call's work on s is
     return check_launch("backward_stage");
   }
 

@@ -96,6 +96,15 @@ hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+// launches are synchronous here, so extra streams and cross-stream waits are trivially satisfied
+enum { hipEventDisableTiming = 2, hipStreamNonBlocking = 1 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  *s = nullptr;
+  return hipErrorUnknown;
+}
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 
 template <typename... KArgs, typename... Args>
 inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t /*shmem*/,

@@ -91,13 +91,24 @@ typedef void __attribute__((address_space(3)))* las_ptr_t;
 __device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gas_ptr_t)src, (las_ptr_t)lds_wave_base, 16, 0, 0);
 }
+// Buffer resource over a dense tensor (raw addressing, stride 0): a load whose byte offset reaches `bytes`
+// returns zero.  Tensors on this path are far below the 4 GiB a 32-bit offset spans.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
+  const unsigned n = bytes > 0xfffffff0l ? 0xfffffff0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)n, 0x00020000);
+}
+// buffer_load_dwordx4 ... lds: lane l copies 16 bytes from (resource base + voff + soff) to
+// (wave-uniform LDS base + 16*l)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (las_ptr_t)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
 // s_waitcnt simm16 (gfx9): vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; only vmcnt waits
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW>
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                          const T* __restrict__ zero_page) {
@@ -119,7 +130,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   __shared__ piece_t smem[NBUF * TILE_PIECES + WM * BN / 2];
   float* red = reinterpret_cast<float*>(&smem[NBUF * TILE_PIECES]);  // [WM][BN][2]
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform values stay in scalar registers
   const int wm = wave / WN, wn = wave % WN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / grid_n, tile_n = tile - tile_m * grid_n;
@@ -127,18 +139,30 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   const int pc = t % NP, lrow = t / NP;
   const int dsh = g.div == 2 ? 1 : 0;
 
-  int a_pix[APT];
-  unsigned a_mask[APT];
+  // Gather state.  Loads go through buffer resources (raw buffer addressing: 32-bit byte offsets, and any
+  // offset >= the tensor size returns zero), so an out-of-image tap or an out-of-range row is just an
+  // all-ones offset: no pointer select, no 64-bit address arithmetic in the K loop.
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(A, (long)g.B * g.Hi * g.Wi * g.C * (long)sizeof(T));
+  const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(Bw, (long)g.N * g.K * (long)sizeof(T));
+  const int CP = g.C / VEC;  // pieces per tap
+  // Source piece of this lane inside a K-step: the XOR swizzle is applied on the source side.  Rows of
+  // one lane differ by multiples of RPP (a multiple of 16), which the swizzle ignores.
+  const int src_piece = pc ^ lds_swz<NP>(lrow);
+  // UNI: a K-step never straddles a tap (C is a multiple of the step), so the tap walk is wave-uniform and
+  // lives in scalar registers; otherwise (stem: 16-byte taps) every lane walks its own piece.
+  constexpr bool uni = UNI;
+  unsigned a_off[APT], a_inv[APT];
 #pragma unroll
   for (int i = 0; i < APT; ++i) {
     const int m = m0 + lrow + i * RPP;
-    a_pix[i] = 0;
-    a_mask[i] = 0u;
+    a_off[i] = 0u;
+    a_inv[i] = ~0u;
     if (m < g.M) {
       const int q = m % g.Q, tmp = m / g.Q;
       const int p = tmp % g.P, b = tmp / g.P;
       const int h0 = p * g.mul_p + g.off_h, w0 = q * g.mul_q + g.off_w;
-      a_pix[i] = ((b * g.Hi + (h0 >> dsh)) * g.Wi + (w0 >> dsh)) * g.C;
+      a_off[i] = (unsigned)((((b * g.Hi + (h0 >> dsh)) * g.Wi + (w0 >> dsh)) * g.C) * (int)sizeof(T)) +
+                 (uni ? (unsigned)src_piece * 16u : 0u);
       int tap = 0;
       for (int r = 0; r < g.R; ++r)
         for (int s = 0; s < g.S; ++s, ++tap) {
@@ -150,22 +174,19 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
             wn_ >>= 1;
           }
           ok = ok && (unsigned)hn < (unsigned)g.Hi && (unsigned)wn_ < (unsigned)g.Wi;
-          a_mask[i] |= (ok ? 1u : 0u) << tap;
+          if (ok) a_inv[i] &= ~(1u << tap);
         }
     }
   }
-  long b_row[BPT];
+  unsigned b_off[BPT];
 #pragma unroll
   for (int i = 0; i < BPT; ++i) {
     const int n = n0 + lrow + i * RPP;
-    b_row[i] = n < g.N ? (long)n * g.K : -1;
+    b_off[i] = n < g.N ? (unsigned)(n * g.K) * (unsigned)sizeof(T) + (unsigned)src_piece * 16u : ~0u;
   }
-  const int CP = g.C / VEC;  // pieces per tap
-  // Source piece of this lane inside a K-step: the XOR swizzle is applied on the source side.  Rows of
-  // one lane differ by multiples of RPP (a multiple of 16), which the swizzle ignores.
-  const int src_piece = pc ^ lds_swz<NP>(lrow);
-  // running decomposition of piece index q = kt*NP + src_piece into (tap = (tr, ts), channel piece cpi)
-  int cpi = src_piece, tr = 0, ts = 0, tap = 0;
+  // running decomposition of the step's first piece (uniform walk) or of this lane's piece (per-lane walk)
+  // into (tap = (tr, ts), channel piece cpi)
+  int cpi = uni ? 0 : src_piece, tr = 0, ts = 0, tap = 0;
   while (cpi >= CP) {
     cpi -= CP;
     ++tap;
@@ -174,23 +195,22 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
       ++tr;
     }
   }
-  long b_src = src_piece * VEC;
+  unsigned b_step = 0;  // byte offset of the K-step inside a weight row (scalar)
+  const unsigned lds_wave = wave * 64;  // this wave's 64 pieces of DMA pass 0 inside a tile
 
   auto issue_tile = [&](int buf) {
-    piece_t* base = &smem[buf * TILE_PIECES + wave * 64];  // this wave's 64 pieces of pass 0
-    const int toff = (g.rsign * (tr >> dsh) * g.Wi + g.ssign * (ts >> dsh)) * g.C + cpi * VEC;
+    piece_t* base = &smem[buf * TILE_PIECES + lds_wave];
+    const unsigned toff =
+        (unsigned)(((g.rsign * (tr >> dsh) * g.Wi + g.ssign * (ts >> dsh)) * g.C + cpi * VEC) * (int)sizeof(T));
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
-      const bool ok = (a_mask[i] >> tap) & 1u;
-      const T* src = ok ? A + (a_pix[i] + toff) : zero_page;
-      dma16(src, base + i * (RPP * NP));
+      // all ones where the tap is outside the image: the buffer bounds check then returns zero
+      const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(a_inv[i], tap, 1);
+      dma16(rsrc_a, (a_off[i] + toff) | inv, 0u, base + i * (RPP * NP));
     }
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const T* src = b_row[i] >= 0 ? Bw + b_row[i] + b_src : zero_page;
-      dma16(src, base + (BM + i * RPP) * NP);
-    }
-    b_src += NP * VEC;
+    for (int i = 0; i < BPT; ++i) dma16(rsrc_b, b_off[i], b_step, base + (BM + i * RPP) * NP);
+    b_step += NP * 16;
     cpi += NP;
     while (cpi >= CP) {
       cpi -= CP;
@@ -374,12 +394,12 @@ inline int igemm_config() {
   return v;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW>
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI = true>
 inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
                             const T* zero_page) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int gm = cdiv(g.M, BM), gn = cdiv(g.N, BN);
-  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW>), dim3(gm * gn), dim3(WM * WN * 64), 0, stream, g, A, Bw,
+  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI>), dim3(gm * gn), dim3(WM * WN * 64), 0, stream, g, A, Bw,
                      ep, gn, zero_page);
   return gm;
 }
@@ -389,8 +409,13 @@ template <typename T>
 inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
                         const T* zero_page) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  const bool wide_k = (g.K % (8 * VEC)) == 0;
+  const bool wide_k = (g.C / VEC) % 8 == 0;  // 128-byte K-steps need taps that are a multiple of them
   int cfg = igemm_config();
+  // channel counts that are not a multiple of the K-step (stem pixel pairs, odd test shapes): per-lane tap walk
+  if ((g.C / VEC) % 4 != 0) {
+    if (g.N <= 64) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);
+    return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);
+  }
   // per-shape default (tools/conv_bench.py on MI355X, B = 192): 256x128 8-wave tiles win for N = 128 with many
   // M tiles (layer2: 120 vs 130 us); 128x128 wins where 256-row tiles would leave CUs idle (layers 3-4)
   if (cfg == 0) cfg = (g.N == 128 && g.M >= 128 * 1024) ? 2 : 1;

@@ -300,6 +300,29 @@ inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(
                                              __attribute__((address_space(3))) void* l, unsigned size, int offset, int) {
   memcpy((char*)(uintptr_t)l + (size_t)emu::cur->lane * size + offset, (const void*)(uintptr_t)g, size);
 }
+// buffer resources (raw addressing): {base, num_records}; a load whose byte offset (voffset + immediate)
+// does not fit below num_records returns zero, as the hardware bounds check does
+struct emu_buffer_rsrc {
+  const char* base;
+  unsigned num_records;
+};
+typedef emu_buffer_rsrc __amdgpu_buffer_rsrc_t;
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_records, int) {
+  return emu_buffer_rsrc{(const char*)p, (unsigned)num_records};
+}
+inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, __attribute__((address_space(3))) void* l,
+                                                     unsigned size, int voffset, int soffset, int offset, int) {
+  char* dst = (char*)(uintptr_t)l + (size_t)emu::cur->lane * size + offset;
+  const unsigned long off = (unsigned long)(unsigned)voffset + (unsigned)offset;
+  if (off + size > r.num_records)
+    memset(dst, 0, size);
+  else
+    memcpy(dst, r.base + off + (unsigned)soffset, size);
+}
+inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width) {
+  return (int)((unsigned)v << (32 - off - width)) >> (32 - width);
+}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // callers pass wave-uniform values
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_barrier() { emu::block_sync(); }
 

@@ -55,6 +55,10 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
 
 
 print("dtype", "fp16" if dtype else "fp32", "B", B)
+ONLY_GEMM = os.environ.get("CB_ONLY") == "gemm"
+if ONLY_GEMM:
+    def bench(*a):  # noqa: F811
+        pass
 bench("layer1 3x3 64->64", 64, 86, 64, 64, 3, 1, 1)
 bench("layer2.0 3x3/2 64->128", 64, 86, 64, 128, 3, 2, 1)
 bench("layer2 3x3 128->128", 32, 43, 128, 128, 3, 1, 1)
@@ -62,6 +66,8 @@ bench("layer2.0 1x1/2 64->128", 64, 86, 64, 128, 1, 2, 0)
 bench("layer3 3x3 256->256", 16, 22, 256, 256, 3, 1, 1)
 bench("layer4 3x3 512->512", 8, 11, 512, 512, 3, 1, 1)
 # stem through the pixel-pair formulation
+if ONLY_GEMM:
+    B = 2
 g, Hp, Wp, H0, W0 = checks.stem_geom(B, 256, 341)
 xp = torch.randn(B, Hp, Wp, 4, device="cuda").to(td)
 wc = (torch.randn(64, 224, device="cuda") * 0.05).to(td)
@@ -77,11 +83,11 @@ print("stem 7x7/2 3->64        M=%8d  fwd %7.1f us %6.0f TF(real) out %5.2f TB/s
       % (g.M, t_f, fl / t_f / 1e6, y.numel() * 2 / t_f / 1e6, t_w, fl / t_w / 1e6))
 
 # asymptotic GEMM rate of the same kernel: 1x1 conv with a long K loop (no taps, 64+ K-steps)
-for (Ci, Co) in ((2048, 1024), (4096, 512)):
-    Bq, Hq = 32, 32
+for (Ci, Co, Bq) in ((2048, 1024, 32), (4096, 512, 32), (2304, 256, 66), (8192, 8192, 8)):
+    Hq = 32
     g, Ho, Wo = checks.fwd_geom(Bq, Hq, Hq, Ci, Co, 1, 1, 0)
     x = torch.randn(Bq, Hq, Hq, Ci, device="cuda").to(td)
     w = (torch.randn(Co, Ci, device="cuda") * 0.02).to(td)
     y = torch.empty(Bq, Hq, Hq, Co, dtype=td, device="cuda")
-    t = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, int(os.environ.get("MN_PRIO", "0")) * 256, None, None, one, ptr(checks.zero_page("cuda")), None))
+    t = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     print("plain GEMM M=%d N=%d K=%d: %7.1f us %6.0f TF" % (g.M, Co, Ci, t, 2.0 * g.M * Co * Ci / t / 1e6))

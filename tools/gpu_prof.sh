@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${TAG:-cur}; R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof_$TAG; export TMPDIR=/tmp
 timeout 600 python bench.py --steps 20 --warmup 5 ${BENCH_ARGS} > gpurun_out/prof_$TAG/bench.json 2> gpurun_out/prof_$TAG/bench.err; tail -1 gpurun_out/prof_$TAG/bench.json
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline ${PROF_ARGS} > $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
 cp /tmp/prof_stats/r_kernel_stats.csv $R/gpurun_out/prof_$TAG/kernel_stats.csv
 python3 - <<PY
 import csv

@@ -196,7 +196,14 @@ __device__ __forceinline__ int wg_swz(int row) {
   return (row & 3) << (PIECES_PER_ROW == 16 ? 2 : 1);
 }
 
-template <int BMO, int BNO, int BKM, int MINW>
+//
+// FAST (stride-1 "same" convolutions, the bulk of the network): the source address of tap (dh, dw) of pixel
+// m is linear in m, so a lane's byte offset is a constant plus a per-step scalar; only the validity of the
+// tap depends on (p, q), and that comes from a per-block LDS table (16-bit mask per pixel of one image,
+// built once) instead of being recomputed for every 16-byte piece.  Loads go through buffer resources: an
+// invalid tap / column / row past M is an all-ones offset and the bounds check returns zero.
+constexpr int WG_TBL = 6144;  // pixels of one image the validity table can hold
+template <int BMO, int BNO, int BKM, int MINW, bool FAST>
 static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a, const half* __restrict__ zero_page) {
   constexpr int VEC = 8;  // BKM = m rows per step (32 or 64)
   constexpr int YCP = BMO / VEC, XCP = BNO / VEC;
@@ -204,13 +211,16 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
   constexpr int YRS = 256 / YCP, XRS = 256 / XCP;              // rows covered per DMA pass
   constexpr int TM = BMO / 64, TN = BNO / 64;
   constexpr int TILE_Y = BKM * BMO, TILE_X = BKM * BNO;        // halves
-  __shared__ half smem[2 * (TILE_Y + TILE_X)] __attribute__((aligned(16)));
+  // ONE LDS object: [2 tiles of dY and X][validity table (FAST)]
+  __shared__ half smem[2 * (TILE_Y + TILE_X) + (FAST ? WG_TBL : 0)] __attribute__((aligned(16)));
+  unsigned short* tbl = reinterpret_cast<unsigned short*>(&smem[2 * (TILE_Y + TILE_X)]);
 
   const GatherGeom& g = a.g;
   const GatherGeom& g_ = a.g;
   const half* dY = reinterpret_cast<const half*>(a.dY);
   const half* X = reinterpret_cast<const half*>(a.X);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware order over a 1-D grid: tiles of one m-range (same split) are adjacent on one XCD, so the
   // dY / X rows they share are fetched into that XCD's L2 once
@@ -234,18 +244,67 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
   const int c0 = x_ok ? kcol % g.C : 0;
   const int dh = g.rsign * (tap / g.S), dw = g.ssign * (tap % g.S);
   int xb[XPT], xp[XPT], xq[XPT];
+  // FAST state
+  const int PQ = g.P * g.Q;
+  unsigned y_fix[YPT], x_fix[XPT];
+  int x_pix[XPT];
+  const unsigned y_bad = y_ok ? 0u : ~0u, x_bad = x_ok ? 0u : ~0u;
+  __amdgpu_buffer_rsrc_t rsrc_y, rsrc_x;
+  if constexpr (FAST) {
+    rsrc_y = make_rsrc(dY, (long)g.M * a.ldy * 2);
+    rsrc_x = make_rsrc(X, (long)g.B * g.Hi * g.Wi * g.C * 2);
+    // validity table: bit `tap` of tbl[pix] is set when that tap of pixel pix = p*Q + q is outside the image
+    for (int pix = t; pix < PQ; pix += 256) {
+      const int p = pix / g.Q, q = pix - p * g.Q;
+      unsigned inv = 0;
+      int tp = 0;
+      for (int r = 0; r < g.R; ++r)
+        for (int s = 0; s < g.S; ++s, ++tp) {
+          const int hn = p + g.off_h + g.rsign * r, wn_ = q + g.off_w + g.ssign * s;
+          if (!((unsigned)hn < (unsigned)g.Hi && (unsigned)wn_ < (unsigned)g.Wi)) inv |= 1u << tp;
+        }
+      tbl[pix] = (unsigned short)inv;
+    }
 #pragma unroll
-  for (int i = 0; i < XPT; ++i) {
-    int m = m_begin + xrow + i * XRS;
-    xq[i] = m % g.Q;
-    int tmp = m / g.Q;
-    xp[i] = tmp % g.P;
-    xb[i] = tmp / g.P;
+    for (int i = 0; i < YPT; ++i)
+      y_fix[i] = (unsigned)(((m_begin + yrow + i * YRS) * a.ldy + n0 + ypiece * VEC) * 2);
+    const int shift = (g.off_h + dh) * g.Wi + g.off_w + dw;  // pixel offset of this lane's tap
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int m = m_begin + xrow + i * XRS;
+      x_fix[i] = (unsigned)(((m + shift) * g.C + c0) * 2);
+      x_pix[i] = m % PQ;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      int m = m_begin + xrow + i * XRS;
+      xq[i] = m % g.Q;
+      int tmp = m / g.Q;
+      xp[i] = tmp % g.P;
+      xb[i] = tmp / g.P;
+    }
   }
+  unsigned step_y = 0, step_x = 0;  // byte offsets of the current step from m_begin (scalar)
 
   auto issue_tile = [&](int mt, int buf) {
     half* ty = &smem[buf * (TILE_Y + TILE_X)];
     half* tx = ty + TILE_Y;
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < YPT; ++i)
+        dma16(rsrc_y, (y_fix[i] + step_y) | y_bad, 0u, ty + (i * YRS * YCP + wave * 64) * VEC);
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const unsigned inv = (unsigned)__builtin_amdgcn_sbfe((int)tbl[x_pix[i]], tap, 1);
+        dma16(rsrc_x, (x_fix[i] + step_x) | inv | x_bad, 0u, tx + (i * XRS * XCP + wave * 64) * VEC);
+        x_pix[i] += BKM;  // BKM <= PQ (launch condition): one conditional wrap
+        x_pix[i] -= x_pix[i] >= PQ ? PQ : 0;
+      }
+      step_y += (unsigned)(BKM * a.ldy * 2);
+      step_x += (unsigned)(BKM * g.C * 2);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < YPT; ++i) {
       const int m = mt + yrow + i * YRS;
@@ -290,6 +349,7 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
   const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
   const int kgrp = (gq >> 1) * 8;
 
+  if constexpr (FAST) __syncthreads();  // validity table complete
   if (m_begin < m_end) issue_tile(m_begin, 0);
   int cur = 0;
   for (int mt = m_begin; mt < m_end; mt += BKM) {
@@ -349,14 +409,30 @@ struct WgradDma<half> {
   template <int BKM, int MINW>
   static void go(const WgradArgs& a, dim3 grid, int bmo, int bno, hipStream_t stream, const half* zp) {
     dim3 block(256);
+    const GatherGeom& g = a.g;
+    static const bool allow_fast = !(getenv("MN_WGRAD_FAST") && atoi(getenv("MN_WGRAD_FAST")) == 0);
+    const bool fast = allow_fast && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&
+                      g.R * g.S <= 16 && g.P * g.Q <= WG_TBL && g.P * g.Q >= BKM && g.C % 8 == 0 &&
+                      (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l;
+    if (fast) {
+      if (bmo == 64 && bno == 64)
+        hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW, true>), grid, block, 0, stream, a, zp);
+      else if (bmo == 64)
+        hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW, true>), grid, block, 0, stream, a, zp);
+      else if (bno == 64)
+        hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW, true>), grid, block, 0, stream, a, zp);
+      else
+        hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW, true>), grid, block, 0, stream, a, zp);
+      return;
+    }
     if (bmo == 64 && bno == 64)
-      hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW>), grid, block, 0, stream, a, zp);
+      hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW, false>), grid, block, 0, stream, a, zp);
     else if (bmo == 64)
-      hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW>), grid, block, 0, stream, a, zp);
+      hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW, false>), grid, block, 0, stream, a, zp);
     else if (bno == 64)
-      hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW>), grid, block, 0, stream, a, zp);
+      hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW, false>), grid, block, 0, stream, a, zp);
     else
-      hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW>), grid, block, 0, stream, a, zp);
+      hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW, false>), grid, block, 0, stream, a, zp);
   }
   static bool launch(const WgradArgs& a, dim3 grid3, int bmo, int bno, hipStream_t stream, const void* zero_page) {
     const half* zp = reinterpret_cast<const half*>(zero_page);

@@ -41,6 +41,7 @@ def test_conv_data_gradient(lib, dtype, shape):
     ((3, 9, 11, 64, 128, 3, 2, 1), 8),
     ((2, 8, 10, 64, 128, 1, 2, 0), 1),
     ((5, 5, 6, 128, 128, 3, 1, 1), 40),   # many splits of the reduction
+    ((3, 7, 9, 128, 128, 3, 1, 1), 40),   # table-driven gather, ragged last split (M = 189)
 ])
 def test_conv_weight_gradient(lib, dtype, shape, blocks):
     checks.check_conv_wgrad(lib, DEV, dtype, *shape, target_blocks=blocks)

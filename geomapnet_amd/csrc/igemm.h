@@ -57,6 +57,27 @@ struct Epilogue {
   float alpha;           // scale applied to the accumulator
 };
 
+// n / d for 0 <= n < 2^31 without the ~35-instruction software division (Granlund-Montgomery round-up
+// multiplier): q = (mulhi(n, mul) + n) >> shift.  The row -> (image, y, x) decomposition of the gather
+// prologue runs once per row of every tile; for the short-K layers it was a third of the block's time.
+struct FastDiv {
+  unsigned mul, shift;
+};
+inline FastDiv make_fastdiv(int d) {
+  int l = 0;
+  while ((1u << l) < (unsigned)d) ++l;
+  FastDiv f;
+  f.mul = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << l) - (unsigned long long)d)) / (unsigned long long)d + 1);
+  f.shift = (unsigned)l;
+  return f;
+}
+__device__ __forceinline__ int fastdiv(int n, FastDiv f) {
+  return (int)((__umulhi((unsigned)n, f.mul) + (unsigned)n) >> f.shift);
+}
+struct RowDiv {
+  FastDiv q, p;  // divisors GatherGeom.Q and GatherGeom.P
+};
+
 template <typename T>
 __device__ __forceinline__ void mma_piece(const PieceView<T>& a, const PieceView<T>& b, floatx16& c);
 template <>
@@ -111,7 +132,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
-                                                                         const T* __restrict__ zero_page) {
+                                                                         const T* __restrict__ zero_page, RowDiv rd) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -124,7 +145,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   static_assert(APT >= 1 && BPT >= 1, "tile too small for the thread count");
   static_assert(D >= 1 && D <= 3, "ring depth");
   static_assert(RPP % 16 == 0, "swizzle must not see the per-thread row stride");
-  static_assert(NBUF * TILE_PIECES * 16 >= 64 * 128 * 4, "epilogue staging does not fit");
+  static_assert(NBUF * TILE_PIECES * 16 >= 64 * (BN < 128 ? BN : 128) * 4, "epilogue staging does not fit");
   // ONE LDS object (a second one makes hipcc drain vmcnt before every fragment read):
   // [ring of tiles][BatchNorm partial reduction: WM*BN*2 floats]
   __shared__ piece_t smem[NBUF * TILE_PIECES + WM * BN / 2];
@@ -158,24 +179,36 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     a_off[i] = 0u;
     a_inv[i] = ~0u;
     if (m < g.M) {
-      const int q = m % g.Q, tmp = m / g.Q;
-      const int p = tmp % g.P, b = tmp / g.P;
+      const int tmp = fastdiv(m, rd.q), q = m - tmp * g.Q;
+      const int b = fastdiv(tmp, rd.p), p = tmp - b * g.P;
       const int h0 = p * g.mul_p + g.off_h, w0 = q * g.mul_q + g.off_w;
       a_off[i] = (unsigned)((((b * g.Hi + (h0 >> dsh)) * g.Wi + (w0 >> dsh)) * g.C) * (int)sizeof(T)) +
                  (uni ? (unsigned)src_piece * 16u : 0u);
-      int tap = 0;
-      for (int r = 0; r < g.R; ++r)
-        for (int s = 0; s < g.S; ++s, ++tap) {
-          int hn = h0 + g.rsign * r, wn_ = w0 + g.ssign * s;
-          bool ok = true;
-          if (dsh) {
-            ok = ((hn | wn_) & 1) == 0;
-            hn >>= 1;
-            wn_ >>= 1;
-          }
-          ok = ok && (unsigned)hn < (unsigned)g.Hi && (unsigned)wn_ < (unsigned)g.Wi;
-          if (ok) a_inv[i] &= ~(1u << tap);
+      // validity is separable: tap (r, s) is inside the image iff row r and column s both are
+      unsigned cinv = 0;  // bit s set: column tap s outside
+      for (int s = 0; s < g.S; ++s) {
+        int wn_ = w0 + g.ssign * s;
+        bool ok = true;
+        if (dsh) {
+          ok = (wn_ & 1) == 0;
+          wn_ >>= 1;
         }
+        ok = ok && (unsigned)wn_ < (unsigned)g.Wi;
+        cinv |= (ok ? 0u : 1u) << s;
+      }
+      const unsigned call = (1u << g.S) - 1u;
+      unsigned inv = 0;
+      for (int r = 0; r < g.R; ++r) {
+        int hn = h0 + g.rsign * r;
+        bool ok = true;
+        if (dsh) {
+          ok = (hn & 1) == 0;
+          hn >>= 1;
+        }
+        ok = ok && (unsigned)hn < (unsigned)g.Hi;
+        inv |= (ok ? cinv : call) << (r * g.S);
+      }
+      a_inv[i] = inv | (g.R * g.S < 32 ? ~0u << (g.R * g.S) : 0u);
     }
   }
   unsigned b_off[BPT];
@@ -399,8 +432,11 @@ inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const 
                             const T* zero_page) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int gm = cdiv(g.M, BM), gn = cdiv(g.N, BN);
+  RowDiv rd;
+  rd.q = make_fastdiv(g.Q);
+  rd.p = make_fastdiv(g.P);
   hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI>), dim3(gm * gn), dim3(WM * WN * 64), 0, stream, g, A, Bw,
-                     ep, gn, zero_page);
+                     ep, gn, zero_page, rd);
   return gm;
 }
 
@@ -416,9 +452,13 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
     if (g.N <= 64) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);
     return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);
   }
-  // per-shape default (tools/conv_bench.py on MI355X, B = 192): 256x128 8-wave tiles win for N = 128 with many
-  // M tiles (layer2: 120 vs 130 us); 128x128 wins where 256-row tiles would leave CUs idle (layers 3-4)
-  if (cfg == 0) cfg = (g.N == 128 && g.M >= 128 * 1024) ? 2 : 1;
+  // per-shape default (tools/conv_bench.py on MI355X, B = 192): 128x128 tiles, two workgroups per CU (512 slots);
+  // when that leaves a few tiles over one full round (layer4: 528 tiles), 256x128 tiles with 128-row wave tiles
+  // put every tile in a single round instead (103 vs 121 us)
+  if (cfg == 0) {
+    const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    cfg = (g.N >= 128 && g.N % 128 == 0 && tiles128 > 512 && tiles128 <= 640) ? 8 : 1;
+  }
   if (cfg >= 8 && cfg <= 13 && (g.N % 64 == 0) && g.N >= 128) {  // 128-row wave tiles (4 waves)
     if (cfg == 8) return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);   // 256x128, ring 3
     if (cfg == 9) return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 2, 2>(g, A, Bw, ep, stream, zero_page);   // 256x128, ring 2
@@ -431,6 +471,11 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
     if (cfg == 8 || cfg == 10) return launch_igemm_cfg<T, 2, 1, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 256x64, 2 waves
     if (cfg == 9 || cfg == 11) return launch_igemm_cfg<T, 2, 2, 4, 1, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 256x64, 4 waves
     return launch_igemm_cfg<T, 4, 1, 2, 2, 4, 3, 3>(g, A, Bw, ep, stream, zero_page);
+  }
+  if (g.N <= 64 && cfg >= 14 && cfg <= 16) {  // more resident blocks for the short-K, narrow-N layers
+    if (cfg == 14 && wide_k) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);
+    if (cfg == 15) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 3, 4>(g, A, Bw, ep, stream, zero_page);
+    return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
   }
   if (g.N <= 64) {
     if (cfg != 1) return launch_igemm_cfg<T, 4, 1, 2, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);

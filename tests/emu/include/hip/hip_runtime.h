@@ -322,7 +322,8 @@ inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, _
 inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width) {
   return (int)((unsigned)v << (32 - off - width)) >> (32 - width);
 }
-inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // callers pass wave-uniform values
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }  // callers pass wave-uniform values
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_barrier() { emu::block_sync(); }
 

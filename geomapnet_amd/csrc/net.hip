@@ -591,7 +591,10 @@ struct Plan : PlanBase {
     a.alpha = 1.f / cfg.loss_scale; a.rows_per_split = 0;
     hipStream_t ws = fork_wgrad(s);
     auto* tp = timer.begin(1, ws);
-    launch_wgrad<T>(a, 1024, ws, zero_page);
+    // reduction splits (measured, tools/conv_bench.py): one round of 2 workgroups per CU for the wide layers (half
+    // the atomic traffic of 1024), more for layer1 and the stem whose pixel dimension is 4-16x longer
+    const int target = u.cp.cout >= 128 ? 512 : (u.M > 2000000 ? 2048 : 1024);
+    launch_wgrad<T>(a, target, ws, zero_page);
     timer.end(tp, ws);
   }
   void conv_dgrad(Unit& u, T* gx, const T* res, const T* gate, hipStream_t s) {

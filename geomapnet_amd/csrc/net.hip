@@ -268,7 +268,8 @@ struct Plan : PlanBase {
   unsigned char* frozen;
   int* stem_colmap;
   RepackJob* repack_jobs;
-  int repack_njobs = 0, repack_blocks = 0;
+  int repack_njobs = 0, repack_blocks = 0, repack_head_jobs = -1, repack_head_blocks = 0;
+  bool grads_zeroed = false;
   unsigned char* pool_idx;  // winning tap of every max-pool window
   void* zero_page;          // 256 zero bytes: source of out-of-image taps for the DMA conv pipeline
   long long* step_dev;      // device-resident Adam step counter
@@ -469,7 +470,12 @@ struct Plan : PlanBase {
       jobs.push_back(j);
     };
     add(stem.cp.w, stem.wf, nullptr, 64, 7, 7, 3, 2);
+    repack_head_jobs = -1;
     for (auto& bk : blocks) {
+      if (bk.stage >= 1 && repack_head_jobs < 0) {  // jobs before this one serve the stem and layer1
+        repack_head_jobs = (int)jobs.size();
+        repack_head_blocks = blk;
+      }
       Unit* us[3] = {&bk.u1, &bk.u2, bk.down ? &bk.ud : nullptr};
       for (Unit* u : us) {
         if (!u) continue;
@@ -483,9 +489,16 @@ struct Plan : PlanBase {
     hipMemcpyAsync(repack_jobs, jobs.data(), jobs.size() * sizeof(RepackJob), hipMemcpyHostToDevice, s);
     hipStreamSynchronize(s);  // `jobs` is a host temporary
   }
-  void repack(hipStream_t s) {
-    hipLaunchKernelGGL((repack_all_kernel<T>), dim3(repack_blocks), dim3(256), 0, s, (const RepackJob*)repack_jobs,
-                       repack_njobs, (const float*)params);
+  // head = stem + layer1 weights (needed first), tail = everything else; the tail can run on the side stream
+  // while the stem and layer1 execute
+  void repack(hipStream_t s_head, hipStream_t s_tail) {
+    const int hj = repack_head_jobs > 0 ? repack_head_jobs : repack_njobs;
+    const int hb = repack_head_jobs > 0 ? repack_head_blocks : repack_blocks;
+    hipLaunchKernelGGL((repack_all_kernel<T>), dim3(hb), dim3(256), 0, s_head, (const RepackJob*)repack_jobs, hj,
+                       (const float*)params, 0);
+    if (repack_blocks > hb)
+      hipLaunchKernelGGL((repack_all_kernel<T>), dim3(repack_blocks - hb), dim3(256), 0, s_tail,
+                         (const RepackJob*)repack_jobs, repack_njobs, (const float*)params, hb);
     weights_dirty = false;
   }
 
@@ -522,7 +535,17 @@ struct Plan : PlanBase {
   }
 
   int forward(const float* images, float* poses_out, int training, hipStream_t s) override {
-    if (weights_dirty) repack(s);
+    return forward_impl(images, poses_out, training, false, s);
+  }
+  int forward_impl(const float* images, float* poses_out, int training, bool zero_grads, hipStream_t s) {
+    // work the stem and layer1 do not depend on goes to the side stream: the repack of the later layers'
+    // weights and optim.learner.zero_grad(); joined before layer2
+    if (weights_dirty || zero_grads) {
+      hipStream_t side = fork_wgrad(s);
+      if (weights_dirty) repack(s, side);
+      if (zero_grads) hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, side);
+    }
+    grads_zeroed = zero_grads;
     cur_training = training;
     if (training) hipMemsetAsync(acc_region, 0, acc_bytes, s);  // forward statistics + backward reduction sums
     hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s, images, xpad, B,
@@ -532,6 +555,7 @@ struct Plan : PlanBase {
     hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
                        (const T*)a0, p0, pool_idx, B, H0, W0, 64, H1, W1);
     for (auto& blk : blocks) {
+      if (blk.stage >= 1) join_wgrad(s);  // no-op once joined
       conv_bn_stats(blk.u1, blk.x, training, s);
       bn_act(blk.u1, nullptr, 1, blk.a1, s);
       conv_bn_stats(blk.u2, blk.a1, training, s);
@@ -543,6 +567,7 @@ struct Plan : PlanBase {
       }
       bn_act(blk.u2, res, 1, blk.out, s);
     }
+    join_wgrad(s);
     const Block& last = blocks.back();
     int F = cfg.feat_dim;
     hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(cdiv((long)B * 512, 256)), dim3(256), 0, s, (const T*)last.out, pooled,
@@ -574,7 +599,7 @@ struct Plan : PlanBase {
     return check_launch("loss");
   }
   int forward_loss(const float* images, const float* targets, float* loss_out, float* poses_out, hipStream_t s) override {
-    if (int e = forward(images, poses_out, 1, s)) return e;
+    if (int e = forward_impl(images, poses_out, 1, true, s)) return e;
     cur_targets = targets;
     cur_loss = loss_out ? loss_out : loss_dev;
     return 0;
@@ -624,7 +649,8 @@ struct Plan : PlanBase {
   void head_backward(hipStream_t s) {
     int F = cfg.feat_dim;
     float unscale = 1.f / cfg.loss_scale;
-    hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, s);  // optim.learner.zero_grad()
+    if (!grads_zeroed) hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, s);  // optim.learner.zero_grad()
+    grads_zeroed = false;
     run_criterion(poses, cur_targets, cur_loss, dposes, grads + L.crit, s);
     hipLaunchKernelGGL(head_bwd_input_kernel, dim3(cdiv((long)B * F, 256)), dim3(256), 0, s, (const float*)dposes,
                        (const float*)feat, (const float*)(params + L.xyz_w), (const float*)(params + L.wpqr_w), dz, B, F,

@@ -124,14 +124,15 @@ struct RepackJob {
 
 template <typename T>
 static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob* __restrict__ jobs, int njobs,
-                                                                const float* __restrict__ params) {
+                                                                const float* __restrict__ params, int blk_base) {
+  const int bid = (int)blockIdx.x + blk_base;  // a launch may cover a sub-range of the table's workgroups
   int j = 0;
-  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  while (j + 1 < njobs && bid >= jobs[j + 1].blk0) ++j;
   const RepackJob job = jobs[j];
   const float* src = params + job.src_off;
   const int O = job.O, R = job.R, S = job.S, I = job.I;
   const long total = job.mode == 2 ? (long)O * R * 32 : (long)O * R * S * I;
-  const long base = (long)((int)blockIdx.x - job.blk0) * 4096;
+  const long base = (long)(bid - job.blk0) * 4096;
   for (int k = 0; k < 16; ++k) {
     const long idx = base + k * 256 + threadIdx.x;
     if (idx >= total) break;

@@ -156,8 +156,14 @@ def main():
         if use_events and conv_ms > 0:
             conv_ms_step = conv_ms / args.steps
             ach = GFLOP_PER_IMAGE_TRAIN * n * T / conv_ms_step  # GFLOP / ms = TFLOP/s, per GPU
+            traffic = None  # HBM bytes of the same launches, from separate rocprofv3 --pmc passes (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01", "pmc_conv_traffic.json")) as f:
+                    traffic = json.load(f)["hbm_bytes_per_step"] if (args.dtype == "fp16" and n == 64) else None
+            except Exception:
+                pass
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "kernel": "igemm_kernel + wgrad_kernel (all %d conv launches of a step)" % (conv_launches // args.steps),
+                    "traffic": traffic, "kernel": "igemm_kernel + wgrad_kernel (all %d conv launches of a step)" % (conv_launches // args.steps),
                     "conv_ms_per_step": round(conv_ms_step, 3), "eager_profiled_ms_per_step": round(eager_ms, 3),
                     "flops_per_step_G": round(GFLOP_PER_IMAGE_TRAIN * n * T, 1),
                     "whole_step_frac": round(GFLOP_PER_IMAGE_TRAIN * n * T / ms_per_step / peak, 4)}

@@ -741,6 +741,12 @@ static int validate(const mn_config* c) {
   if (c->H < 32 || c->W < 32) return fail("config: image must be at least 32x32");
   if (c->feat_dim < 64 || c->feat_dim % 64 != 0) return fail("config: feat_dim must be a multiple of 64");
   if (!(c->loss_scale > 0.f)) return fail("config: loss_scale must be positive");
+  {  // the largest activation (stem output, NHWC) must stay below the 4 GiB a 32-bit buffer offset spans
+    const long frames = c->mode == MN_MODE_POSENET ? 1 : (c->mode == MN_MODE_MAPNET ? c->T : 2 * c->T);
+    const long px = ((c->H - 1) / 2 + 1) * (long)((c->W - 1) / 2 + 1);
+    if (c->windows * frames * px * 64 * (c->dtype == MN_DTYPE_F16 ? 2 : 4) >= 0xfffffff0l)
+      return fail("config: batch too large (an activation tensor would exceed 4 GiB); split the batch");
+  }
   return 0;
 }
 

@@ -56,6 +56,11 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   GatherGeom g = to_geom(gg);
   if (int e = check_geom(g, dtype)) return e;
   if (!zero_page) return fail("igemm: zero_page (>= 16 zero bytes of device memory) is required");
+  {
+    const long es = dtype == MN_DTYPE_F16 ? 2 : 4;
+    if ((long)gg->B * gg->Hi * gg->Wi * gg->C * es >= 0xfffffff0l || (long)gg->N * gg->K * es >= 0xfffffff0l)
+      return fail("igemm: operands must be smaller than 4 GiB (32-bit buffer offsets)");
+  }
   Epilogue ep;
   ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
   ep.alpha = alpha;

@@ -141,8 +141,10 @@ typedef struct mn_gather_geom {
 
 /* out[m][n] = alpha * sum_k gather(A)[m][k] * Bw[n][k] (+bias, relu, residual): conv forward /
  * data-gradient / linear.  stats: [mn_op_igemm_grid_m(M)][2][N] fp32 partial column sums or NULL.
- * zero_page: >= 16 zero bytes in device memory, 16-byte aligned (source of the taps that fall outside
- * the image for the LDS-DMA pipeline), or NULL to use the register-staged kernel. */
+ * A and Bw are read through 32-bit-offset buffer resources (each must be smaller than 4 GiB); taps outside
+ * the image are zero-filled by the hardware bounds check.  zero_page: >= 16 zero bytes in device memory,
+ * 16-byte aligned; required (the weight-gradient kernels that gather strided convolutions read their
+ * out-of-image taps from it; mn_op_igemm accepts it for symmetry). */
 int mn_op_igemm(int dtype, const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
                 const float* bias, int relu, const void* res, const void* res_gate, float alpha, const void* zero_page,
                 void* stream);

@@ -141,19 +141,25 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long M, int C,
                                                              double* __restrict__ accum, int rows_per_block,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial,
+                                                             const float* __restrict__ sg_gamma,
+                                                             const float* __restrict__ sg_beta) {
+  // sg_gamma/sg_beta non-null ("self gate"): the consumer is this BatchNorm's own ReLU, so the gate
+  // relu'(bn(y)) is recomputed from y (y*scale + shift > 0, the forward's arithmetic) instead of being read
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ float red[2][256][VEC];
   const int cpr = C / VEC;           // pieces per row (power of two, <= 256)
   const int rlanes = 256 / cpr;
   const int cp = threadIdx.x % cpr, rl = threadIdx.x / cpr;
   const int c0 = cp * VEC;
-  float mu[VEC], is[VEC], s1[VEC], s2[VEC];
+  float mu[VEC], is[VEC], s1[VEC], s2[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
     mu[e] = mean[c0 + e];
     is[e] = invstd[c0 + e];
     s1[e] = s2[e] = 0.f;
+    sc[e] = sg_gamma ? sg_gamma[c0 + e] * is[e] : 0.f;
+    sh[e] = sg_gamma ? sg_beta[c0 + e] - mu[e] * sc[e] : 0.f;
   }
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
@@ -176,6 +182,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
       for (int e = 0; e < VEC; ++e) {
         float gv = (float)vg[u].e[e];
         if (gate && !((float)vm[u].e[e] > 0.f)) gv = 0.f;
+        if (sg_gamma && !((float)vy[u].e[e] * sc[e] + sh[e] > 0.f)) gv = 0.f;
         s1[e] += gv;
         s2[e] += gv * ((float)vy[u].e[e] - mu[e]) * is[e];
       }
@@ -213,12 +220,14 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const double* __restrict__ accum, double count,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float grad_unscale, T* __restrict__ gy, long npieces, int C) {
+                                                            float grad_unscale, T* __restrict__ gy, long npieces, int C,
+                                                            const float* __restrict__ sg_beta) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512];
+  __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512], s_sh[512];
   for (int c = threadIdx.x; c < C; c += 256) {
     const double sg = accum[c], sgx = accum[C + c];
     s_k1[c] = gamma[c] * invstd[c];
+    s_sh[c] = sg_beta ? sg_beta[c] - mean[c] * (gamma[c] * invstd[c]) : 0.f;
     s_mg[c] = (float)(sg / count);
     s_mgx[c] = (float)(sgx / count);
     s_mean[c] = mean[c];
@@ -241,6 +250,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
       int c = c0 + e;
       float gv = (float)vg.e[e];
       if (gate && !((float)vm.e[e] > 0.f)) gv = 0.f;
+      if (sg_beta && !((float)vy.e[e] * s_k1[c] + s_sh[c] > 0.f)) gv = 0.f;  // self gate (see the reduce kernel)
       float xh = ((float)vy.e[e] - s_mean[c]) * s_is[c];
       o.e[e] = (T)(s_k1[c] * (gv - s_mg[c] - xh * s_mgx[c]));
     }
@@ -295,8 +305,12 @@ static __global__ void __launch_bounds__(256) bn_fwd_stats_kernel(const T* __res
 template <typename T>
 inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, const float* gamma, const float* mean,
                           const float* invstd, float* dgamma, float* dbeta, T* gy, double* accum, float grad_unscale,
-                          hipStream_t s, float* partial = nullptr) {
+                          hipStream_t s, float* partial = nullptr, const float* self_gate_beta = nullptr) {
+  // self_gate_beta: the gradient g is taken w.r.t. relu(bn(y)) of THIS BatchNorm; the ReLU gate is recomputed
+  // from y and `gate` is not read
   constexpr int VEC = ElemTraits<T>::VEC;
+  const float* sg_gamma = self_gate_beta ? gamma : nullptr;
+  if (self_gate_beta) gate = nullptr;
   // ~4096 workgroups in flight: the reduction is HBM-bound and needs the whole chip
   const int rlanes = 256 / (C / VEC);
   long rows = (M + 4095) / 4096;
@@ -305,13 +319,13 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
-                     rows_per_block, partial);
+                     rows_per_block, partial, sg_gamma, self_gate_beta);
   if (partial)
     hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(nblk, 64), cdiv(C, 64)), dim3(256), 0, s,
                        (const float*)partial, nblk, C, accum, 64);
   long np = M * C / VEC;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd, gamma,
-                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C);
+                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C, self_gate_beta);
 }
 
 // ---- global average pool --------------------------------------------------------------------------

@@ -413,11 +413,12 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 inline int igemm_grid_m(int M) { return cdiv(M, 128); }
 
 // Tile configuration.  MN_IGEMM_CONFIG (tuning knob, read once) overrides the per-shape choice:
-//   1: 128x128 / 128x64, 4 waves, 128-byte steps, 2 buffers          (2 blocks/CU)
-//   2: 256x128, 8 waves, 64-byte steps, 2 buffers, registers capped   (2 blocks/CU)
-//   3: 256x128, 8 waves, 128-byte steps, 2 buffers                    (1 block/CU)
-//   4: 256x256, 8 waves, 64-byte steps, 2 buffers                     (1 block/CU)
-//   5: as 1, but 256x64 (4x1 waves) for N <= 64
+//   1: 128x128 / 128x64 (N <= 64), 4 waves of 64x64 / 64x32, 128-byte K-steps, 2 buffers   (2 workgroups/CU)
+//   2: 256x128, 8 waves of 64x64, 64-byte K-steps, 2 buffers
+//   8: 256x128, 4 waves of 128x64, 64-byte K-steps, 3 buffers                              (2 workgroups/CU)
+//  10: 256x256, 4 waves of 128x128, 64-byte K-steps, 3 buffers                             (1 workgroup/CU)
+// Measured alternatives that lost everywhere and were removed: 3-4 workgroups/CU (64-byte steps), deeper rings,
+// 256x64 tiles for N = 64, 8-wave 256x256.
 inline int igemm_config() {
   static int v = -1;
   if (v < 0) {
@@ -459,35 +460,15 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
     cfg = (g.N >= 128 && g.N % 128 == 0 && tiles128 > 512 && tiles128 <= 640) ? 8 : 1;
   }
-  if (cfg >= 8 && cfg <= 13 && (g.N % 64 == 0) && g.N >= 128) {  // 128-row wave tiles (4 waves)
-    if (cfg == 8) return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);   // 256x128, ring 3
-    if (cfg == 9) return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 2, 2>(g, A, Bw, ep, stream, zero_page);   // 256x128, ring 2
-    if (cfg == 10 && g.N >= 256) return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 3, 1>(g, A, Bw, ep, stream, zero_page);  // 256x256
-    if (cfg == 11 && g.N >= 256) return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 2, 1>(g, A, Bw, ep, stream, zero_page);
-    if (cfg == 12 && g.N >= 256) return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 4, 1>(g, A, Bw, ep, stream, zero_page);
-    return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);
-  }
-  if (cfg >= 8 && g.N <= 64) {
-    if (cfg == 8 || cfg == 10) return launch_igemm_cfg<T, 2, 1, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 256x64, 2 waves
-    if (cfg == 9 || cfg == 11) return launch_igemm_cfg<T, 2, 2, 4, 1, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 256x64, 4 waves
-    return launch_igemm_cfg<T, 4, 1, 2, 2, 4, 3, 3>(g, A, Bw, ep, stream, zero_page);
-  }
-  if (g.N <= 64 && cfg >= 14 && cfg <= 16) {  // more resident blocks for the short-K, narrow-N layers
-    if (cfg == 14 && wide_k) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);
-    if (cfg == 15) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 3, 4>(g, A, Bw, ep, stream, zero_page);
-    return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
-  }
   if (g.N <= 64) {
-    if (cfg != 1) return launch_igemm_cfg<T, 4, 1, 2, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);
     if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
     return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
   }
-  if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
-  if (cfg == 6) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 3, 4>(g, A, Bw, ep, stream, zero_page);  // 2 tiles in flight
-  if (cfg == 7) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 4, 4>(g, A, Bw, ep, stream, zero_page);  // 3 tiles in flight
-  if (cfg == 3 && wide_k) return launch_igemm_cfg<T, 4, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
-  if (cfg == 4 && g.N >= 256) return launch_igemm_cfg<T, 4, 2, 2, 4, 4, 2, 2>(g, A, Bw, ep, stream, zero_page);
-  if (cfg == 4) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 8 && g.N % 64 == 0)  // 256x128, 4 waves of 128x64, 64-byte K-steps, 3 buffers
+    return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 10 && g.N >= 256 && g.N % 128 == 0)  // 256x256, 4 waves of 128x128 (one wave per SIMD)
+    return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 3, 1>(g, A, Bw, ep, stream, zero_page);
+  if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);  // 256x128, 8 waves
   if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
   return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
 }

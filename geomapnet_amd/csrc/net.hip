@@ -606,10 +606,13 @@ struct Plan : PlanBase {
   }
 
   // ---- backward -------------------------------------------------------------------------------------
-  void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s) {
+  // self_gate: `gate` is relu(bn_u(y)) itself (a1 of a block, a0 of the stem): recomputed from y, not read
+  void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s, bool self_gate = false) {
     launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
-                     grads + u.bp.beta, u.gy, u.accum_b, 1.f / cfg.loss_scale, s, bwd_partial);
+                     grads + u.bp.beta, u.gy, u.accum_b, 1.f / cfg.loss_scale, s, bwd_partial,
+                     (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr);
   }
+  bool self_gate_ok = !(getenv("MN_SELF_GATE") && atoi(getenv("MN_SELF_GATE")) == 0);
   void conv_wgrad(Unit& u, const T* x, hipStream_t s) {
     WgradArgs a;
     a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
@@ -635,7 +638,7 @@ struct Plan : PlanBase {
     bn_bwd(blk.u2, blk.gout, blk.out, s);
     conv_wgrad(blk.u2, blk.a1, s);
     conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
-    bn_bwd(blk.u1, blk.ga1, blk.a1, s);
+    bn_bwd(blk.u1, blk.ga1, blk.a1, s, true);
     conv_wgrad(blk.u1, blk.x, s);
     if (blk.down) {
       bn_bwd(blk.ud, blk.gout, blk.out, s);
@@ -680,7 +683,7 @@ struct Plan : PlanBase {
   void stem_backward(hipStream_t s) {
     hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s,
                        (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
-    bn_bwd(stem, ga0, a0, s);
+    bn_bwd(stem, ga0, a0, s, true);
     conv_wgrad(stem, xpad, s);  // the input gradient of the stem is not needed (nothing consumes it)
   }
   int backward_stage(int stage, hipStream_t s) override {

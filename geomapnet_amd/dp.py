@@ -55,19 +55,22 @@ def _staged_step(engine, plan, images, targets, lib, h, s):
     lib.check(lib.train_forward_loss(h, ptr(images), ptr(targets), ptr(plan["loss"]), ptr(poses), s))
     grads = engine.grads()
     works = []
+    multi = world_size() > 1 or (dist.is_available() and dist.is_initialized())
     for stage in (3, 2, 1, 0):
         lib.check(lib.train_backward_stage(h, stage, s))
         off, cnt = C.c_int64(), C.c_int64()
         lib.check(lib.grad_bucket(h, stage, C.byref(off), C.byref(cnt)))
         bucket = grads[off.value: off.value + cnt.value]
         # async: RCCL runs on its own stream, ordered after the kernels enqueued so far
-        works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+        if multi:
+            works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
     for w in works:
         w.wait()  # stream-level wait on CUDA/HIP; blocking on gloo
     lib.check(lib.optim_step(h, 1.0 / world_size(), s))
     engine._stepped(plan)
     # reported loss = mean of the rank losses (one scalar all-reduce)
     loss = plan["loss"].clone()
-    dist.all_reduce(loss, op=dist.ReduceOp.SUM)
-    loss /= world_size()
+    if multi:
+        dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+        loss /= world_size()
     return loss, poses.clone()

@@ -6,12 +6,18 @@ read-back the reference does at :361).  With torch.distributed initialised (worl
 is issued in stages so each gradient bucket's RCCL all-reduce overlaps the remaining backward
 (geomapnet_amd/dp.py).
 """
+import os
+
 import torch
 
 from .criterion import _Criterion
 from .engine import MODE_POSENET
 from .posenet import MapNet, engine_of
 from . import dp
+
+
+# diagnostic: issue the step in the staged (data-parallel) form even on one GPU, e.g. to measure its overhead
+_FORCE_STAGED = os.environ.get("MN_FORCE_STAGED", "0") == "1"
 
 
 def _bind(engine, criterion, optim):
@@ -57,7 +63,7 @@ def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, tra
     plan = engine.plan(mode, n, t, H, W)
     lr, wd, betas, eps = optim.learner.hyper()
     engine.configure_step(plan, lr, wd, betas, eps, float(max_grad_norm), criterion.learn_beta, criterion.learn_gamma)
-    if dp.world_size() > 1:
+    if dp.world_size() > 1 or _FORCE_STAGED:
         loss, poses = dp.train_step(engine, plan, data, target)
     else:
         loss, poses = engine.train_step(plan, data, target)

@@ -116,6 +116,24 @@ def test_mapnet_train_step_fp16_close(lib):
                             grad_l2_rtol=None)
 
 
+def test_mapnet_staged_step_fp32_parity_with_rccl(lib, monkeypatch):
+    """the data-parallel form of the step on one GPU: forward / 4 backward stages / optimiser as separate captured
+    segments with a (single-rank) RCCL all-reduce of every gradient bucket in between"""
+    import torch.distributed as dist
+    import geomapnet_amd.train as T
+    monkeypatch.setattr(T, "_FORCE_STAGED", True)
+    started = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        started = True
+    try:
+        checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+    finally:
+        if started:
+            dist.destroy_process_group()
+
+
 def test_eval_forward_parity(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=3, H=128, W=171)
     checks.check_eval_forward(lib, DEV, "fp16", B=3, H=128, W=171, atol=3e-2)

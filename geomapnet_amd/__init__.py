@@ -5,3 +5,4 @@ from .posenet import PoseNet, MapNet, resnet34  # noqa: F401
 from .criterion import PoseNetCriterion, MapNetCriterion, MapNetOnlineCriterion  # noqa: F401
 from .optimizer import Optimizer  # noqa: F401
 from .train import step_feedfwd  # noqa: F401
+from . import evaluate  # noqa: F401  (scripts/eval.py flow + error metric)

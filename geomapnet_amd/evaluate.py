@@ -1,0 +1,89 @@
+"""Evaluation flow and error metric of the reference (host side, fp64 numpy, as the reference computes it).
+
+Mirrors /root/reference/scripts/eval.py:153-205 (inference loop, "take the middle prediction",
+un-normalisation, error statistics) and the numpy helpers it uses from
+/root/reference/common/pose_utils.py: `qexp` (:319-327), `quaternion_angular_error` (:361-371);
+`t_criterion` is the L2 norm of eval.py:80.  The network forward inside the loop is the HIP path
+(`step_feedfwd(train=False)`); pose-graph optimisation (eval.py:177-182) is out of scope.
+"""
+import numpy as np
+
+from .train import step_feedfwd
+
+
+def qexp(q):
+    """exponential map (3,) -> (4,): [cos n, sinc(n/pi) q]   (pose_utils.py:319-327)"""
+    q = np.asarray(q)
+    n = np.linalg.norm(q)
+    return np.hstack((np.cos(n), np.sinc(n / np.pi) * q))
+
+
+def quaternion_angular_error(q1, q2):
+    """angular error between two quaternions in degrees   (pose_utils.py:361-371)"""
+    d = abs(np.dot(q1, q2))
+    d = min(1.0, max(-1.0, d))
+    return 2 * np.arccos(d) * 180 / np.pi
+
+
+def log_quaternion_angular_error(q1, q2):
+    """pose_utils.py:358-359"""
+    return quaternion_angular_error(qexp(q1), qexp(q2))
+
+
+def t_criterion(t_pred, t_gt):
+    """eval.py:80"""
+    return np.linalg.norm(np.asarray(t_pred) - np.asarray(t_gt))
+
+
+q_criterion = quaternion_angular_error
+
+
+def to_pose7(logq_poses, pose_m, pose_s):
+    """[M,6] (translation, log-quaternion) -> [M,7] (un-normalised translation, unit quaternion);
+    eval.py:166-175 and :184-186"""
+    p = np.asarray(logq_poses, dtype=np.float64).reshape(-1, 6)
+    q = [qexp(r[3:]) for r in p]
+    out = np.hstack((p[:, :3], np.asarray(q).reshape(-1, 4)))
+    out[:, :3] = (out[:, :3] * np.asarray(pose_s, dtype=np.float64)) + np.asarray(pose_m, dtype=np.float64)
+    return out
+
+
+def pose_errors(pred_poses, targ_poses):
+    """per-frame translation error (same unit as the poses) and rotation error (degrees) of [L,7] arrays
+    (eval.py:192-196)"""
+    t_loss = np.asarray([t_criterion(p, t) for p, t in zip(pred_poses[:, :3], targ_poses[:, :3])])
+    q_loss = np.asarray([q_criterion(p, t) for p, t in zip(pred_poses[:, 3:], targ_poses[:, 3:])])
+    return t_loss, q_loss
+
+
+def summarize(t_loss, q_loss):
+    """the numbers eval.py:202-205 prints"""
+    return {"median_t": float(np.median(t_loss)), "mean_t": float(np.mean(t_loss)),
+            "median_q": float(np.median(q_loss)), "mean_q": float(np.mean(q_loss))}
+
+
+def evaluate(model, batches, pose_m=(0.0, 0.0, 0.0), pose_s=(1.0, 1.0, 1.0), cuda=True):
+    """Inference loop of eval.py:153-190 without pose-graph optimisation.
+
+    `batches`: iterable of (data, target) as the reference's DataLoader yields them with batch_size 1:
+    data [1,3,H,W] (PoseNet) or [1,T,3,H,W] (MapNet, `--model mapnet*`), target [1,6] / [1,T,6].  For
+    every batch the MIDDLE prediction of the window is kept (eval.py:187-190: `output[len(output)/2]`).
+    Returns (summary dict, pred_poses [L,7], targ_poses [L,7])."""
+    pred, targ = [], []
+    was_training = model.training
+    model.eval()
+    try:
+        for data, target in batches:
+            _, output = step_feedfwd(data, model, cuda, train=False)
+            s = output.size()
+            out = output.detach().cpu().numpy().reshape((-1, s[-1]))
+            tgt = np.asarray(target.detach().cpu().numpy() if hasattr(target, "detach") else target).reshape((-1, s[-1]))
+            out = to_pose7(out, pose_m, pose_s)
+            tgt = to_pose7(tgt, pose_m, pose_s)
+            pred.append(out[len(out) // 2])
+            targ.append(tgt[len(tgt) // 2])
+    finally:
+        model.train(was_training)
+    pred_poses, targ_poses = np.asarray(pred), np.asarray(targ)
+    t_loss, q_loss = pose_errors(pred_poses, targ_poses)
+    return summarize(t_loss, q_loss), pred_poses, targ_poses

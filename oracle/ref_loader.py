@@ -11,6 +11,8 @@ What is executed unmodified:
   * common/pose_utils.py:1-304     (torch section) -- the file as a whole is Python-2 only
     (print statements from :800) and imports transforms3d (:13-14, not installed), so the
     torch section is exec'd with `xrange = range` and those two import lines dropped.
+  * common/pose_utils.py:306-327, :358-371  (numpy qlog/qexp and the angular-error metric used by
+    scripts/eval.py), exec'd into the same namespace as `pose_utils_np`.
 `MapNetOnlineCriterion.forward` divides with `/` at :150 (Python-2 integer division); a
 subclass re-evaluates the same source with `//`.
 """
@@ -41,6 +43,13 @@ def load():
     pose_utils = types.ModuleType("common.pose_utils")
     pose_utils.__dict__["xrange"] = range
     exec(compile(src, "reference:common/pose_utils.py[1:304]", "exec"), pose_utils.__dict__)
+    with open(os.path.join(REFERENCE_ROOT, "common", "pose_utils.py")) as f:
+        all_lines = f.read().split("\n")
+    np_src = "\n".join(all_lines[305:327]) + "\n\n" + "\n".join(all_lines[357:371]) + "\n"
+    pose_utils_np = types.ModuleType("common.pose_utils_numpy_section")
+    import numpy as _np
+    pose_utils_np.__dict__["np"] = _np
+    exec(compile(np_src, "reference:common/pose_utils.py[306:327,358:371]", "exec"), pose_utils_np.__dict__)
 
     saved = {k: sys.modules.get(k) for k in ("common", "common.pose_utils", "common.criterion")}
     pkg = types.ModuleType("common")
@@ -77,7 +86,7 @@ def load():
     class MapNetOnlineCriterionPy3(criterion.MapNetOnlineCriterion):
         forward = g["forward"]
 
-    ns = types.SimpleNamespace(pose_utils=pose_utils, criterion=criterion, posenet=posenet,
+    ns = types.SimpleNamespace(pose_utils=pose_utils, pose_utils_np=pose_utils_np, criterion=criterion, posenet=posenet,
                                MapNetOnlineCriterionPy3=MapNetOnlineCriterionPy3)
     _cache["ns"] = ns
     return ns

@@ -436,3 +436,35 @@ def check_eval_forward(lib, dev, dtype_name, B=3, H=64, W=85, atol=1e-3):
         ref = onet(x)
     out = net(x.to(dev))
     assert (out.cpu() - ref).abs().max().item() <= atol * max(1.0, ref.abs().max().item())
+
+
+def check_eval_flow(lib, dev, dtype_name, L=4, T=3, H=64, W=85, rtol=2e-3):
+    """scripts/eval.py flow (window in, middle prediction kept, qexp, un-normalise, median/mean errors):
+    geomapnet_amd.evaluate on the HIP forward vs the oracle forward + the oracle's numpy metric"""
+    _fresh()
+    import numpy as np
+    import geomapnet_amd as G
+    from geomapnet_amd import evaluate as E
+    from oracle import pose_math
+    G.set_compute_dtype(dtype_name)
+    onet, net = build_pair(lib, dev)
+    x, t = oracle.make_batch("mapnet", L, H, W, seed=21)
+    pose_m, pose_s = np.array([0.5, -1.0, 2.0]), np.array([2.0, 3.0, 0.5])
+    batches = [(x[i:i + 1].to(dev), t[i:i + 1]) for i in range(L)]
+    summary, pred7, targ7 = E.evaluate(net, batches, pose_m, pose_s, cuda=(dev != "cpu"))
+    assert pred7.shape == (L, 7) and targ7.shape == (L, 7)
+    onet.eval()
+    want_t, want_q = [], []
+    with torch.no_grad():
+        for i in range(L):
+            o = onet(x[i:i + 1]).numpy().reshape(-1, 6)
+            g = t[i:i + 1].numpy().reshape(-1, 6)
+            mid = len(o) // 2
+            po = np.hstack((o[mid, :3] * pose_s + pose_m, pose_math.qexp_np(o[mid, 3:])))
+            pg = np.hstack((g[mid, :3] * pose_s + pose_m, pose_math.qexp_np(g[mid, 3:])))
+            want_t.append(np.linalg.norm(po[:3] - pg[:3]))
+            want_q.append(pose_math.quaternion_angular_error(po[3:], pg[3:]))
+    want = [np.median(want_t), np.mean(want_t), np.median(want_q), np.mean(want_q)]
+    got = [summary["median_t"], summary["mean_t"], summary["median_q"], summary["mean_q"]]
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol)
+    return summary

@@ -32,8 +32,41 @@ def crit_case(crit, pred, targ, names):
     return out
 
 
+def make_eval_metric(ns):
+    """evaluation metric of scripts/eval.py computed with the reference's numpy helpers
+    (common/pose_utils.py:319-327 qexp, :361-371 quaternion_angular_error; eval.py:80 t_criterion,
+    :166-175 qexp of predictions and targets, :184-186 un-normalisation, :192-205 statistics)"""
+    P = ns.pose_utils_np
+    rng = np.random.RandomState(20260925)
+    L = 257
+    targ = np.concatenate((rng.randn(L, 3), np.zeros((L, 3))), axis=1)
+    axis = rng.randn(L, 3)
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    targ[:, 3:] = axis * rng.uniform(0.05, 1.2, size=(L, 1))
+    pred = targ + np.concatenate((0.2 * rng.randn(L, 3), 0.05 * rng.randn(L, 3)), axis=1)
+    pred[0] = targ[0]                 # identical pose: zero error
+    pred[1, 3:] = 0.0                 # zero rotation vector: sinc(0) branch of qexp
+    pred[2, 3:] = -targ[2, 3:]        # opposite rotation
+    pose_m, pose_s = np.array([1.5, -0.3, 12.0]), np.array([3.0, 0.7, 20.0])
+    pred7 = np.hstack((pred[:, :3], np.asarray([P.qexp(p[3:]) for p in pred])))
+    targ7 = np.hstack((targ[:, :3], np.asarray([P.qexp(p[3:]) for p in targ])))
+    pred7[:, :3] = (pred7[:, :3] * pose_s) + pose_m
+    targ7[:, :3] = (targ7[:, :3] * pose_s) + pose_m
+    t_loss = np.asarray([np.linalg.norm(p - t) for p, t in zip(pred7[:, :3], targ7[:, :3])])
+    q_loss = np.asarray([P.quaternion_angular_error(p, t) for p, t in zip(pred7[:, 3:], targ7[:, 3:])])
+    lq = np.asarray([P.log_quaternion_angular_error(p[3:], t[3:]) for p, t in zip(pred, targ)])
+    np.savez_compressed(os.path.join(HERE, "eval_metric.npz"), pred=pred, targ=targ, pose_m=pose_m, pose_s=pose_s, pred7=pred7,
+                        targ7=targ7, t_loss=t_loss, q_loss=q_loss, logq_err=lq,
+                        stats=np.array([np.median(t_loss), np.mean(t_loss), np.median(q_loss), np.mean(q_loss)]))
+
+
 def main():
     ns = ref_loader.load()
+    if sys.argv[1:] == ["eval_metric"]:
+        make_eval_metric(ns)
+        print("wrote eval_metric.npz")
+        return
+    make_eval_metric(ns)
     C = ns.criterion
     gen = torch.Generator().manual_seed(1234)
     cases = {}

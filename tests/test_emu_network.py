@@ -22,6 +22,10 @@ def test_eval_forward_fp32(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=2, H=40, W=53)
 
 
+def test_eval_flow_and_metric_fp32(lib):
+    checks.check_eval_flow(lib, DEV, "fp32", L=2, T=3, H=40, W=53)
+
+
 @pytest.mark.slow
 def test_mapnet_online_train_step_fp32_parity_with_clip(lib):
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet++", N=1, H=40, W=53, steps=1, max_grad_norm=5.0, lr=1e-5, wd=0.0,

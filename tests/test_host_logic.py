@@ -84,3 +84,24 @@ def test_criterion_facade_surface():
     assert list(p.state_dict().keys()) == ["sax", "saq"]
     o = G.MapNetOnlineCriterion(gps_mode=True)
     assert o.mode == 3 and G.MapNetOnlineCriterion().mode == 2
+
+
+def test_evaluate_metric_matches_reference_golden(golden_dir):
+    """geomapnet_amd.evaluate (host side of scripts/eval.py) against vectors computed by the reference's own
+    numpy helpers: qexp, un-normalisation, L2 translation error, quaternion angular error, median / mean"""
+    import numpy as np
+    from geomapnet_amd import evaluate as E
+    g = np.load(os.path.join(golden_dir, "eval_metric.npz"))
+    pred7 = E.to_pose7(g["pred"], g["pose_m"], g["pose_s"])
+    targ7 = E.to_pose7(g["targ"], g["pose_m"], g["pose_s"])
+    np.testing.assert_allclose(pred7, g["pred7"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(targ7, g["targ7"], rtol=0, atol=1e-13)
+    t_loss, q_loss = E.pose_errors(pred7, targ7)
+    np.testing.assert_allclose(t_loss, g["t_loss"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(q_loss, g["q_loss"], rtol=0, atol=1e-10)
+    s = E.summarize(t_loss, q_loss)
+    np.testing.assert_allclose([s["median_t"], s["mean_t"], s["median_q"], s["mean_q"]], g["stats"], rtol=1e-12)
+    lq = [E.log_quaternion_angular_error(p[3:], t[3:]) for p, t in zip(g["pred"], g["targ"])]
+    np.testing.assert_allclose(lq, g["logq_err"], rtol=0, atol=1e-10)
+    assert t_loss[0] == 0.0 and q_loss[0] < 1e-5           # identical pose
+    assert 0.0 <= q_loss[2] <= 180.0                       # opposite rotation vector

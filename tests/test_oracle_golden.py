@@ -105,3 +105,12 @@ def test_eval_metric_identities():
         assert abs(pose_math.quaternion_angular_error(q1, q2) - abs(a - b) * 180 / np.pi) < 1e-6
     v = np.array([0.1, -0.4, 0.25])
     np.testing.assert_allclose(pose_math.qlog_np(pose_math.qexp_np(v)), v, atol=1e-12)
+
+
+def test_eval_metric_matches_reference_golden(golden_dir):
+    """oracle numpy helpers vs vectors produced by the reference's own qexp / quaternion_angular_error"""
+    g = np.load(os.path.join(golden_dir, "eval_metric.npz"))
+    q = np.asarray([pose_math.qexp_np(p[3:]) for p in g["pred"]])
+    np.testing.assert_allclose(q, g["pred7"][:, 3:], rtol=0, atol=1e-15)
+    err = [pose_math.quaternion_angular_error(a, b) for a, b in zip(g["pred7"][:, 3:], g["targ7"][:, 3:])]
+    np.testing.assert_allclose(err, g["q_loss"], rtol=0, atol=1e-12)

@@ -94,3 +94,15 @@ def test_filter_nans_hook_equivalence(ref):
         (m(x) * cot).sum().backward()
     for (k, p), q in zip(a.named_parameters(), b.parameters()):
         np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=1e-5, atol=1e-7, equal_nan=True, err_msg=k)
+
+
+def test_numpy_metric_helpers_are_the_reference_ones(ref):
+    """pose_utils.py:306-327,358-371 executed from the reference tree vs the oracle restatement"""
+    P = ref.pose_utils_np
+    rng = np.random.RandomState(3)
+    for _ in range(50):
+        v, w = rng.randn(3) * rng.uniform(0, 1.5), rng.randn(3) * rng.uniform(0, 1.5)
+        np.testing.assert_array_equal(P.qexp(v), pose_math.qexp_np(v))
+        assert P.quaternion_angular_error(P.qexp(v), P.qexp(w)) == pose_math.quaternion_angular_error(pose_math.qexp_np(v), pose_math.qexp_np(w))
+        np.testing.assert_allclose(P.qlog(P.qexp(v)), pose_math.qlog_np(pose_math.qexp_np(v)), rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(P.qexp(np.zeros(3)), pose_math.qexp_np(np.zeros(3)))

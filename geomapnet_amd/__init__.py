@@ -4,5 +4,5 @@ from .engine import set_compute_dtype, get_compute_dtype  # noqa: F401
 from .posenet import PoseNet, MapNet, resnet34  # noqa: F401
 from .criterion import PoseNetCriterion, MapNetCriterion, MapNetOnlineCriterion  # noqa: F401
 from .optimizer import Optimizer  # noqa: F401
-from .train import step_feedfwd  # noqa: F401
+from .train import step_feedfwd, load_state_dict, save_checkpoint, load_checkpoint  # noqa: F401
 from . import evaluate  # noqa: F401  (scripts/eval.py flow + error metric)

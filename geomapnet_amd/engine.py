@@ -90,6 +90,11 @@ class Engine:
         if self.lib.backend_name == "hip" and not self.params.is_cuda:
             raise MapNetHipError("the MapNet HIP path needs the model on a GPU (model.cuda()); there is no CPU fallback")
 
+    def ensure_opt_state(self):
+        if self.opt_state is None:
+            self.opt_state = torch.zeros(3 * self.n_params, dtype=torch.float32, device=self.device)
+        return self.opt_state
+
     def grads(self):
         return self.opt_state[: self.n_params]
 
@@ -104,8 +109,7 @@ class Engine:
         key = (mode, windows, T, H, W, dtype, scale)
         p = self.plans.get(key)
         if p is None:
-            if self.opt_state is None:
-                self.opt_state = torch.zeros(3 * self.n_params, dtype=torch.float32, device=self.device)
+            self.ensure_opt_state()
             cfg = Config(mode=mode, dtype=DTYPES[dtype], windows=windows, T=T, H=H, W=W, feat_dim=self.feat_dim,
                          filter_nans=int(self.filter_nans), loss_scale=scale, eps_mode=self.eps_mode)
             nbytes = int(self.lib.plan_bytes(C.byref(cfg)))

@@ -38,29 +38,70 @@ class FusedAdam:
         raise RuntimeError("FusedAdam.step() runs inside geomapnet_amd.train.step_feedfwd (one fused HIP call per "
                            "training step); call step_feedfwd(..., train=True)")
 
+    # -- torch.optim.Adam's state_dict format (checkpoints interchange with the reference's
+    #    `optimizer.learner.state_dict()`, common/train.py:202 / :170): per-parameter `exp_avg` / `exp_avg_sq`
+    #    in the parameter's own (OIHW) shape, indexed in param_groups order
+    def _moment_views(self, p):
+        eng = self._engine
+        n, off = eng.n_params, p.storage_offset()
+        if p.untyped_storage().data_ptr() != eng.params.untyped_storage().data_ptr():
+            raise RuntimeError("parameter is not a view of the engine's parameter arena")
+        return (eng.opt_state.as_strided(p.size(), p.stride(), n + off),
+                eng.opt_state.as_strided(p.size(), p.stride(), 2 * n + off))
+
     def state_dict(self):
-        sd = {"param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
-        if self._engine is not None and self._engine.opt_state is not None:
-            n = self._engine.n_params
-            sd["step"] = self._engine.step_count
-            sd["exp_avg"] = self._engine.opt_state[n:2 * n].clone()
-            sd["exp_avg_sq"] = self._engine.opt_state[2 * n:3 * n].clone()
-        return sd
+        state, groups, idx = {}, [], 0
+        eng = self._engine
+        have = eng is not None and eng.opt_state is not None and eng.step_count > 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                if have:
+                    m, v = self._moment_views(p)
+                    state[idx] = {"step": int(eng.step_count), "exp_avg": m.clone().contiguous(),
+                                  "exp_avg_sq": v.clone().contiguous()}
+                ids.append(idx)
+                idx += 1
+            packed = {k: v for k, v in g.items() if k != "params"}
+            packed["params"] = ids
+            groups.append(packed)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+        groups = sd.get("param_groups", [])
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for g, s in zip(self.param_groups, groups):
+            if len(s.get("params", g["params"])) != len(g["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of "
+                                 "optimizer's group")
             g.update({k: v for k, v in s.items() if k != "params"})
-        self._pending = {k: sd[k] for k in ("step", "exp_avg", "exp_avg_sq") if k in sd}
+        self._pending = dict(sd.get("state", {}))
+        if self._engine is not None:
+            self._apply_pending()
+
+    def _apply_pending(self):
+        pend = getattr(self, "_pending", None)
+        if not pend:
+            return
+        eng = self._engine
+        eng.ensure_opt_state()
+        step, idx = 0, 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = pend.get(idx, pend.get(str(idx)))
+                if st is not None:
+                    m, v = self._moment_views(p)
+                    m.copy_(st["exp_avg"].to(m.device).reshape(m.shape))
+                    v.copy_(st["exp_avg_sq"].to(v.device).reshape(v.shape))
+                    step = max(step, int(st["step"]))
+                idx += 1
+        eng.step_count = step
+        self._pending = None
 
     def _attach(self, engine):
         self._engine = engine
-        pend = getattr(self, "_pending", None)
-        if pend and engine.opt_state is not None:
-            n = engine.n_params
-            engine.opt_state[n:2 * n].copy_(pend["exp_avg"])
-            engine.opt_state[2 * n:3 * n].copy_(pend["exp_avg_sq"])
-            engine.step_count = int(pend["step"])
-            self._pending = None
+        self._apply_pending()
 
 
 class Optimizer:

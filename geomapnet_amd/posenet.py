@@ -78,6 +78,16 @@ class _ArenaModule(nn.Module):
         self._engine.params_touched()
         return r
 
+    def state_dict(self, *args, **kwargs):
+        """as nn.Module.state_dict; the int64 `num_batches_tracked` scalars are returned as copies because they
+        share the buffer arena with the fp32 running statistics and torch.save refuses one storage viewed as
+        two dtypes"""
+        sd = super().state_dict(*args, **kwargs)
+        for k, v in list(sd.items()):
+            if torch.is_tensor(v) and v.dtype == torch.int64:
+                sd[k] = v.clone()
+        return sd
+
 
 # ---- torchvision-style initialisation ----------------------------------------------------------
 def _kaiming_normal_(t, mode):

@@ -69,3 +69,57 @@ def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, tra
         loss, poses = engine.train_step(plan, data, target)
     output = poses.view(n, -1, 6) if mode != MODE_POSENET else poses
     return loss.item(), output
+
+
+# ---- checkpoints: /root/reference/common/train.py:22-53 (load_state_dict), :162-178 (resume), :198-204 (save) ----
+def load_state_dict(model, state_dict):
+    """Loads a state dict when the model (or the state dict) has some prefix before the parameter names, e.g. a
+    PoseNet checkpoint into MapNet (`mapnet.` prefix) or the reverse; the prefix is found from the first
+    parameter name (common/train.py:22-53)."""
+    model_names = [n for n, _ in model.named_parameters()]
+    state_names = [n for n in state_dict.keys()]
+    if model_names[0].find(state_names[0]) >= 0:
+        model_prefix = model_names[0].replace(state_names[0], "")
+        state_prefix = None
+    elif state_names[0].find(model_names[0]) >= 0:
+        state_prefix = state_names[0].replace(model_names[0], "")
+        model_prefix = None
+    else:
+        raise KeyError("Could not find the correct prefixes between %s and %s" % (model_names[0], state_names[0]))
+    from collections import OrderedDict
+    new_state_dict = OrderedDict()
+    for k, v in state_dict.items():
+        if state_prefix is None:
+            k = model_prefix + k
+        else:
+            k = k.replace(state_prefix, "")
+        new_state_dict[k] = v
+    model.load_state_dict(new_state_dict)
+
+
+def save_checkpoint(filename, epoch, model, optimizer, criterion):
+    """the reference's checkpoint dict (common/train.py:198-204); `filename` None returns the dict only"""
+    checkpoint_dict = {"epoch": epoch, "model_state_dict": model.state_dict(),
+                       "optim_state_dict": optimizer.learner.state_dict(),
+                       "criterion_state_dict": criterion.state_dict()}
+    if filename is not None:
+        torch.save(checkpoint_dict, filename)
+    return checkpoint_dict
+
+
+def load_checkpoint(checkpoint, model, optimizer=None, criterion=None, resume_optim=False):
+    """Trainer.__init__'s resume logic (common/train.py:162-178); `checkpoint` is a dict or a file name.
+    Returns the epoch to start from (0 unless resume_optim)."""
+    if not isinstance(checkpoint, dict):
+        checkpoint = torch.load(checkpoint, map_location=lambda storage, loc: storage, weights_only=False)
+    load_state_dict(model, checkpoint["model_state_dict"])
+    start_epoch = 0
+    if resume_optim:
+        optimizer.learner.load_state_dict(checkpoint["optim_state_dict"])
+        start_epoch = checkpoint["epoch"]
+        if "criterion_state_dict" in checkpoint:
+            c_state = dict(checkpoint["criterion_state_dict"])
+            append_dict = {k: torch.Tensor([0.0]) for k, _ in criterion.named_parameters() if k not in c_state}
+            c_state.update(append_dict)
+            criterion.load_state_dict(c_state)
+    return start_epoch

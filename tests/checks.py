@@ -468,3 +468,77 @@ def check_eval_flow(lib, dev, dtype_name, L=4, T=3, H=64, W=85, rtol=2e-3):
     got = [summary["median_t"], summary["mean_t"], summary["median_q"], summary["mean_q"]]
     np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol)
     return summary
+
+
+def check_checkpoint_interop(lib, dev, H=40, W=53):
+    """optimiser / criterion / model state in the reference's checkpoint format: torch.optim.Adam-shaped
+    state_dict (loadable by a real torch Adam over the oracle's parameters, moments equal to the oracle's),
+    save -> load -> resume reproduces the next step, prefix logic of common/train.py:22-53"""
+    _fresh()
+    import numpy as np
+    import geomapnet_amd as G
+    G.set_compute_dtype("fp32")
+
+    def make(seed=7):
+        onet, net = build_pair(lib, dev, seed=seed)
+        oc = oracle.MapNetCriterion(0.0, -3.0, 0.0, -3.0, True, True)
+        c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+        og = [{"params": onet.parameters()}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}]
+        gg = [{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}]
+        return (onet, oc, oracle.Optimizer(og, "adam", base_lr=1e-4, weight_decay=5e-4),
+                net, c, G.Optimizer(gg, "adam", base_lr=1e-4, weight_decay=5e-4))
+
+    onet, oc, oopt, net, c, opt = make()
+    assert opt.learner.state_dict()["state"] == {}  # as torch before the first step
+    x, t = oracle.make_batch("mapnet", 1, H, W, seed=7)
+    onet.train()
+    net.train()
+    oracle.step_feedfwd(x, onet, False, t, oc, oopt, True)
+    G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True)
+    sd = opt.learner.state_dict()
+    osd = oopt.learner.state_dict()
+    assert set(sd.keys()) == {"state", "param_groups"}
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in osd["param_groups"]]
+    assert sorted(sd["state"].keys()) == sorted(osd["state"].keys())
+    num = den = 0.0
+    for k, st in sd["state"].items():
+        assert int(st["step"]) == 1 and tuple(st["exp_avg"].shape) == tuple(osd["state"][k]["exp_avg"].shape)
+        assert st["exp_avg"].is_contiguous()
+        num += (st["exp_avg"].cpu().double() - osd["state"][k]["exp_avg"].double()).pow(2).sum().item()
+        den += osd["state"][k]["exp_avg"].double().pow(2).sum().item()
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+    # a real torch.optim.Adam accepts it
+    probe = torch.optim.Adam([{"params": list(onet.parameters())}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}],
+                             lr=1e-4, weight_decay=5e-4)
+    probe.load_state_dict({"state": {k: {a: (b.cpu() if torch.is_tensor(b) else b) for a, b in v.items()} for k, v in sd["state"].items()},
+                           "param_groups": sd["param_groups"]})
+    # and the oracle's (genuine torch) state loads into the fused optimiser bit-exactly
+    onet2, oc2, oopt2, net2, c2, opt2 = make(seed=8)
+    opt2.learner.load_state_dict(osd)
+    ckpt = G.save_checkpoint(None, 3, net, opt, c)
+    import io
+    buf = io.BytesIO()
+    torch.save(ckpt, buf)
+    buf.seek(0)
+    ckpt = torch.load(buf, map_location="cpu", weights_only=False)
+    assert G.load_checkpoint(ckpt, net2, opt2, c2, resume_optim=True) == 3
+    net2.train()
+    l1, p1 = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True)
+    l2, p2 = G.step_feedfwd(x.to(dev), net2, dev != "cpu", t.to(dev), c2, opt2, True)
+    assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l1)), (l1, l2)
+    assert (p1 - p2).abs().max().item() <= 1e-5
+    sd1, sd2 = opt.learner.state_dict(), opt2.learner.state_dict()
+    assert int(sd2["state"][0]["step"]) == 2
+    worst = max((sd1["state"][k]["exp_avg_sq"] - sd2["state"][k]["exp_avg_sq"]).abs().max().item() /
+                (sd1["state"][k]["exp_avg_sq"].abs().max().item() + 1e-30) for k in sd1["state"])
+    assert worst < 1e-3, worst
+    for k in ("sax", "saq", "srx", "srq"):
+        assert abs(float(getattr(c, k).detach()) - float(getattr(c2, k).detach())) < 1e-6
+    # prefix logic: PoseNet-named state into MapNet and back (common/train.py:22-53)
+    G.load_state_dict(net2, net.mapnet.state_dict())
+    G.load_state_dict(net2.mapnet, net.state_dict())
+    try:
+        G.load_state_dict(net2, {"unrelated.weight": torch.zeros(1)})
+        raise AssertionError("expected KeyError")
+    except KeyError:
+        pass

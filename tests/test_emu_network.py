@@ -22,6 +22,10 @@ def test_eval_forward_fp32(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=2, H=40, W=53)
 
 
+def test_checkpoint_interop_and_resume(lib):
+    checks.check_checkpoint_interop(lib, DEV)
+
+
 def test_eval_flow_and_metric_fp32(lib):
     checks.check_eval_flow(lib, DEV, "fp32", L=2, T=3, H=40, W=53)
 

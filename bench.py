@@ -131,7 +131,7 @@ def main():
     # so the conv MFMA launches are timed with HIP event pairs on the launch stream over a second run of the
     # SAME K steps issued eagerly; kernel durations do not depend on how the launch was issued.
     conv_ms, conv_launches, eager_ms = 0.0, 0, None
-    if use_events and rank == 0:
+    if use_events:  # every rank takes part: with world > 1 each step contains collectives
         eng.lib.check(eng.lib.set_profiling(plan["handle"], 1))
         torch.cuda.synchronize()
         t1 = time.perf_counter()

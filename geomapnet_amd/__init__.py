@@ -6,3 +6,4 @@ from .criterion import PoseNetCriterion, MapNetCriterion, MapNetOnlineCriterion 
 from .optimizer import Optimizer  # noqa: F401
 from .train import step_feedfwd, load_state_dict, save_checkpoint, load_checkpoint  # noqa: F401
 from . import evaluate  # noqa: F401  (scripts/eval.py flow + error metric)
+from . import data  # noqa: F401  (MF / MFOnline batch construction, VO targets, process_poses)

@@ -1,0 +1,184 @@
+"""Batch construction of the reference (host side): the step BEFORE the hot path.
+
+Mirrors /root/reference/dataset_loaders/composite.py:18-126 (`MF`: windows of `steps` frames `skip` apart,
+optionally with VOs appended; `MFOnline`: labelled window + unlabelled window with real VOs) and the pose
+helpers they use from /root/reference/common/pose_utils.py: `calc_vos_simple` (:234-246), `calc_vos_safe`
+(:219-232, :276-288 through the numpy `qexp`/`qlog` :306-327), `process_poses` (:329-356).  Everything here
+is CPU data preparation in the reference too (DataLoader workers); the image datasets themselves
+(7Scenes / RobotCar readers) are out of scope -- `MF` takes any indexable dataset of (image, pose6) pairs.
+"""
+import numpy as np
+import torch
+
+from .evaluate import qexp
+
+
+def qlog(q):
+    """logarithm map (4,) -> (3,)   (pose_utils.py:306-317)"""
+    q = np.asarray(q)
+    if all(q[1:] == 0):
+        return np.zeros(3)
+    return np.arccos(q[0]) * q[1:] / np.linalg.norm(q[1:])
+
+
+def _qmult(a, b):
+    """Hamilton product, normalised (pose_utils.py:44-62)"""
+    w = a[0] * b[0] - np.dot(a[1:], b[1:])
+    v = a[0] * b[1:] + b[0] * a[1:] + np.cross(a[1:], b[1:])
+    q = np.hstack((w, v))
+    return q / np.linalg.norm(q)
+
+
+def _rotate(t, q):
+    """t + 2 q_s (q_v x t) + 2 q_v x (q_v x t)   (pose_utils.py:120-132)"""
+    b = np.cross(q[1:], t)
+    return t + 2 * q[0] * b + 2 * np.cross(q[1:], b)
+
+
+def calc_vos_simple(poses):
+    """[N,T,6] -> [N,T-1,6]: differences of consecutive poses, all six components (pose_utils.py:234-246)"""
+    poses = torch.as_tensor(poses)
+    return poses[:, 1:] - poses[:, :-1]
+
+
+def calc_vos_safe(poses):
+    """[N,T,6] -> [N,T-1,6]: VO of consecutive poses in the first pose's frame, through the numpy qexp/qlog
+    (no gradient), fp32 as the reference (pose_utils.py:219-232, :276-288)"""
+    poses = torch.as_tensor(poses)
+    p = poses.detach().cpu().numpy().astype(np.float32)
+    out = np.zeros((p.shape[0], p.shape[1] - 1, 6), dtype=np.float32)
+    for n in range(p.shape[0]):
+        for i in range(p.shape[1] - 1):
+            q0 = np.asarray(qexp(p[n, i, 3:]), dtype=np.float32)
+            q1 = np.asarray(qexp(p[n, i + 1, 3:]), dtype=np.float32)
+            q0i = np.hstack((q0[:1], -q0[1:]))
+            out[n, i, :3] = _rotate(p[n, i + 1, :3] - p[n, i, :3], q0i)
+            out[n, i, 3:] = np.asarray(qlog(_qmult(q0i, q1).astype(np.float32)), dtype=np.float32)
+    return torch.from_numpy(out).to(poses.dtype)
+
+
+def mat2quat(R):
+    """rotation matrix -> unit quaternion (w, x, y, z), w >= 0 up to the caller's hemisphere fix (the
+    reference calls transforms3d.quaternions.mat2quat, pose_utils.py:346; same eigen-free closed form)"""
+    R = np.asarray(R, dtype=np.float64)
+    K = np.array([[R[0, 0] - R[1, 1] - R[2, 2], 0, 0, 0],
+                  [R[0, 1] + R[1, 0], R[1, 1] - R[0, 0] - R[2, 2], 0, 0],
+                  [R[0, 2] + R[2, 0], R[1, 2] + R[2, 1], R[2, 2] - R[0, 0] - R[1, 1], 0],
+                  [R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1], R[0, 0] + R[1, 1] + R[2, 2]]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)  # transforms3d's method: eigenvector of the largest eigenvalue
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    if q[0] < 0:
+        q = -q
+    return q
+
+
+def process_poses(poses_in, mean_t, std_t, align_R, align_t, align_s):
+    """raw 3x4 poses [N,12] -> aligned, normalised (translation, log-quaternion) [N,6]  (pose_utils.py:329-356)"""
+    poses_in = np.asarray(poses_in)
+    poses_out = np.zeros((len(poses_in), 6))
+    poses_out[:, 0:3] = poses_in[:, [3, 7, 11]]
+    for i in range(len(poses_out)):
+        R = poses_in[i].reshape((3, 4))[:3, :3]
+        q = mat2quat(np.dot(align_R, R))
+        q *= np.sign(q[0])  # constrain to hemisphere
+        poses_out[i, 3:] = qlog(q)
+        t = poses_out[i, :3] - align_t
+        poses_out[i, :3] = align_s * np.dot(align_R, t[:, np.newaxis]).squeeze()
+    poses_out[:, :3] -= mean_t
+    poses_out[:, :3] /= std_t
+    return poses_out
+
+
+class MF(torch.utils.data.Dataset):
+    """Returns multiple consecutive frames, and optionally VOs (composite.py:18-102).  `dataset` is any indexable
+    dataset returning (image [3,H,W], pose [6]); with include_vos and real, `gt_dataset` + `dataset.gt_idx` supply
+    the absolute poses as in the reference."""
+
+    def __init__(self, dataset, include_vos=False, no_duplicates=False, steps=2, skip=1, variable_skip=False, real=False,
+                 train=True, vo_func=calc_vos_simple, gt_dataset=None):
+        if isinstance(dataset, str):
+            raise NotImplementedError("the 7Scenes / RobotCar image readers are outside the MI355X hot path; pass a "
+                                      "dataset object")
+        self.steps, self.skip, self.variable_skip, self.real = steps, skip, variable_skip, real
+        self.include_vos, self.train, self.vo_func, self.no_duplicates = include_vos, train, vo_func, no_duplicates
+        self.dset, self.gt_dset = dataset, gt_dataset
+        self.L = self.steps * self.skip
+
+    def get_indices(self, index):
+        if self.variable_skip:
+            skips = np.random.randint(1, high=self.skip + 1, size=self.steps - 1)
+        else:
+            skips = self.skip * np.ones(self.steps - 1)
+        offsets = np.insert(skips, 0, 0).cumsum()
+        offsets -= offsets[len(offsets) // 2]  # Python-2 integer division in the reference (:66)
+        if self.no_duplicates:
+            offsets += self.steps // 2 * self.skip
+        offsets = offsets.astype(int)
+        idx = index + offsets
+        idx = np.minimum(np.maximum(idx, 0), len(self.dset) - 1)
+        assert np.all(idx >= 0), "{:d}".format(index)
+        assert np.all(idx < len(self.dset))
+        return idx
+
+    def __getitem__(self, index):
+        idx = self.get_indices(index)
+        clip = [self.dset[i] for i in idx]
+        imgs = torch.stack([c[0] for c in clip], dim=0)
+        poses = torch.stack([c[1] for c in clip], dim=0)
+        if self.include_vos:
+            vos = self.vo_func(poses.unsqueeze(0))[0]
+            if self.real:  # absolute poses need to come from the GT dataset
+                clip = [self.gt_dset[self.dset.gt_idx[i]] for i in idx]
+                poses = torch.stack([c[1] for c in clip], dim=0)
+            poses = torch.cat((poses, vos), dim=0)
+        return imgs, poses
+
+    def __len__(self):
+        L = len(self.dset)
+        if self.no_duplicates:
+            L -= (self.steps - 1) * self.skip
+        return L
+
+
+class MFOnline(torch.utils.data.Dataset):
+    """a labelled window with absolute poses + an unlabelled window with real VOs (composite.py:104-126):
+    images [2*steps,3,H,W], poses [steps + (steps-1), 6] (or [2*steps, 6] in gps_mode)"""
+
+    def __init__(self, train_dataset, val_dataset, gps_mode=False, val_gt_dataset=None, **kwargs):
+        self.gps_mode = gps_mode
+        self.train_set = MF(train_dataset, train=True, **kwargs)
+        self.val_set = MF(val_dataset, train=False, include_vos=(not gps_mode), real=True, vo_func=calc_vos_safe,
+                          no_duplicates=True, gt_dataset=val_gt_dataset, **kwargs)
+
+    def __getitem__(self, idx):
+        train_ims, train_poses = self.train_set[idx % len(self.train_set)]
+        val_ims, val_vos = self.val_set[idx % len(self.val_set)]  # val_vos contains abs poses if gps_mode
+        if not self.gps_mode:
+            val_vos = val_vos[len(val_ims):]
+        return torch.cat((train_ims, val_ims)), torch.cat((train_poses, val_vos))
+
+    def __len__(self):
+        return len(self.val_set)
+
+
+class SyntheticFrames(torch.utils.data.Dataset):
+    """stand-in for the image datasets: L frames of N(0,1) pixels (the post-Normalize distribution) on a smooth
+    random trajectory, poses as (translation, log-quaternion); `gt_idx` = identity, as a dataset whose `real`
+    poses index the ground truth one-to-one"""
+
+    def __init__(self, length, H=256, W=341, seed=7):
+        g = torch.Generator().manual_seed(seed)
+        self.images = None
+        self.shape, self.seed, self.length = (3, H, W), seed, length
+        t = torch.cumsum(0.05 * torch.randn(length, 3, generator=g), dim=0)
+        axis = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0)
+        ang = torch.cumsum(0.02 * torch.rand(length, generator=g), dim=0) + 0.05
+        self.poses = torch.cat((t, axis[None, :] * (ang[:, None] / 2)), dim=1)
+        self.gt_idx = np.arange(length)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + int(i))
+        return torch.randn(*self.shape, generator=g), self.poses[int(i)]

@@ -50,6 +50,23 @@ def load():
     import numpy as _np
     pose_utils_np.__dict__["np"] = _np
     exec(compile(np_src, "reference:common/pose_utils.py[306:327,358:371]", "exec"), pose_utils_np.__dict__)
+    # the *_safe torch helpers (:98-118, :219-232, :276-288) call the numpy qexp/qlog of the same file
+    pose_utils.__dict__["qexp"] = pose_utils_np.qexp
+    pose_utils.__dict__["qlog"] = pose_utils_np.qlog
+
+    # dataset_loaders/composite.py:60-75 `MF.get_indices`, the window-index rule; the module imports the image
+    # datasets (Python-2 only), so only this method's source is executed, with the two Python-2 integer
+    # divisions written as `//` and `np.int` (removed from numpy) as `int`
+    with open(os.path.join(REFERENCE_ROOT, "dataset_loaders", "composite.py")) as f:
+        comp = f.read().split("\n")
+    start = next(i for i, l in enumerate(comp) if l.strip().startswith("def get_indices"))
+    end = next(i for i in range(start + 1, len(comp)) if comp[i].strip().startswith("def "))
+    import textwrap
+    gi_src = textwrap.dedent("\n".join(comp[start:end]))
+    assert "len(offsets) / 2" in gi_src and "self.steps/2" in gi_src and "np.int)" in gi_src
+    gi_src = gi_src.replace("len(offsets) / 2", "len(offsets) // 2").replace("self.steps/2", "self.steps//2").replace("np.int)", "int)")
+    gi_ns = {"np": _np}
+    exec(compile(gi_src, "reference:dataset_loaders/composite.py[get_indices]", "exec"), gi_ns)
 
     saved = {k: sys.modules.get(k) for k in ("common", "common.pose_utils", "common.criterion")}
     pkg = types.ModuleType("common")
@@ -86,7 +103,7 @@ def load():
     class MapNetOnlineCriterionPy3(criterion.MapNetOnlineCriterion):
         forward = g["forward"]
 
-    ns = types.SimpleNamespace(pose_utils=pose_utils, pose_utils_np=pose_utils_np, criterion=criterion, posenet=posenet,
+    ns = types.SimpleNamespace(mf_get_indices=gi_ns["get_indices"], pose_utils=pose_utils, pose_utils_np=pose_utils_np, criterion=criterion, posenet=posenet,
                                MapNetOnlineCriterionPy3=MapNetOnlineCriterionPy3)
     _cache["ns"] = ns
     return ns

@@ -60,13 +60,40 @@ def make_eval_metric(ns):
                         stats=np.array([np.median(t_loss), np.mean(t_loss), np.median(q_loss), np.mean(q_loss)]))
 
 
+def make_batch_construction(ns):
+    """window indices of MF.get_indices (dataset_loaders/composite.py:60-75) and VO targets of calc_vos_safe /
+    calc_vos_simple (common/pose_utils.py:219-246,276-288), executed from the reference sources"""
+    import types
+    out = {}
+    cases = []
+    for steps, skip, nodup, L in ((3, 10, False, 100), (3, 10, True, 100), (2, 1, False, 7), (5, 3, True, 40), (4, 2, False, 9),
+                                  (3, 1, True, 3)):
+        self = types.SimpleNamespace(variable_skip=False, skip=skip, steps=steps, no_duplicates=nodup, dset=list(range(L)))
+        for index in sorted({0, 1, L // 2, L - 2, L - 1}):
+            if index < 0:
+                continue
+            cases.append([steps, skip, int(nodup), L, index] + list(ns.mf_get_indices(self, index)) + [-1] * (8 - steps))
+    out["get_indices"] = np.asarray(cases, dtype=np.int64)
+    gen = torch.Generator().manual_seed(4321)
+    poses = _poses(gen, 6, 4)
+    out["poses"] = poses.numpy()
+    out["vos_safe"] = ns.pose_utils.calc_vos_safe(poses).numpy()
+    out["vos_simple"] = ns.pose_utils.calc_vos_simple(poses).numpy()
+    np.savez_compressed(os.path.join(HERE, "batch_construction.npz"), **out)
+
+
 def main():
     ns = ref_loader.load()
     if sys.argv[1:] == ["eval_metric"]:
         make_eval_metric(ns)
         print("wrote eval_metric.npz")
         return
+    if sys.argv[1:] == ["batch_construction"]:
+        make_batch_construction(ns)
+        print("wrote batch_construction.npz")
+        return
     make_eval_metric(ns)
+    make_batch_construction(ns)
     C = ns.criterion
     gen = torch.Generator().manual_seed(1234)
     cases = {}

@@ -105,3 +105,51 @@ def test_evaluate_metric_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(lq, g["logq_err"], rtol=0, atol=1e-10)
     assert t_loss[0] == 0.0 and q_loss[0] < 1e-5           # identical pose
     assert 0.0 <= q_loss[2] <= 180.0                       # opposite rotation vector
+
+
+def test_batch_construction_matches_reference_golden(golden_dir):
+    """geomapnet_amd.data (MF window indices, VO targets) against vectors produced by the reference's own
+    MF.get_indices / calc_vos_safe / calc_vos_simple"""
+    import numpy as np
+    from geomapnet_amd import data as D
+    g = np.load(os.path.join(golden_dir, "batch_construction.npz"))
+    for row in g["get_indices"]:
+        steps, skip, nodup, L, index = [int(v) for v in row[:5]]
+        mf = D.MF(list(range(L)), steps=steps, skip=skip, no_duplicates=bool(nodup))
+        np.testing.assert_array_equal(mf.get_indices(index), row[5:5 + steps])
+        assert len(mf) == L - ((steps - 1) * skip if nodup else 0)
+    poses = torch.from_numpy(g["poses"])
+    np.testing.assert_allclose(D.calc_vos_safe(poses).numpy(), g["vos_safe"], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(D.calc_vos_simple(poses).numpy(), g["vos_simple"])
+
+
+def test_mf_and_mfonline_batches_feed_the_criteria_shapes():
+    """MF / MFOnline over a synthetic frame dataset produce the [N,T,...] batches step_feedfwd expects
+    (composite.py:76-126): MapNet [T,3,H,W] + [T,6]; MapNet++ [2T,3,H,W] + [T + (T-1), 6]; gps [2T,6]"""
+    import numpy as np
+    from geomapnet_amd import data as D
+    ds = D.SyntheticFrames(20, 8, 9)
+    mf = D.MF(ds, steps=3, skip=10, include_vos=False)
+    ims, poses = mf[10]
+    assert ims.shape == (3, 3, 8, 9) and poses.shape == (3, 6)
+    assert torch.equal(poses[1], ds.poses[10])                      # the middle frame is the indexed one
+    val = D.SyntheticFrames(30, 8, 9, seed=3)
+    on = D.MFOnline(ds, val, val_gt_dataset=val, steps=3, skip=2)
+    ims, poses = on[5]
+    assert ims.shape == (6, 3, 8, 9) and poses.shape == (5, 6) and len(on) == 30 - 2 * 2
+    idx = on.val_set.get_indices(5)
+    want = D.calc_vos_safe(val.poses[idx].unsqueeze(0))[0]
+    assert torch.equal(poses[3:], want)
+    gps = D.MFOnline(ds, val, gps_mode=True, steps=3, skip=2)
+    assert gps[5][1].shape == (6, 6)
+    # process_poses: identity alignment returns (t - mean)/std and the log-quaternion of R
+    q = np.array([0.9, 0.1, -0.3, 0.2]); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    raw = np.hstack((R, np.array([[1.0], [2.0], [3.0]]))).reshape(1, 12)
+    out = D.process_poses(raw, mean_t=np.array([0.5, 0.5, 0.5]), std_t=np.array([2.0, 2.0, 2.0]), align_R=np.eye(3),
+                          align_t=np.zeros(3), align_s=1.0)
+    np.testing.assert_allclose(out[0, :3], [0.25, 0.75, 1.25])
+    np.testing.assert_allclose(out[0, 3:], D.qlog(q), atol=1e-12)

@@ -106,3 +106,12 @@ def test_numpy_metric_helpers_are_the_reference_ones(ref):
         assert P.quaternion_angular_error(P.qexp(v), P.qexp(w)) == pose_math.quaternion_angular_error(pose_math.qexp_np(v), pose_math.qexp_np(w))
         np.testing.assert_allclose(P.qlog(P.qexp(v)), pose_math.qlog_np(pose_math.qexp_np(v)), rtol=0, atol=1e-15)
     np.testing.assert_array_equal(P.qexp(np.zeros(3)), pose_math.qexp_np(np.zeros(3)))
+
+
+def test_batch_construction_helpers_are_the_reference_ones(ref):
+    """calc_vos_safe executed from the reference (pose_utils.py:219-232,276-288 + numpy qexp/qlog) vs the oracle's
+    numpy restatement used to build MapNet++ targets"""
+    gen = torch.Generator().manual_seed(99)
+    poses = _poses(gen, 4, 3)
+    want = ref.pose_utils.calc_vos_safe(poses).numpy()
+    np.testing.assert_allclose(pose_math.calc_vos_safe_np(poses.numpy()), want, rtol=0, atol=2e-6)

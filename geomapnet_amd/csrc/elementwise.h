@@ -6,6 +6,7 @@
 // using the unbiased variance.
 #pragma once
 #include "common.h"
+#include "pool.h"
 
 namespace mn {
 
@@ -134,6 +135,94 @@ static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restric
   }
 }
 
+// Stem: BatchNorm (finalize as above) + ReLU + max-pool 3x3/2/1 in one pass: the normalised activation is
+// never written.  Values are rounded to T before the comparison so the routing (first maximum) is the one the
+// two-pass form (bn_apply then maxpool_fwd) takes.
+template <typename T>
+static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __restrict__ y, const double* __restrict__ accum,
+                                                               double count, BnParams p, int training, T* __restrict__ out,
+                                                               unsigned char* __restrict__ idx, int B, int H, int W, int C,
+                                                               int Po, int Qo) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  __shared__ float s_scale[512], s_shift[512];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mean, var;
+    double unbiased = 0;
+    if (training) {
+      double m = accum[c] / count;
+      double v = accum[C + c] / count - m * m;
+      if (v < 0) v = 0;
+      mean = (float)m;
+      var = (float)v;
+      unbiased = count > 1 ? v * count / (count - 1) : v;
+    } else {
+      mean = p.running_mean[c];
+      var = p.running_var[c];
+    }
+    const float invstd = 1.0f / sqrtf(var + p.eps);
+    const float sc = p.gamma[c] * invstd;
+    s_scale[c] = sc;
+    s_shift[c] = p.beta[c] - mean * sc;
+    if (blockIdx.x == 0) {
+      p.mean[c] = mean;
+      p.invstd[c] = invstd;
+      if (training) {
+        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+        p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+        if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
+      }
+    }
+  }
+  __syncthreads();
+  const int cpr = C / VEC;
+  const long total = (long)B * Po * Qo * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % cpr);
+    long tmp = i / cpr;
+    const int qo = (int)(tmp % Qo);
+    tmp /= Qo;
+    const int po = (int)(tmp % Po);
+    const int b = (int)(tmp / Po);
+    const int c0 = cp * VEC;
+    float best[VEC];
+    unsigned char arg[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      best[e] = -INFINITY;
+      arg[e] = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = po * 2 - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int w = qo * 2 - 1 + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        PieceView<T> v;
+        v.p = reinterpret_cast<const piece_t*>(y)[((long)(b * H + h) * W + w) * cpr + cp];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float f = fmaxf((float)v.e[e] * s_scale[c0 + e] + s_shift[c0 + e], 0.f);
+          f = (float)(T)f;
+          if (f > best[e]) {  // strict: the first maximum wins
+            best[e] = f;
+            arg[e] = (unsigned char)(r * 3 + s);
+          }
+        }
+      }
+    }
+    PieceView<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.e[e] = (T)best[e];
+    reinterpret_cast<piece_t*>(out)[i] = o.p;
+    if (idx) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) idx[i * VEC + e] = arg[e];
+    }
+  }
+}
+
 // ---- BatchNorm backward ---------------------------------------------------------------------------
 // reduce: accum[0][c] += sum gm, accum[1][c] += sum gm * xhat,  gm = g * (gate > 0 if gate)
 template <typename T>
@@ -143,7 +232,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
                                                              double* __restrict__ accum, int rows_per_block,
                                                              float* __restrict__ partial,
                                                              const float* __restrict__ sg_gamma,
-                                                             const float* __restrict__ sg_beta) {
+                                                             const float* __restrict__ sg_beta, PoolGradSrc pg) {
   // sg_gamma/sg_beta non-null ("self gate"): the consumer is this BatchNorm's own ReLU, so the gate
   // relu'(bn(y)) is recomputed from y (y*scale + shift > 0, the forward's arithmetic) instead of being read
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -172,7 +261,18 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
       const long rr = r + (long)u * rlanes;
       const bool in = rr < r1;
       const long idx = (in ? rr : r) * cpr + cp;
-      vg[u].p = in ? reinterpret_cast<const piece_t*>(g)[idx] : zero_piece();
+      if (pg.idx) {  // the gradient is the max-pool's input gradient, gathered on the fly
+        float a[VEC];
+        const long rrow = in ? rr : r;
+        const int w_ = (int)(rrow % pg.W);
+        const long t2 = rrow / pg.W;
+        pool_grad_piece<T>(pg.idx, reinterpret_cast<const T*>(pg.gout), (int)(t2 / pg.H), (int)(t2 % pg.H), w_, cp, cpr, pg.Po,
+                           pg.Qo, a);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) vg[u].e[e] = in ? (T)a[e] : (T)0.f;
+      } else {
+        vg[u].p = in ? reinterpret_cast<const piece_t*>(g)[idx] : zero_piece();
+      }
       vy[u].p = reinterpret_cast<const piece_t*>(y)[idx];
       if (gate) vm[u].p = reinterpret_cast<const piece_t*>(gate)[idx];
     }
@@ -221,7 +321,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
                                                             const double* __restrict__ accum, double count,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float grad_unscale, T* __restrict__ gy, long npieces, int C,
-                                                            const float* __restrict__ sg_beta) {
+                                                            const float* __restrict__ sg_beta, PoolGradSrc pg) {
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512], s_sh[512];
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -242,7 +342,18 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
     int c0 = (int)(i % cpr) * VEC;
     PieceView<T> vg, vy, vm, o;
-    vg.p = reinterpret_cast<const piece_t*>(g)[i];
+    if (pg.idx) {
+      float a[VEC];
+      const long row = i / cpr;
+      const int w_ = (int)(row % pg.W);
+      const long t2 = row / pg.W;
+      pool_grad_piece<T>(pg.idx, reinterpret_cast<const T*>(pg.gout), (int)(t2 / pg.H), (int)(t2 % pg.H), w_, (int)(i % cpr), cpr,
+                         pg.Po, pg.Qo, a);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vg.e[e] = (T)a[e];
+    } else {
+      vg.p = reinterpret_cast<const piece_t*>(g)[i];
+    }
     vy.p = reinterpret_cast<const piece_t*>(y)[i];
     if (gate) vm.p = reinterpret_cast<const piece_t*>(gate)[i];
 #pragma unroll
@@ -305,7 +416,8 @@ static __global__ void __launch_bounds__(256) bn_fwd_stats_kernel(const T* __res
 template <typename T>
 inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, const float* gamma, const float* mean,
                           const float* invstd, float* dgamma, float* dbeta, T* gy, double* accum, float grad_unscale,
-                          hipStream_t s, float* partial = nullptr, const float* self_gate_beta = nullptr) {
+                          hipStream_t s, float* partial = nullptr, const float* self_gate_beta = nullptr,
+                          PoolGradSrc pg = PoolGradSrc()) {
   // self_gate_beta: the gradient g is taken w.r.t. relu(bn(y)) of THIS BatchNorm; the ReLU gate is recomputed
   // from y and `gate` is not read
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -319,13 +431,13 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
-                     rows_per_block, partial, sg_gamma, self_gate_beta);
+                     rows_per_block, partial, sg_gamma, self_gate_beta, pg);
   if (partial)
     hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(nblk, 64), cdiv(C, 64)), dim3(256), 0, s,
                        (const float*)partial, nblk, C, accum, 64);
   long np = M * C / VEC;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd, gamma,
-                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C, self_gate_beta);
+                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C, self_gate_beta, pg);
 }
 
 // ---- global average pool --------------------------------------------------------------------------

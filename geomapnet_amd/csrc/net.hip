@@ -110,10 +110,22 @@ struct GraphSeg {
 
 struct PlanBase {
   virtual ~PlanBase() {
-    for (auto& g : segs)
-      if (g.exec) hipGraphExecDestroy(g.exec);
+    // ROCm 7.2 workaround: graph execs that contain a fork/join are NOT destroyed, and the side stream is
+    // process-wide and never destroyed.  Destroying such an exec leaves the runtime with dangling references to
+    // the forked capture stream: a LATER graph launch (of another plan) then crashes in
+    // hip::Graph::UpdateStreams (reproduced: two plans trained and freed, a third one captured and launched;
+    // leaking either the execs or the stream avoids it).  The leak is a few hundred graph nodes per plan.
     for (hipEvent_t e : fork_events) hipEventDestroy(e);
-    if (wstream) hipStreamDestroy(wstream);
+  }
+  static hipStream_t shared_side_stream() {
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
+      streams[dev] = nullptr;
+      (void)hipGetLastError();
+    }
+    return streams[dev];
   }
   // Weight-gradient launches do not feed the data-gradient chain, so they run on a second stream: their
   // workgroups fill the CUs the tail of each data-gradient launch leaves idle (layers 3-4 at B = 192 have
@@ -135,9 +147,8 @@ struct PlanBase {
   }
   hipStream_t fork_wgrad(hipStream_t s) {
     if (!overlap_wgrad || s == nullptr || timer.enabled) return s;
-    if (!wstream && hipStreamCreateWithFlags(&wstream, hipStreamNonBlocking) != hipSuccess) {
+    if (!wstream && !(wstream = shared_side_stream())) {
       overlap_wgrad = false;
-      (void)hipGetLastError();
       return s;
     }
     hipEvent_t e = next_fork_event();
@@ -182,8 +193,7 @@ struct PlanBase {
       (void)hipGetLastError();
       return rc != 0 ? rc : body();
     }
-    if (gs.exec) hipGraphExecDestroy(gs.exec);
-    gs.exec = nullptr;
+    gs.exec = nullptr;  // a superseded exec is leaked, see ~PlanBase
     e = hipGraphInstantiate(&gs.exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
     if (e != hipSuccess) {
@@ -551,9 +561,15 @@ struct Plan : PlanBase {
     hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s, images, xpad, B,
                        H, W, Hp, Wp);
     conv_bn_stats(stem, xpad, training, s);
-    bn_act(stem, nullptr, 1, a0, s);
-    hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
-                       (const T*)a0, p0, pool_idx, B, H0, W0, 64, H1, W1);
+    if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
+      hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
+                         (const T*)stem.y, (const double*)stem.accum_f, (double)stem.M, bn_params(stem), cur_training, p0,
+                         pool_idx, B, H0, W0, 64, H1, W1);
+    } else {
+      bn_act(stem, nullptr, 1, a0, s);
+      hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
+                         (const T*)a0, p0, pool_idx, B, H0, W0, 64, H1, W1);
+    }
     for (auto& blk : blocks) {
       if (blk.stage >= 1) join_wgrad(s);  // no-op once joined
       conv_bn_stats(blk.u1, blk.x, training, s);
@@ -612,6 +628,7 @@ struct Plan : PlanBase {
                      grads + u.bp.beta, u.gy, u.accum_b, 1.f / cfg.loss_scale, s, bwd_partial,
                      (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr);
   }
+  bool fuse_stem = !(getenv("MN_FUSE_STEM") && atoi(getenv("MN_FUSE_STEM")) == 0);
   bool self_gate_ok = !(getenv("MN_SELF_GATE") && atoi(getenv("MN_SELF_GATE")) == 0);
   void conv_wgrad(Unit& u, const T* x, hipStream_t s) {
     WgradArgs a;
@@ -681,9 +698,19 @@ struct Plan : PlanBase {
                        (const float*)dpooled, last.gout, B, Hl * Wl, 512);
   }
   void stem_backward(hipStream_t s) {
-    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s,
-                       (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
-    bn_bwd(stem, ga0, a0, s, true);
+    if (fuse_stem) {
+      // the max-pool's input gradient is gathered from (argmax, pooled gradient) inside the BatchNorm backward
+      // passes and the ReLU gate is recomputed from y: neither the activation nor its gradient exists in memory
+      PoolGradSrc pg;
+      pg.idx = pool_idx; pg.gout = gp0; pg.H = H0; pg.W = W0; pg.Po = H1; pg.Qo = W1;
+      launch_bn_bwd<T>((const T*)nullptr, (const T*)nullptr, (const T*)stem.y, stem.M, 64, params + stem.bp.gamma, stem.mean,
+                       stem.invstd, grads + stem.bp.gamma, grads + stem.bp.beta, stem.gy, stem.accum_b,
+                       1.f / cfg.loss_scale, s, bwd_partial, params + stem.bp.beta, pg);
+    } else {
+      hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s,
+                         (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
+      bn_bwd(stem, ga0, a0, s, true);
+    }
     conv_wgrad(stem, xpad, s);  // the input gradient of the stem is not needed (nothing consumes it)
   }
   int backward_stage(int stage, hipStream_t s) override {

@@ -105,4 +105,45 @@ static __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const unsigned 
   }
 }
 
+// Gradient of one input position of the max-pool, gathered on the fly: sum of the output gradients of the (at
+// most four) windows whose recorded argmax is this position; rounded to T like the stored gradient would be.
+template <typename T>
+__device__ __forceinline__ void pool_grad_piece(const unsigned char* __restrict__ idx, const T* __restrict__ gout, int b,
+                                                int h, int w, int cp, int cpr, int Po, int Qo,
+                                                float (&acc)[ElemTraits<T>::VEC]) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int po = h / 2; po <= (h + 1) / 2 && po < Po; ++po)
+    for (int qo = w / 2; qo <= (w + 1) / 2 && qo < Qo; ++qo) {
+      const unsigned char mytap = (unsigned char)((h - (po * 2 - 1)) * 3 + (w - (qo * 2 - 1)));
+      const long o = ((long)(b * Po + po) * Qo + qo) * cpr + cp;
+      unsigned char a[VEC];
+      if (VEC == 8) {
+        unsigned long long packed = reinterpret_cast<const unsigned long long*>(idx)[o];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = (unsigned char)(packed >> (8 * e));
+      } else {
+        unsigned packed = reinterpret_cast<const unsigned*>(idx)[o];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = (unsigned char)(packed >> (8 * e));
+      }
+      PieceView<T> gv;
+      gv.p = reinterpret_cast<const piece_t*>(gout)[o];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (a[e] == mytap) acc[e] += (float)gv.e[e];
+    }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = (float)(T)acc[e];
+}
+
+// Source of the incoming gradient of a BatchNorm backward pass when it is the max-pool's input gradient:
+// (argmax bytes, pooled gradient) instead of a materialised tensor
+struct PoolGradSrc {
+  const unsigned char* idx = nullptr;  // null: read the gradient tensor
+  const void* gout = nullptr;
+  int H = 0, W = 0, Po = 0, Qo = 0;
+};
+
 }  // namespace mn

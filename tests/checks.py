@@ -473,7 +473,7 @@ def check_eval_flow(lib, dev, dtype_name, L=4, T=3, H=64, W=85, rtol=2e-3, check
     return summary
 
 
-def check_checkpoint_interop(lib, dev, H=40, W=53):
+def check_checkpoint_interop(lib, dev, H=40, W=53, resume_step=True):
     """optimiser / criterion / model state in the reference's checkpoint format: torch.optim.Adam-shaped
     state_dict (loadable by a real torch Adam over the oracle's parameters, moments equal to the oracle's),
     save -> load -> resume reproduces the next step, prefix logic of common/train.py:22-53"""
@@ -526,6 +526,21 @@ def check_checkpoint_interop(lib, dev, H=40, W=53):
     ckpt = torch.load(buf, map_location="cpu", weights_only=False)
     assert G.load_checkpoint(ckpt, net2, opt2, c2, resume_optim=True) == 3
     net2.train()
+    if not resume_step:  # (emulator runs) state equality after the load instead of one more step on both replicas
+        from geomapnet_amd.train import _bind
+        _bind(net2.mapnet._engine, c2, opt2)
+        sd2 = opt2.learner.state_dict()
+        for k, st in sd["state"].items():
+            assert int(sd2["state"][k]["step"]) == 1
+            assert torch.equal(sd2["state"][k]["exp_avg"].cpu(), st["exp_avg"].cpu())
+            assert torch.equal(sd2["state"][k]["exp_avg_sq"].cpu(), st["exp_avg_sq"].cpu())
+        for (k1, v1), (k2, v2) in zip(net.state_dict().items(), net2.state_dict().items()):
+            assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu()), k1
+        for k in ("sax", "saq", "srx", "srq"):
+            assert float(getattr(c, k).detach()) == float(getattr(c2, k).detach())
+        G.load_state_dict(net2, net.mapnet.state_dict())
+        G.load_state_dict(net2.mapnet, net.state_dict())
+        return
     l1, p1 = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True)
     l2, p2 = G.step_feedfwd(x.to(dev), net2, dev != "cpu", t.to(dev), c2, opt2, True)
     assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l1)), (l1, l2)

@@ -630,11 +630,11 @@ struct Plan : PlanBase {
   }
   bool fuse_stem = !(getenv("MN_FUSE_STEM") && atoi(getenv("MN_FUSE_STEM")) == 0);
   bool self_gate_ok = !(getenv("MN_SELF_GATE") && atoi(getenv("MN_SELF_GATE")) == 0);
-  void conv_wgrad(Unit& u, const T* x, hipStream_t s) {
+  // `ws`: the stream the launch goes to (the side stream after a fork, or the main stream)
+  void conv_wgrad(Unit& u, const T* x, hipStream_t ws) {
     WgradArgs a;
     a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
     a.alpha = 1.f / cfg.loss_scale; a.rows_per_split = 0;
-    hipStream_t ws = fork_wgrad(s);
     auto* tp = timer.begin(1, ws);
     // reduction splits (measured, tools/conv_bench.py): one round of 2 workgroups per CU for the wide layers (half
     // the atomic traffic of 1024), more for layer1 and the stem whose pixel dimension is 4-16x longer
@@ -653,13 +653,16 @@ struct Plan : PlanBase {
   void block_backward(Block& blk, hipStream_t s) {
     // gm = gout * (out > 0) feeds bn2 (and bn_d); see DESIGN.md section 4
     bn_bwd(blk.u2, blk.gout, blk.out, s);
-    conv_wgrad(blk.u2, blk.a1, s);
     conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
     bn_bwd(blk.u1, blk.ga1, blk.a1, s, true);
-    conv_wgrad(blk.u1, blk.x, s);
+    if (blk.down) bn_bwd(blk.ud, blk.gout, blk.out, s);
+    // ONE fork per block (forking per launch measured the same): all its weight gradients go to the side stream
+    // while the main stream finishes the block's data gradient and runs the next block's chain
+    hipStream_t ws = fork_wgrad(s);
+    conv_wgrad(blk.u2, blk.a1, ws);
+    conv_wgrad(blk.u1, blk.x, ws);
     if (blk.down) {
-      bn_bwd(blk.ud, blk.gout, blk.out, s);
-      conv_wgrad(blk.ud, blk.x, s);
+      conv_wgrad(blk.ud, blk.x, ws);
       conv_dgrad(blk.u1, blk.gx, nullptr, nullptr, s);
       conv_dgrad(blk.ud, blk.gx, blk.gx, nullptr, s);  // accumulate the projection path in place
     } else {
@@ -711,7 +714,8 @@ struct Plan : PlanBase {
                          (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
       bn_bwd(stem, ga0, a0, s, true);
     }
-    conv_wgrad(stem, xpad, s);  // the input gradient of the stem is not needed (nothing consumes it)
+    // the input gradient of the stem is not needed (nothing consumes it); last launch of the step: main stream
+    conv_wgrad(stem, xpad, s);
   }
   int backward_stage(int stage, hipStream_t s) override {
     if (stage < 0 || stage > 3) return fail("backward_stage: stage must be 0..3");

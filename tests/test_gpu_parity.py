@@ -89,6 +89,14 @@ def test_mapnet_train_step_fp32_parity_small(lib):
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
 
 
+@pytest.mark.parametrize("mask", ["0", "3"])
+def test_mapnet_train_step_fp32_parity_stem_variants(lib, monkeypatch, mask):
+    """MN_FUSE_STEM: 0 = separate BatchNorm / max-pool passes, 3 = fused forward AND max-pool gradient gathered inside
+    the BatchNorm backward (the default, 1, is what every other test runs)"""
+    monkeypatch.setenv("MN_FUSE_STEM", mask)
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=1, loss_rtol=1e-4, pose_atol=2e-3)
+
+
 def test_mapnet_train_step_fp32_parity_full_resolution(lib):
     """(N=2, T=3, 3, 256, 341): north-star tolerances 1e-4 on loss (relative, |loss| > 1) and 1e-3 on pose"""
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3)

@@ -395,7 +395,7 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int n = n0 + wm * (BMO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.N && dst >= 0 && a.alpha != 0.f) unsafeAtomicAdd(a.dW + (long)n * a.ldw + dst, acc[i][j][r] * a.alpha);
+        if (n < g.N && dst >= 0) unsafeAtomicAdd(a.dW + (long)n * a.ldw + dst, acc[i][j][r] * a.alpha);
       }
     }
 }
@@ -466,7 +466,6 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
   a.rows_per_split = rows;
   dim3 grid(cdiv(g.N, bmo), cdiv(g.K, bno), splits), block(256);
   static const bool use_dma = !(getenv("MN_WGRAD_DMA") && atoi(getenv("MN_WGRAD_DMA")) == 0);
-  if (getenv("MN_WGRAD_NOSTORE")) a.alpha = 0.f;  // experiment: measure the cost of the atomic epilogue
   if (use_dma && WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) return;
   if (bmo == 64 && bno == 64)
     hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, block, 0, stream, a);

@@ -43,6 +43,38 @@ static __global__ void __launch_bounds__(256) nchw_to_padded_nhwc4_kernel(const 
   }
 }
 
+// ---- input: uint8 NHWC (decoded image bytes) -> normalised, zero-padded NHWC4 ---------------------------
+// torchvision's ToTensor + Normalize on the device: x = u8 / 255, (x - mean[c]) / std[c], as one
+// multiply-add per element (scale = 1/(255 std), shift = -mean/std).  Reads 3 B/pixel instead of 12.
+struct InputNorm {
+  float scale[3], shift[3];
+};
+template <typename T>
+static __global__ void __launch_bounds__(256) u8nhwc_to_padded_nhwc4_kernel(const unsigned char* __restrict__ in,
+                                                                      T* __restrict__ out, int B, int H, int W, int Hp,
+                                                                      int Wp, InputNorm nm) {
+  long total = (long)B * Hp * Wp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int wp = (int)(i % Wp);
+    long tmp = i / Wp;
+    int hp = (int)(tmp % Hp);
+    int b = (int)(tmp / Hp);
+    int h = hp - 3, w = wp - 3;
+    T v[4] = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+      const unsigned char* p = in + (((long)b * H + h) * W + w) * 3;
+      v[0] = (T)((float)p[0] * nm.scale[0] + nm.shift[0]);
+      v[1] = (T)((float)p[1] * nm.scale[1] + nm.shift[1]);
+      v[2] = (T)((float)p[2] * nm.scale[2] + nm.shift[2]);
+    }
+    T* o = out + i * 4;
+    o[0] = v[0];
+    o[1] = v[1];
+    o[2] = v[2];
+    o[3] = v[3];
+  }
+}
+
 // ---- BatchNorm statistics -------------------------------------------------------------------------
 // stage 1: fold the conv epilogue's per-block partials [GM][2][N] into fp64 accumulators [2][N]
 static __global__ void __launch_bounds__(256) bn_reduce_partials_kernel(const float* __restrict__ partial, int GM, int N,

@@ -209,9 +209,11 @@ struct PlanBase {
   }
   virtual void after_optim_host() = 0;
   virtual int sync_step_to_device(hipStream_t s) = 0;
-  virtual int forward(const float* images, float* poses_out, int training, hipStream_t s) = 0;
+  virtual int forward(const void* images, float* poses_out, int training, hipStream_t s) = 0;
+  bool input_u8 = false;  // images are uint8 NHWC, normalised on the device (mn_set_input_u8)
+  InputNorm input_norm{{1.f, 1.f, 1.f}, {0.f, 0.f, 0.f}};
   virtual int loss_only(const float* pred, const float* targ, float* loss_out, hipStream_t s) = 0;
-  virtual int forward_loss(const float* images, const float* targets, float* loss_out, float* poses_out,
+  virtual int forward_loss(const void* images, const float* targets, float* loss_out, float* poses_out,
                            hipStream_t s) = 0;
   virtual int backward_stage(int stage, hipStream_t s) = 0;
   virtual int optim_step(float grad_mul, hipStream_t s) = 0;
@@ -544,10 +546,10 @@ struct Plan : PlanBase {
                        (double)u.M, bn_params(u), cur_training, res, out, np, u.cp.cout, relu);
   }
 
-  int forward(const float* images, float* poses_out, int training, hipStream_t s) override {
+  int forward(const void* images, float* poses_out, int training, hipStream_t s) override {
     return forward_impl(images, poses_out, training, false, s);
   }
-  int forward_impl(const float* images, float* poses_out, int training, bool zero_grads, hipStream_t s) {
+  int forward_impl(const void* images, float* poses_out, int training, bool zero_grads, hipStream_t s) {
     // work the stem and layer1 do not depend on goes to the side stream: the repack of the later layers'
     // weights and optim.learner.zero_grad(); joined before layer2
     if (weights_dirty || zero_grads) {
@@ -558,8 +560,12 @@ struct Plan : PlanBase {
     grads_zeroed = zero_grads;
     cur_training = training;
     if (training) hipMemsetAsync(acc_region, 0, acc_bytes, s);  // forward statistics + backward reduction sums
-    hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s, images, xpad, B,
-                       H, W, Hp, Wp);
+    if (input_u8)
+      hipLaunchKernelGGL((u8nhwc_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
+                         (const unsigned char*)images, xpad, B, H, W, Hp, Wp, input_norm);
+    else
+      hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
+                         (const float*)images, xpad, B, H, W, Hp, Wp);
     conv_bn_stats(stem, xpad, training, s);
     if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
       hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
@@ -614,7 +620,7 @@ struct Plan : PlanBase {
     run_criterion(pred, targ, loss_out, nullptr, nullptr, s);
     return check_launch("loss");
   }
-  int forward_loss(const float* images, const float* targets, float* loss_out, float* poses_out, hipStream_t s) override {
+  int forward_loss(const void* images, const float* targets, float* loss_out, float* poses_out, hipStream_t s) override {
     if (int e = forward_impl(images, poses_out, 1, true, s)) return e;
     cur_targets = targets;
     cur_loss = loss_out ? loss_out : loss_dev;
@@ -858,7 +864,21 @@ extern "C" int mn_set_step_count(mn_handle* h, int64_t step) {
   return 0;
 }
 extern "C" int64_t mn_get_step_count(mn_handle* h) { return (h && h->plan) ? h->plan->step : -1; }
-extern "C" int mn_forward(mn_handle* h, const float* images, float* poses_out, int training, void* stream) {
+extern "C" int mn_set_input_u8(mn_handle* h, int enable, const float* mean, const float* std) {
+  MN_H(h);
+  if (enable && (!mean || !std)) return fail("mn_set_input_u8: mean and std (3 floats each, host memory) are required");
+  if (enable)
+    for (int c = 0; c < 3; ++c) {
+      if (!(std[c] > 0.f)) return fail("mn_set_input_u8: std must be positive");
+      P.input_norm.scale[c] = 1.f / (255.f * std[c]);
+      P.input_norm.shift[c] = -mean[c] / std[c];
+    }
+  if (P.input_u8 != (enable != 0)) P.hyper_version++;  // captured graphs bake the conversion kernel in
+  P.hyper_version += enable ? 1 : 0;                     // ... and its constants
+  P.input_u8 = enable != 0;
+  return 0;
+}
+extern "C" int mn_forward(mn_handle* h, const void* images, float* poses_out, int training, void* stream) {
   MN_H(h);
   return P.forward(images, poses_out, training, (hipStream_t)stream);
 }
@@ -866,7 +886,7 @@ extern "C" int mn_loss(mn_handle* h, const float* pred, const float* targ, float
   MN_H(h);
   return P.loss_only(pred, targ, loss_out, (hipStream_t)stream);
 }
-extern "C" int mn_train_forward_loss(mn_handle* h, const float* images, const float* targets, float* loss_out,
+extern "C" int mn_train_forward_loss(mn_handle* h, const void* images, const float* targets, float* loss_out,
                                      float* poses_out, void* stream) {
   MN_H(h);
   P.timer.reset();
@@ -899,7 +919,7 @@ extern "C" int mn_optim_step(mn_handle* h, float grad_mul, void* stream) {
   if (rc == 0) P.after_optim_host();
   return rc;
 }
-extern "C" int mn_train_step(mn_handle* h, const float* images, const float* targets, float* loss_out, float* poses_out,
+extern "C" int mn_train_step(mn_handle* h, const void* images, const float* targets, float* loss_out, float* poses_out,
                              void* stream) {
   MN_H(h);
   hipStream_t s = (hipStream_t)stream;

@@ -58,6 +58,7 @@ class Engine:
         self.dtype = None  # None -> module default at plan creation
         self.loss_scale = None
         self.eps_mode = 0
+        self.input_u8 = None  # (mean[3], std[3]) when images arrive as uint8 NHWC and are normalised on the device
 
     # -- arenas ---------------------------------------------------------------------------------
     @property
@@ -127,6 +128,13 @@ class Engine:
         if p["version"] != self.version:
             self.lib.check(self.lib.params_changed(p["handle"]))
             p["version"] = self.version
+        if p.get("input_u8") != self.input_u8:
+            if self.input_u8 is None:
+                self.lib.check(self.lib.set_input_u8(p["handle"], 0, None, None))
+            else:
+                mean, std = ((C.c_float * 3)(*[float(v) for v in vals]) for vals in self.input_u8)
+                self.lib.check(self.lib.set_input_u8(p["handle"], 1, mean, std))
+            p["input_u8"] = self.input_u8
         self.lib.check(self.lib.set_step_count(p["handle"], self.step_count))
         return p
 
@@ -134,9 +142,24 @@ class Engine:
         self.version += 1
 
     # -- calls --------------------------------------------------------------------------------------
+    def set_input_u8(self, mean=None, std=None):
+        """images become uint8 [.., H, W, 3]; (x/255 - mean)/std runs on the device.  mean=None: back to fp32 NCHW."""
+        self.input_u8 = None if mean is None else (tuple(float(v) for v in mean), tuple(float(v) for v in std))
+
+    def image_dims(self, images):
+        """-> (H, W) of one frame, for either input format; validates the dtype against the configured format"""
+        if self.input_u8 is not None:
+            if images.dtype != torch.uint8 or images.shape[-1] != 3:
+                raise MapNetHipError("uint8 input mode expects uint8 images [..., H, W, 3]")
+            return int(images.shape[-3]), int(images.shape[-2])
+        if images.dtype != torch.float32:
+            raise MapNetHipError("expected fp32 images [..., 3, H, W] (or call set_input_u8 for uint8 NHWC input)")
+        return int(images.shape[-2]), int(images.shape[-1])
+
     def forward(self, images, training):
-        """images: fp32 [B,3,H,W] contiguous on the engine's device -> poses [B,6]."""
-        B, _, H, W = images.shape
+        """images: fp32 [B,3,H,W] (or uint8 [B,H,W,3]) contiguous on the engine's device -> poses [B,6]."""
+        B = images.shape[0]
+        H, W = self.image_dims(images)
         p = self.plan(MODE_POSENET, B, 1, H, W)
         out = torch.empty(B, 6, dtype=torch.float32, device=self.device)
         self.lib.check(self.lib.forward(p["handle"], ptr(images), ptr(out), int(bool(training)), _stream(images)))

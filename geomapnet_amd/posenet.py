@@ -197,13 +197,19 @@ class PoseNet(_ArenaModule):
                     b.data.zero_()
         eng.params_touched()
 
+    def set_input_u8(self, mean=None, std=None):
+        """Device-side ToTensor + Normalize: inputs become uint8 [N,H,W,3] (PoseNet) / [N,T,H,W,3] (MapNet) and
+        (x/255 - mean)/std is applied by the conversion kernel.  `mean=None` restores fp32 [N,3,H,W] input."""
+        self._engine.set_input_u8(mean, std)
+
     def forward(self, x):
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise ValueError("PoseNet.forward expects [N,3,H,W]")
+        u8 = self._engine.input_u8 is not None
+        if x.dim() != 4 or (x.shape[-1] if u8 else x.shape[1]) != 3:
+            raise ValueError("PoseNet.forward expects [N,3,H,W] (or uint8 [N,H,W,3] after set_input_u8)")
         x = x.detach()
         if x.device != self._engine.device:
             raise RuntimeError("input on %s but model on %s" % (x.device, self._engine.device))
-        x = x.float().contiguous()
+        x = x.contiguous() if u8 else x.float().contiguous()
         # dropout: identity, as under the reference's pinned PyTorch 0.4.1 (F.dropout default
         # training=False at models/posenet.py:68-69; SURVEY.md section 5)
         return self._engine.forward(x, self.training)
@@ -218,6 +224,9 @@ class MapNet(nn.Module):
         s = x.size()
         poses = self.mapnet(x.reshape(-1, *s[2:]))
         return poses.view(s[0], s[1], -1)
+
+    def set_input_u8(self, mean=None, std=None):
+        self.mapnet.set_input_u8(mean, std)
 
     def load_state_dict(self, state_dict, strict=True):
         r = super().load_state_dict(state_dict, strict)

@@ -47,7 +47,7 @@ def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, tra
     if not model.training:
         raise RuntimeError("step_feedfwd(train=True) on a model in eval mode")
     target = target.to(dev, non_blocking=True).float().contiguous()
-    data = data.float().contiguous()
+    data = data.contiguous() if engine.input_u8 is not None else data.float().contiguous()
     mode = criterion.mode
     if mode == MODE_POSENET:
         if data.dim() != 4:
@@ -58,7 +58,7 @@ def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, tra
             raise ValueError("MapNet training expects a MapNet model and data [N,T,3,H,W]")
         n = data.shape[0]
         t = data.shape[1] if mode == 1 else data.shape[1] // 2
-    H, W = data.shape[-2], data.shape[-1]
+    H, W = engine.image_dims(data)
     _bind(engine, criterion, optim)
     plan = engine.plan(mode, n, t, H, W)
     lr, wd, betas, eps = optim.learner.hyper()

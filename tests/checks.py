@@ -560,3 +560,43 @@ def check_checkpoint_interop(lib, dev, H=40, W=53, resume_step=True):
         raise AssertionError("expected KeyError")
     except KeyError:
         pass
+
+
+def check_u8_input(lib, dev, N=1, H=40, W=53):
+    """device-side ToTensor + Normalize: uint8 NHWC input vs the same images normalised on the host (fp32 NCHW),
+    forward and one training step against the oracle"""
+    _fresh()
+    import geomapnet_amd as G
+    G.set_compute_dtype("fp32")
+    onet, net = build_pair(lib, dev)
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (N, 3, H, W, 3), generator=g, dtype=torch.uint8)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    x = ((u8.float() / 255.0 - torch.tensor(mean)) / torch.tensor(std)).permute(0, 1, 4, 2, 3).contiguous()
+    _, t = oracle.make_batch("mapnet", N, 8, 8, seed=7)
+    net.eval()
+    onet.eval()
+    with torch.no_grad():
+        ref = onet(x)
+    net.set_input_u8(mean, std)
+    got = net(u8.to(dev)).cpu()
+    assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+    try:
+        net(x.to(dev))
+        raise AssertionError("fp32 input must be rejected in uint8 mode")
+    except (ValueError, G._binding.MapNetHipError):
+        pass
+    oc = oracle.MapNetCriterion(0.0, -3.0, 0.0, -3.0, True, True)
+    c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+    oopt = oracle.Optimizer([{"params": onet.parameters()}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}], "adam",
+                            base_lr=1e-4, weight_decay=5e-4)
+    opt = G.Optimizer([{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}], "adam",
+                      base_lr=1e-4, weight_decay=5e-4)
+    onet.train()
+    net.train()
+    lo, po = oracle.step_feedfwd(x, onet, False, t, oc, oopt, True)
+    l, p = G.step_feedfwd(u8.to(dev), net, dev != "cpu", t.to(dev), c, opt, True)
+    assert abs(l - lo) <= 1e-4 * max(1.0, abs(lo)), (l, lo)
+    assert (p.cpu() - po.detach()).abs().max().item() <= 2e-3 * max(1.0, po.abs().max().item())
+    net.set_input_u8(None)
+    assert net.mapnet._engine.input_u8 is None

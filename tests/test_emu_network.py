@@ -26,6 +26,10 @@ def test_checkpoint_interop_and_resume(lib):
     checks.check_checkpoint_interop(lib, DEV, H=32, W=40, resume_step=False)
 
 
+def test_uint8_input_pipeline(lib):
+    checks.check_u8_input(lib, DEV, N=1, H=32, W=40)
+
+
 def test_eval_flow_and_metric_fp32(lib):
     checks.check_eval_flow(lib, DEV, "fp32", L=2, T=3, H=32, W=40)
 

@@ -151,6 +151,10 @@ def test_checkpoint_interop_and_resume(lib):
     checks.check_checkpoint_interop(lib, DEV, H=64, W=85)
 
 
+def test_uint8_input_pipeline(lib):
+    checks.check_u8_input(lib, DEV, N=2, H=128, W=171)
+
+
 def test_eval_flow_and_metric(lib):
     """scripts/eval.py flow on synthetic windows: median / mean translation and rotation error"""
     checks.check_eval_flow(lib, DEV, "fp32", L=8, T=3, H=128, W=171)

@@ -118,15 +118,20 @@ template <typename T>
 static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, const double* __restrict__ accum,
                                                         double count, BnParams p, int training,
                                                         const T* __restrict__ res, T* __restrict__ out, long npieces,
-                                                        int C, int relu) {
+                                                        int C, int relu, int accum_rows) {
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ float s_scale[512], s_shift[512];
   for (int c = threadIdx.x; c < C; c += 256) {
     float mean, var;
     double unbiased = 0;
     if (training) {
-      double m = accum[c] / count;
-      double v = accum[C + c] / count - m * m;
+      double sa = 0, sb = 0;  // accum: [accum_rows][2][C]
+      for (int r = 0; r < accum_rows; ++r) {
+        sa += accum[(long)r * 2 * C + c];
+        sb += accum[(long)r * 2 * C + C + c];
+      }
+      double m = sa / count;
+      double v = sb / count - m * m;
       if (v < 0) v = 0;
       mean = (float)m;
       var = (float)v;
@@ -174,15 +179,20 @@ template <typename T>
 static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __restrict__ y, const double* __restrict__ accum,
                                                                double count, BnParams p, int training, T* __restrict__ out,
                                                                unsigned char* __restrict__ idx, int B, int H, int W, int C,
-                                                               int Po, int Qo) {
+                                                               int Po, int Qo, int accum_rows) {
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ float s_scale[512], s_shift[512];
   for (int c = threadIdx.x; c < C; c += 256) {
     float mean, var;
     double unbiased = 0;
     if (training) {
-      double m = accum[c] / count;
-      double v = accum[C + c] / count - m * m;
+      double sa = 0, sb = 0;  // accum: [accum_rows][2][C]
+      for (int r = 0; r < accum_rows; ++r) {
+        sa += accum[(long)r * 2 * C + c];
+        sb += accum[(long)r * 2 * C + C + c];
+      }
+      double m = sa / count;
+      double v = sb / count - m * m;
       if (v < 0) v = 0;
       mean = (float)m;
       var = (float)v;
@@ -264,7 +274,8 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
                                                              double* __restrict__ accum, int rows_per_block,
                                                              float* __restrict__ partial,
                                                              const float* __restrict__ sg_gamma,
-                                                             const float* __restrict__ sg_beta, PoolGradSrc pg) {
+                                                             const float* __restrict__ sg_beta, PoolGradSrc pg,
+                                                             int accum_rows) {
   // sg_gamma/sg_beta non-null ("self gate"): the consumer is this BatchNorm's own ReLU, so the gate
   // relu'(bn(y)) is recomputed from y (y*scale + shift > 0, the forward's arithmetic) instead of being read
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -336,9 +347,10 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
     if (partial) {  // [gridDim.x][2][C] fp32 partials, folded by bn_reduce_partials_kernel (few atomics)
       partial[((long)blockIdx.x * 2 + 0) * C + idx] = (float)a;
       partial[((long)blockIdx.x * 2 + 1) * C + idx] = (float)b;
-    } else {
-      atomicAdd(accum + idx, a);
-      atomicAdd(accum + C + idx, b);
+    } else {  // accum: [accum_rows][2][C]; the row spreads the same-address contention
+      double* row = accum + (long)((int)blockIdx.x % accum_rows) * 2 * C;
+      atomicAdd(row + idx, a);
+      atomicAdd(row + C + idx, b);
     }
   }
 }
@@ -353,11 +365,15 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
                                                             const double* __restrict__ accum, double count,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float grad_unscale, T* __restrict__ gy, long npieces, int C,
-                                                            const float* __restrict__ sg_beta, PoolGradSrc pg) {
+                                                            const float* __restrict__ sg_beta, PoolGradSrc pg, int accum_rows) {
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512], s_sh[512];
   for (int c = threadIdx.x; c < C; c += 256) {
-    const double sg = accum[c], sgx = accum[C + c];
+    double sg = 0, sgx = 0;  // accum: [accum_rows][2][C]
+    for (int r = 0; r < accum_rows; ++r) {
+      sg += accum[(long)r * 2 * C + c];
+      sgx += accum[(long)r * 2 * C + C + c];
+    }
     s_k1[c] = gamma[c] * invstd[c];
     s_sh[c] = sg_beta ? sg_beta[c] - mean[c] * (gamma[c] * invstd[c]) : 0.f;
     s_mg[c] = (float)(sg / count);
@@ -449,7 +465,8 @@ template <typename T>
 inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, const float* gamma, const float* mean,
                           const float* invstd, float* dgamma, float* dbeta, T* gy, double* accum, float grad_unscale,
                           hipStream_t s, float* partial = nullptr, const float* self_gate_beta = nullptr,
-                          PoolGradSrc pg = PoolGradSrc()) {
+                          PoolGradSrc pg = PoolGradSrc(), int accum_rows = 1) {
+  // accum_rows > 1: the reduction adds straight into accum[accum_rows][2][C] (fp64 atomics) and `partial` is unused
   // self_gate_beta: the gradient g is taken w.r.t. relu(bn(y)) of THIS BatchNorm; the ReLU gate is recomputed
   // from y and `gate` is not read
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -462,14 +479,15 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   if (rows < 4L * rlanes) rows = 4L * rlanes;
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
+  if (accum_rows > 1) partial = nullptr;
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
-                     rows_per_block, partial, sg_gamma, self_gate_beta, pg);
+                     rows_per_block, partial, sg_gamma, self_gate_beta, pg, accum_rows);
   if (partial)
     hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(nblk, 64), cdiv(C, 64)), dim3(256), 0, s,
                        (const float*)partial, nblk, C, accum, 64);
   long np = M * C / VEC;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd, gamma,
-                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C, self_gate_beta, pg);
+                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C, self_gate_beta, pg, accum_rows);
 }
 
 // ---- global average pool --------------------------------------------------------------------------

@@ -50,6 +50,8 @@ struct Epilogue {
   void* out;             // [M][ldc], element type T
   int ldc;
   float* stats;          // [grid_m][2][N] column partial sums (sum, sum of squares) or null
+  double* stats_accum = nullptr;  // alternative: [stats_rows][2][N] fp64 accumulators, added to atomically (row =
+  int stats_rows = 0;             // tile_m % stats_rows spreads the same-address contention); consumer sums the rows
   const float* bias;     // [N] or null
   int relu;              // max(0, .) after bias
   const void* res;       // residual [M][ldc] of type T or null
@@ -383,7 +385,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
         }
         __syncthreads();
       }
-  if (ep.stats) {
+  if (ep.stats || ep.stats_accum) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       s1[j] += __shfl_xor(s1[j], 32);
@@ -403,8 +405,14 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
           a += red[(w * BN + c) * 2 + 0];
           b += red[(w * BN + c) * 2 + 1];
         }
-        ep.stats[((long)tile_m * 2 + 0) * g.N + n0 + c] = a;
-        ep.stats[((long)tile_m * 2 + 1) * g.N + n0 + c] = b;
+        if (ep.stats_accum) {
+          double* row = ep.stats_accum + (long)(tile_m % ep.stats_rows) * 2 * g.N;
+          atomicAdd(row + n0 + c, (double)a);
+          atomicAdd(row + g.N + n0 + c, (double)b);
+        } else {
+          ep.stats[((long)tile_m * 2 + 0) * g.N + n0 + c] = a;
+          ep.stats[((long)tile_m * 2 + 1) * g.N + n0 + c] = b;
+        }
       }
   }
 }

@@ -242,7 +242,7 @@ struct Plan : PlanBase {
     T* y = nullptr;   // raw conv output [M][Cout]
     T* gy = nullptr;  // its gradient
     float *mean, *invstd;
-    double *accum_f, *accum_b;  // fp64 sums of the forward statistics / backward reductions, [2][C] each
+    double *accum_f, *accum_b;  // fp64 sums of the forward statistics / backward reductions, [ACC_ROWS][2][C] each
     int ldw;           // row pitch of the master weight gradient
     const int* colmap = nullptr;
   };
@@ -271,11 +271,13 @@ struct Plan : PlanBase {
   std::vector<Block> blocks;
   int Hl, Wl;  // last feature map
   float *pooled, *feat, *poses, *dposes, *dz, *dpooled, *fcT, *loss_dev;
-  float* stats_partial;
+  // BatchNorm sums are accumulated with fp64 atomics straight from the producing kernels (conv epilogue, backward
+  // reduction) into ACC_ROWS rows per unit (row = producer block % ACC_ROWS, to spread same-address contention);
+  // the consuming apply kernels add the rows in their prologue.  No separate partial-reduction launches.
+  static constexpr int ACC_ROWS = 8;
   double* acc_region = nullptr;
   size_t acc_bytes = 0;
   int cur_training = 1;
-  float* bwd_partial;  // [<= 4200][2][C] partial sums of the BatchNorm backward reduction
   double* sqnorm;
   unsigned char* frozen;
   int* stem_colmap;
@@ -294,8 +296,8 @@ struct Plan : PlanBase {
     Bump b;
     auto A = [&](size_t bytes) { return base ? base + b.take(bytes) : (b.take(bytes), (char*)nullptr); };
     // all BatchNorm accumulators live in one region so a single memset per step clears them
-    size_t acc_doubles = 4 * 64;
-    for (auto& blk : blocks) acc_doubles += (size_t)4 * blk.u1.cp.cout * (blk.down ? 3 : 2);
+    size_t acc_doubles = (size_t)ACC_ROWS * 4 * 64;
+    for (auto& blk : blocks) acc_doubles += (size_t)ACC_ROWS * 4 * blk.u1.cp.cout * (blk.down ? 3 : 2);
     acc_bytes = acc_doubles * 8;
     acc_region = (double*)A(acc_bytes);
     double* acc_cursor = acc_region;
@@ -306,8 +308,8 @@ struct Plan : PlanBase {
       u.mean = (float*)A(C * 4);
       u.invstd = (float*)A(C * 4);
       u.accum_f = acc_cursor;
-      u.accum_b = acc_cursor ? acc_cursor + 2 * C : nullptr;
-      if (acc_cursor) acc_cursor += 4 * C;
+      u.accum_b = acc_cursor ? acc_cursor + (size_t)ACC_ROWS * 2 * C : nullptr;
+      if (acc_cursor) acc_cursor += (size_t)ACC_ROWS * 4 * C;
     };
     xpad = (T*)A((size_t)B * Hp * Wp * 4 * sizeof(T));
     // stem
@@ -321,7 +323,6 @@ struct Plan : PlanBase {
     pool_idx = (unsigned char*)A(n1);
     const T* x = p0;
     T* gx = gp0;
-    size_t max_partial = (size_t)igemm_grid_m((int)stem.M) * 2 * 64;
     for (auto& blk : blocks) {
       blk.x = x;
       blk.gx = gx;
@@ -335,8 +336,6 @@ struct Plan : PlanBase {
         else
           u->wf = base ? (T*)(params + u->cp.w) : nullptr;  // fp32: the OHWI master is the operand
         u->wd = (T*)A(wn * sizeof(T));
-        size_t part = (size_t)igemm_grid_m((int)u->M) * 2 * u->cp.cout;
-        if (part > max_partial) max_partial = part;
       }
       size_t no = (size_t)blk.u2.M * blk.u2.cp.cout;
       blk.a1 = (T*)A(no * sizeof(T));
@@ -356,8 +355,6 @@ struct Plan : PlanBase {
     dpooled = (float*)A((size_t)B * 512 * 4);
     fcT = (float*)A((size_t)512 * F * 4);
     loss_dev = (float*)A(256);
-    stats_partial = (float*)A(max_partial * 4);
-    bwd_partial = (float*)A((size_t)4200 * 2 * 512 * 4);
     sqnorm = (double*)A(256);
     frozen = (unsigned char*)A(256);
     stem_colmap = (int*)A(224 * 4);
@@ -530,20 +527,20 @@ struct Plan : PlanBase {
   }
   void conv_bn_stats(Unit& u, const T* x, int training, hipStream_t s) {
     Epilogue ep;
-    ep.out = u.y; ep.ldc = u.cp.cout; ep.stats = training ? stats_partial : nullptr; ep.bias = nullptr; ep.relu = 0;
+    ep.out = u.y; ep.ldc = u.cp.cout; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0;
     ep.res = nullptr; ep.res_gate = nullptr; ep.alpha = 1.f;
+    if (training) {
+      ep.stats_accum = u.accum_f;
+      ep.stats_rows = ACC_ROWS;
+    }
     auto* tp = timer.begin(0, s);
-    const int GM = launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
+    launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
     timer.end(tp, s);
-    int N = u.cp.cout;
-    if (training)
-      hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(GM, 64), cdiv(N, 64)), dim3(256), 0, s,
-                         (const float*)stats_partial, GM, N, u.accum_f, 64);
   }
   void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s) {
     long np = u.M * u.cp.cout / VEC;
     hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const double*)u.accum_f,
-                       (double)u.M, bn_params(u), cur_training, res, out, np, u.cp.cout, relu);
+                       (double)u.M, bn_params(u), cur_training, res, out, np, u.cp.cout, relu, ACC_ROWS);
   }
 
   int forward(const void* images, float* poses_out, int training, hipStream_t s) override {
@@ -570,7 +567,7 @@ struct Plan : PlanBase {
     if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
       hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
                          (const T*)stem.y, (const double*)stem.accum_f, (double)stem.M, bn_params(stem), cur_training, p0,
-                         pool_idx, B, H0, W0, 64, H1, W1);
+                         pool_idx, B, H0, W0, 64, H1, W1, ACC_ROWS);
     } else {
       bn_act(stem, nullptr, 1, a0, s);
       hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
@@ -631,8 +628,8 @@ struct Plan : PlanBase {
   // self_gate: `gate` is relu(bn_u(y)) itself (a1 of a block, a0 of the stem): recomputed from y, not read
   void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s, bool self_gate = false) {
     launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
-                     grads + u.bp.beta, u.gy, u.accum_b, 1.f / cfg.loss_scale, s, bwd_partial,
-                     (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr);
+                     grads + u.bp.beta, u.gy, u.accum_b, 1.f / cfg.loss_scale, s, nullptr,
+                     (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr, PoolGradSrc(), ACC_ROWS);
   }
   // bit 0: BatchNorm+ReLU+max-pool in one forward pass (-0.15 ms/step); bit 1: max-pool gradient gathered inside the
   // BatchNorm backward passes instead of a maxpool_bwd launch (measured +0.05 ms/step: the gather runs twice) -- off
@@ -718,7 +715,7 @@ struct Plan : PlanBase {
       pg.idx = pool_idx; pg.gout = gp0; pg.H = H0; pg.W = W0; pg.Po = H1; pg.Qo = W1;
       launch_bn_bwd<T>((const T*)nullptr, (const T*)nullptr, (const T*)stem.y, stem.M, 64, params + stem.bp.gamma, stem.mean,
                        stem.invstd, grads + stem.bp.gamma, grads + stem.bp.beta, stem.gy, stem.accum_b,
-                       1.f / cfg.loss_scale, s, bwd_partial, params + stem.bp.beta, pg);
+                       1.f / cfg.loss_scale, s, nullptr, params + stem.bp.beta, pg, ACC_ROWS);
     } else {
       hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s,
                          (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);

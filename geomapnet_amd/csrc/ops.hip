@@ -148,7 +148,7 @@ static int bn_train_fwd_t(const void* y, int64_t M, int C, const float* gamma, c
   p.num_batches_tracked = nullptr; p.mean = mean; p.invstd = invstd; p.eps = eps; p.momentum = momentum;
   long np = M * C / ElemTraits<T>::VEC;
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)y, (const double*)accum,
-                     (double)M, p, 1, (const T*)res, (T*)out, np, C, relu);
+                     (double)M, p, 1, (const T*)res, (T*)out, np, C, relu, 1);
   return check_launch("bn_train_fwd");
 }
 

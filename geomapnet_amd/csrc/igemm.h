@@ -50,6 +50,10 @@ struct Epilogue {
   void* out;             // [M][ldc], element type T
   int ldc;
   float* stats;          // [grid_m][2][N] column partial sums (sum, sum of squares) or null
+  // stream-K (see igemm_kernel): fp32 slabs [blocks][2][BM*BN] (scratch) and arrival counters [blocks] (zero on
+  // entry, left zero on exit); null = every workgroup owns whole tiles
+  float* sk_ws = nullptr;
+  int* sk_counters = nullptr;
   double* stats_accum = nullptr;  // alternative: [stats_rows][2][N] fp64 accumulators, added to atomically (row =
   int stats_rows = 0;             // tile_m % stats_rows spreads the same-address contention); consumer sums the rows
   const float* bias;     // [N] or null
@@ -114,6 +118,10 @@ typedef void __attribute__((address_space(3)))* las_ptr_t;
 __device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gas_ptr_t)src, (las_ptr_t)lds_wave_base, 16, 0, 0);
 }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// by-value helpers: __builtin_bit_cast applied directly to a vector ELEMENT expression reads element 0 (clang)
+__device__ __forceinline__ unsigned f32_bits(float f) { return __builtin_bit_cast(unsigned, f); }
+__device__ __forceinline__ float bits_f32(unsigned u) { return __builtin_bit_cast(float, u); }
 // Buffer resource over a dense tensor (raw addressing, stride 0): a load whose byte offset reaches `bytes`
 // returns zero.  Tensors on this path are far below the 4 GiB a 32-bit offset spans.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
@@ -131,10 +139,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI>
+//
+// SK (stream-K): the launch has a fixed number of workgroups (the resident slots of the chip) and the tile-major
+// iteration space tiles x K-steps is cut into equal contiguous ranges, so a grid of 528 or 1056 tiles costs 1.03 /
+// 2.06 rounds of work instead of 2 / 3.  A workgroup whose range covers only part of a tile adds its fp32
+// accumulators to its own workspace slab and bumps the tile's arrival counter; the second of the two workgroups
+// that share a tile adds the other's slab and runs the normal epilogue.  Nobody waits for anybody.
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SK = false>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
-                                                                         const T* __restrict__ zero_page, RowDiv rd) {
+                                                                         const T* __restrict__ zero_page, RowDiv rd,
+                                                                         int sk_tiles) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -156,7 +171,25 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform values stay in scalar registers
   const int wm = wave / WN, wn = wave % WN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int KT = g.K / (NP * VEC);
+  // [it, it_end): this workgroup's range of the tile-major (tile, K-step) iteration space
+  long it, it_end;
+  long sk_total = 0;
+  if constexpr (SK) {
+    static_assert(UNI, "stream-K needs the uniform tap walk");
+    sk_total = (long)sk_tiles * KT;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    it = lb * sk_total / gridDim.x;
+    it_end = (lb + 1) * sk_total / gridDim.x;
+  } else {
+    it = (long)xcd_remap(blockIdx.x, gridDim.x) * KT;
+    it_end = it + KT;
+  }
+  while (it < it_end) {
+  const int tile = (int)(it / KT);
+  const int k0 = (int)(it - (long)tile * KT);
+  const int k1 = (int)(it_end - it < (long)(KT - k0) ? k0 + (it_end - it) : KT);
+  it += k1 - k0;
   const int tile_m = tile / grid_n, tile_n = tile - tile_m * grid_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int pc = t % NP, lrow = t / NP;
@@ -222,6 +255,13 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   // running decomposition of the step's first piece (uniform walk) or of this lane's piece (per-lane walk)
   // into (tap = (tr, ts), channel piece cpi)
   int cpi = uni ? 0 : src_piece, tr = 0, ts = 0, tap = 0;
+  if (SK && k0 > 0) {  // the range starts inside the tile (uniform walk: plain scalar divisions)
+    const int piece0 = k0 * NP;
+    tap = piece0 / CP;
+    cpi = piece0 - tap * CP;
+    tr = tap / g.S;
+    ts = tap - tr * g.S;
+  }
   while (cpi >= CP) {
     cpi -= CP;
     ++tap;
@@ -230,7 +270,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
       ++tr;
     }
   }
-  unsigned b_step = 0;  // byte offset of the K-step inside a weight row (scalar)
+  unsigned b_step = (unsigned)k0 * NP * 16;  // byte offset of the K-step inside a weight row (scalar)
   const unsigned lds_wave = wave * 64;  // this wave's 64 pieces of DMA pass 0 inside a tile
 
   auto issue_tile = [&](int buf) {
@@ -265,14 +305,14 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int KT = g.K / (NP * VEC);
+  const int NK = k1 - k0;  // K-steps of this segment
 #pragma unroll
   for (int j = 0; j < D; ++j)
-    if (j < KT) issue_tile(j);
+    if (j < NK) issue_tile(j);
   int cur = 0, nxt = D % NBUF;
-  for (int kt = 0; kt < KT; ++kt) {
-    // tiles issued so far: min(KT, kt + D); tile kt must have landed
-    const int ahead = min(KT, kt + D) - (kt + 1);
+  for (int kt = 0; kt < NK; ++kt) {
+    // tiles issued so far: min(NK, kt + D); tile kt must have landed
+    const int ahead = min(NK, kt + D) - (kt + 1);
     if (D >= 3 && ahead >= 2)
       wait_vmcnt<2 * IPT>();
     else if (D >= 2 && ahead >= 1)
@@ -280,7 +320,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everyone is done reading buffer `nxt`
-    if (kt + D < KT) issue_tile(nxt);  // tiles are issued strictly in K order
+    if (kt + D < NK) issue_tile(nxt);  // tiles are issued strictly in K order
     const piece_t* ta = &smem[cur * TILE_PIECES];
     // fragments are register double-buffered: the ds_reads of sub-step ks+1 are issued before the MFMAs
     // of sub-step ks so LDS latency hides under the matrix pipe
@@ -313,6 +353,54 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
   }
   __syncthreads();  // all fragment reads done before the ring is reused as epilogue staging
+
+  if constexpr (SK) {
+    if (k0 != 0 || k1 != KT) {
+      // Partial tile.  Ranges are at least one tile long (the launcher only uses stream-K when tiles > workgroups),
+      // so a tile is shared by exactly two workgroups: lb, which holds its head (k0 == 0), and lb + 1, which holds
+      // its tail.  Each writes its fp32 accumulators to its own slab (write-through stores, no atomics), publishes
+      // with one counter increment, and whoever arrives second adds the other's slab and runs the epilogue
+      // (cdna_hip_programming.md, in-launch split-K reduction).
+      const int lb = xcd_remap(blockIdx.x, gridDim.x);
+      const bool head = k0 == 0;
+      const int cidx = head ? lb : lb - 1;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(ep.sk_ws, (long)gridDim.x * 2 * (BM * BN) * 4);
+      const unsigned mine = (unsigned)((lb * 2 + (head ? 1 : 0)) * (BM * BN) * 4);
+      const unsigned theirs = (unsigned)(((head ? lb + 1 : lb - 1) * 2 + (head ? 0 : 1)) * (BM * BN) * 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = f32_bits(acc[i][j][q * 4 + e]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + ((((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 16, 0,
+                                                   16 /* sc1: write-through */);
+          }
+      wait_vmcnt<0>();
+      __syncthreads();
+      int* flag = reinterpret_cast<int*>(red);
+      if (t == 0) flag[0] = atomicAdd(&ep.sk_counters[cidx], 1);
+      __syncthreads();
+      const bool last = flag[0] != 0;
+      __syncthreads();  // everyone has read the flag before `red` is reused
+      if (!last) continue;
+      if (t == 0) atomicExch(&ep.sk_counters[cidx], 0);  // leave the counter ready for the next launch
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                rs, theirs + ((((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 16, 0, 16 /* sc1: bypass this XCD's L2 */);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] += bits_f32(v[e]);
+          }
+    }
+  }
 
   // ---- epilogue ---------------------------------------------------------------------------------
   T* out = reinterpret_cast<T*>(ep.out);
@@ -415,6 +503,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
         }
       }
   }
+  if constexpr (SK) __syncthreads();  // `red` and the staging area are free before the next segment starts
+  }  // segments of this workgroup's range
 }
 
 // upper bound of the number of M-blocks a launch uses (sizes the BatchNorm partial buffer)
@@ -436,23 +526,43 @@ inline int igemm_config() {
   return v;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI = true>
+// number of workgroups a stream-K launch uses: two per CU (the occupancy of the 128x128 configuration)
+inline int igemm_sk_blocks() {
+  static int v = 0;
+  if (v == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    v = 2 * cus;
+  }
+  return v;
+}
+
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI = true, bool ALLOW_SK = false>
 inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
-                            const T* zero_page) {
+                            const T* zero_page, int sk_blocks = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int gm = cdiv(g.M, BM), gn = cdiv(g.N, BN);
   RowDiv rd;
   rd.q = make_fastdiv(g.Q);
   rd.p = make_fastdiv(g.P);
+  if constexpr (UNI && ALLOW_SK) {
+    if (sk_blocks > 0 && sk_blocks < gm * gn && ep.sk_ws && ep.sk_counters) {
+      hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, true>), dim3(sk_blocks), dim3(WM * WN * 64), 0,
+                         stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
+      return gm;
+    }
+  }
   hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI>), dim3(gm * gn), dim3(WM * WN * 64), 0, stream, g, A, Bw,
-                     ep, gn, zero_page, rd);
+                     ep, gn, zero_page, rd, gm * gn);
   return gm;
 }
 
 // returns the number of M-blocks used (= rows of the stats partial buffer that were written)
 template <typename T>
 inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
-                        const T* zero_page) {
+                        const T* zero_page, int sk_blocks = 0) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const bool wide_k = (g.C / VEC) % 8 == 0;  // 128-byte K-steps need taps that are a multiple of them
   int cfg = igemm_config();
@@ -464,6 +574,21 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
   // per-shape default (tools/conv_bench.py on MI355X, B = 192): 128x128 tiles, two workgroups per CU (512 slots);
   // when that leaves a few tiles over one full round (layer4: 528 tiles), 256x128 tiles with 128-row wave tiles
   // put every tile in a single round instead (103 vs 121 us)
+  // With a stream-K workspace: grids of 1..6 rounds that do not fill their last round are cut into equal ranges
+  // instead (sk_blocks > 0 forces it, for tests).
+  // Measured on MI355X (tools/quant_probe.py, SK=1): 1056 tiles 123 vs 120 us, 528 tiles 105 vs 103 us (256x128
+  // tiles), 2064 tiles 113 vs 118 us, whole step 19.8 vs 19.65 ms -- every extra segment pays a gather prologue and
+  // a pipeline fill, which eats what the balanced ranges save.  Off unless MN_STREAMK=1 (or sk_blocks is forced).
+  static const bool allow_sk = getenv("MN_STREAMK") && atoi(getenv("MN_STREAMK")) != 0;
+  if (ep.sk_ws && ep.sk_counters && g.N >= 128 && (cfg == 0 || cfg == 1) && (allow_sk || sk_blocks > 0)) {
+    const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    const int G = sk_blocks > 0 ? sk_blocks : igemm_sk_blocks();
+    const bool want = sk_blocks > 0 || (tiles128 > G && tiles128 < 6L * G && (tiles128 % G) * 8 < 7L * G);
+    if (want && tiles128 > G) {
+      if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, true>(g, A, Bw, ep, stream, zero_page, G);
+      return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2, true, true>(g, A, Bw, ep, stream, zero_page, G);
+    }
+  }
   if (cfg == 0) {
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
     cfg = (g.N >= 128 && g.N % 128 == 0 && tiles128 > 512 && tiles128 <= 640) ? 8 : 1;

@@ -285,6 +285,8 @@ struct Plan : PlanBase {
   int repack_njobs = 0, repack_blocks = 0, repack_head_jobs = -1, repack_head_blocks = 0;
   bool grads_zeroed = false;
   unsigned char* pool_idx;  // winning tap of every max-pool window
+  float* sk_ws = nullptr;   // stream-K slabs [igemm_sk_blocks()][2][128*128] and
+  int* sk_counters = nullptr;  // arrival counters; zero between launches (igemm.h)
   void* zero_page;          // 256 zero bytes: source of out-of-image taps for the DMA conv pipeline
   long long* step_dev;      // device-resident Adam step counter
   float* bc_dev;            // {1 - beta1^t, 1 - beta2^t}, derived on device from step_dev
@@ -360,6 +362,8 @@ struct Plan : PlanBase {
     stem_colmap = (int*)A(224 * 4);
     repack_jobs = (RepackJob*)A(64 * sizeof(RepackJob));
     zero_page = (void*)A(256);
+    sk_ws = (float*)A((size_t)igemm_sk_blocks() * 2 * 128 * 128 * 4);
+    sk_counters = (int*)A((size_t)igemm_sk_blocks() * 4);
     step_dev = (long long*)A(256);
     bc_dev = (float*)A(256);
     return b.cur;
@@ -533,6 +537,8 @@ struct Plan : PlanBase {
       ep.stats_accum = u.accum_f;
       ep.stats_rows = ACC_ROWS;
     }
+    ep.sk_ws = sk_ws;
+    ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
     launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
     timer.end(tp, s);
@@ -653,6 +659,8 @@ struct Plan : PlanBase {
     Epilogue ep;
     ep.out = gx; ep.ldc = u.cp.cin; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = res; ep.res_gate = gate;
     ep.alpha = 1.f;
+    ep.sk_ws = sk_ws;
+    ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
     launch_igemm<T>(u.gd, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page);
     timer.end(tp, s);

@@ -71,6 +71,25 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   return check_launch("igemm");
 }
 
+extern "C" int mn_op_igemm_streamk(int dtype, const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc,
+                                   float* stats, const float* bias, int relu, const void* res, const void* res_gate,
+                                   float alpha, float* ws, int* counters, int blocks, void* stream) {
+  begin_call();
+  GatherGeom g = to_geom(gg);
+  if (int e = check_geom(g, dtype)) return e;
+  if (!ws || !counters || blocks < 1) return fail("igemm_streamk: workspace, counters and blocks >= 1 are required");
+  const int VEC = dtype == MN_DTYPE_F16 ? 8 : 4;
+  if (g.N < 128 || (g.C / VEC) % 4 != 0) return fail("igemm_streamk: needs N >= 128 and C a multiple of the K-step");
+  Epilogue ep;
+  ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
+  ep.alpha = alpha; ep.sk_ws = ws; ep.sk_counters = counters;
+  if (dtype == MN_F16)
+    launch_igemm<half>(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, (const half*)nullptr, blocks);
+  else
+    launch_igemm<float>(g, (const float*)A, (const float*)Bw, ep, (hipStream_t)stream, (const float*)nullptr, blocks);
+  return check_launch("igemm_streamk");
+}
+
 extern "C" int mn_op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
                            const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream) {
   begin_call();

@@ -157,6 +157,12 @@ int mn_op_igemm(int dtype, const mn_gather_geom* g, const void* A, const void* B
                 const float* bias, int relu, const void* res, const void* res_gate, float alpha, const void* zero_page,
                 void* stream);
 int mn_op_igemm_grid_m(int M);
+/* The same operator with the stream-K schedule (igemm.h): `blocks` workgroups share the (tile, K-step) iteration
+ * space in equal ranges; ws: fp32 scratch [blocks][2][128*128]; counters: int32 [blocks], zero on entry and zero
+ * again on return.  Requires N >= 128 and C a multiple of the K-step; falls back to whole tiles when blocks >= tiles. */
+int mn_op_igemm_streamk(int dtype, const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
+                        const float* bias, int relu, const void* res, const void* res_gate, float alpha, float* ws,
+                        int32_t* counters, int blocks, void* stream);
 /* dW[n][colmap(k)] += alpha * sum_m dY[m][n] * gather(X)[m][k]  (fp32 atomics into dW) */
 int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw,
                 const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream);

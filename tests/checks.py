@@ -94,6 +94,37 @@ def check_conv_fwd(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, seed=0):
     assert ((s2 - (ref ** 2).sum((0, 2, 3))).abs() / (ref ** 2).sum((0, 2, 3))).max().item() <= 1e-4
 
 
+def check_conv_streamk(lib, dev, dtype, B, H, W, Cin, Cout, k, blocks, seed=3):
+    """stream-K schedule of the conv forward (+ BatchNorm column sums + residual): same results as the reference conv,
+    workspace and counters handed back zeroed; `blocks` chosen so tiles are cut at arbitrary K-steps"""
+    _fresh()
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(td).float()
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) * (2.0 / (Cin * k * k)) ** 0.5).to(td).float()
+    res = torch.randn(B, Cout, H, W, generator=gen).to(td).float()
+    ref = F.conv2d(x.double(), w.double(), stride=1, padding=k // 2) + res.double()
+    g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, k, 1, k // 2)
+    xn, wn, rn = _nhwc(x, td, dev), _nhwc(w, td, dev), _nhwc(res, td, dev)
+    out = torch.zeros(B, Ho, Wo, Cout, dtype=td, device=dev)
+    gm = lib.op_igemm_grid_m(g.M)
+    st = torch.zeros(gm, 2, Cout, device=dev)
+    ws = torch.zeros(blocks, 2, 128 * 128, device=dev)
+    cnt = torch.zeros(blocks, dtype=torch.int32, device=dev)
+    for _ in range(2):  # twice: the second launch relies on the state the first one left behind
+        lib.check(lib.op_igemm_streamk(dtype, C.byref(g), K(xn), K(wn), K(out), Cout, K(st), None, 0, K(rn), None, f32(1), K(ws),
+                                       K(cnt), blocks, None))
+        dev_sync(dev)
+        o = out.cpu().double().permute(0, 3, 1, 2)
+        scale = ref.abs().max().item()
+        assert (o - ref).abs().max().item() <= OUT_TOL[dtype] * scale + 1e-6
+        assert cnt.abs().max().item() == 0
+    conv = ref - res.double()  # statistics are taken before the residual
+    s1 = st[:, 0].sum(0).cpu().double()
+    n = B * Ho * Wo
+    assert (s1 - conv.sum((0, 2, 3))).abs().max().item() <= 1e-4 * scale * n ** 0.5 + 1e-3
+
+
 def check_conv_dgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, with_res=True, seed=1):
     _fresh()
     td = TD[dtype]

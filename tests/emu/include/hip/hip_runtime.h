@@ -131,6 +131,21 @@ inline double atomicAdd(double* p, double v) { return emu_atomic_add(p, v); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline float unsafeAtomicAdd(float* p, float v) { return emu_atomic_add(p, v); }
+inline float atomicExch(float* p, float v) {
+  unsigned old, nv;
+  memcpy(&nv, &v, 4);
+  old = __atomic_exchange_n(reinterpret_cast<unsigned*>(p), nv, __ATOMIC_SEQ_CST);
+  float r;
+  memcpy(&r, &old, 4);
+  return r;
+}
+inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) {
+  *v = 4;  // a small "chip": stream-K launches use 8 workgroups under the emulator
+  return hipSuccess;
+}
+
 inline double unsafeAtomicAdd(double* p, double v) { return emu_atomic_add(p, v); }
 
 // ---- wave collectives ---------------------------------------------------------------------
@@ -322,6 +337,15 @@ inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, _
     memset(dst, 0, size);
   else
     memcpy(dst, r.base + off + (unsigned)soffset, size);
+}
+typedef unsigned emu_u32x4 __attribute__((ext_vector_type(4)));
+inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+  if ((unsigned long)(unsigned)voffset + 16 <= r.num_records) memcpy(const_cast<char*>(r.base) + (unsigned)voffset + (unsigned)soffset, &v, 16);
+}
+inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+  emu_u32x4 v = {0, 0, 0, 0};
+  if ((unsigned long)(unsigned)voffset + 16 <= r.num_records) memcpy(&v, r.base + (unsigned)voffset + (unsigned)soffset, 16);
+  return v;
 }
 inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width) {
   return (int)((unsigned)v << (32 - off - width)) >> (32 - width);

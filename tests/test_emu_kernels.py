@@ -25,6 +25,17 @@ def test_conv_forward(lib, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape,blocks", [
+    ((4, 16, 16, 64, 128, 3), 3),     # 8 tiles x 9..18 K-steps over 3 workgroups: cuts inside tiles
+    ((5, 16, 16, 128, 256, 3), 7),    # 20 tiles over 7 workgroups
+    ((3, 12, 11, 64, 128, 1), 2),     # ragged M (396 rows), one K-step per tile at fp16: cuts only at tile borders
+    ((2, 16, 16, 64, 128, 3), 9),     # more workgroups than tiles: whole-tile schedule
+])
+def test_conv_stream_k(lib, dtype, shape, blocks):
+    checks.check_conv_streamk(lib, DEV, dtype, *shape, blocks=blocks)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1),
     (2, 9, 11, 64, 128, 3, 2, 1),    # stride-2 data gradient (div = 2 gather)

@@ -44,6 +44,15 @@ def test_conv_data_gradient(lib, dtype, shape):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape,blocks", [
+    ((4, 16, 16, 64, 128, 3), 3), ((5, 16, 16, 128, 256, 3), 7), ((3, 12, 11, 64, 128, 1), 2), ((2, 16, 16, 64, 128, 3), 9),
+    ((33, 16, 22, 256, 256, 3), 64),   # 182 tiles over 64 workgroups
+])
+def test_conv_stream_k(lib, dtype, shape, blocks):
+    checks.check_conv_streamk(lib, DEV, dtype, *shape, blocks=blocks)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape,blocks", [
     ((2, 9, 11, 64, 64, 3, 1, 1), 8), ((3, 9, 11, 64, 128, 3, 2, 1), 8), ((2, 8, 10, 64, 128, 1, 2, 0), 1),
     ((5, 5, 6, 128, 128, 3, 1, 1), 40), ((2, 64, 86, 64, 64, 3, 1, 1), 1024), ((4, 8, 11, 512, 512, 3, 1, 1), 1024),
     ((3, 7, 9, 128, 128, 3, 1, 1), 40), ((7, 16, 22, 256, 256, 3, 1, 1), 1024),

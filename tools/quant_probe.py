@@ -41,7 +41,13 @@ for (Ci, Co, H, W, Bs) in SHAPES:
         w = (torch.randn(Co, 3, 3, Ci, device="cuda") * 0.05).half()
         y = torch.empty(B, Ho, Wo, Co, dtype=torch.half, device="cuda")
         st = torch.zeros(lib.op_igemm_grid_m(g.M), 2, Co, device="cuda")
-        t = timeit(lambda: lib.op_igemm(1, C.byref(g), ptr(x), ptr(w), ptr(y), Co, ptr(st), None, 0, None, None, one,
+        if os.environ.get("SK"):
+            ws = torch.zeros(512, 2, 128 * 128, device="cuda")
+            cnt = torch.zeros(512, dtype=torch.int32, device="cuda")
+            t = timeit(lambda: lib.op_igemm_streamk(1, C.byref(g), ptr(x), ptr(w), ptr(y), Co, ptr(st), None, 0, None, None, one,
+                                                    ptr(ws), ptr(cnt), 512, None))
+        else:
+          t = timeit(lambda: lib.op_igemm(1, C.byref(g), ptr(x), ptr(w), ptr(y), Co, ptr(st), None, 0, None, None, one,
                                          ptr(checks.zero_page("cuda")), None))
         tiles = ((g.M + 127) // 128) * (Co // 128)
         print("C=%d M=%7d tiles128=%5d (%.2f rounds of 512)  %7.1f us  %5.0f TF  %6.3f us/tile-slot-round"

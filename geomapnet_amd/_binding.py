@@ -68,6 +68,8 @@ _PROTOS = {
     "mn_op_oihw_to_ohwi": (c_i, [c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),
     "mn_op_criterion": (c_i, [c_i, c_i, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_f, c_void]),
     "mn_op_calc_vos": (c_i, [c_void, c_i, c_i, c_void, c_void, c_void, c_void]),
+    "mn_pgo_optimize": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, C.c_double, C.c_double, C.c_double,
+                              C.c_double, c_i, c_void]),
     "mn_op_adam": (c_i, [c_void, c_void, c_void, c_void, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_void,
                          c_i, c_void]),
     "mn_op_bn_train_fwd": (c_i, [c_i, c_void, c_i64, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_i,

@@ -9,6 +9,7 @@
 #include "head.h"
 #include "igemm.h"
 #include "optim.h"
+#include "pgo.h"
 #include "pool.h"
 #include "wgrad.h"
 #include "util.h"
@@ -131,6 +132,21 @@ extern "C" int mn_op_calc_vos(const float* poses, int N, int T, float* vos, cons
   hipLaunchKernelGGL(calc_vos_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, poses, N, T, vos, cot,
                      dposes);
   return check_launch("calc_vos");
+}
+
+extern "C" int mn_pgo_optimize(const double* poses, const double* vos, double* out, int32_t* status, int W, int N,
+                               int fc_vos, double sax, double saq, double srx, double srq, int n_iters, void* stream) {
+  begin_call();
+  if (W <= 0) return fail("pgo: no windows");
+  if (N < 2 || N > kPgoMaxN) return fail("pgo: 2 <= poses per window <= 12");
+  if (!(sax > 0.0 && saq > 0.0 && srx > 0.0 && srq > 0.0)) return fail("pgo: covariances must be positive");
+  if (n_iters < 0) return fail("pgo: n_iters < 0");
+  if (!poses || !vos || !out || !status) return fail("pgo: null pointer");
+  PgoArgs a;
+  a.poses = poses; a.vos = vos; a.out = out; a.status = status; a.W = W; a.N = N; a.fc = fc_vos ? 1 : 0; a.n_iters = n_iters;
+  a.w_ax = sqrt(1.0 / sax); a.w_aq = sqrt(1.0 / saq); a.w_rx = sqrt(1.0 / srx); a.w_rq = sqrt(1.0 / srq);
+  hipLaunchKernelGGL(pgo_kernel, dim3(W), dim3(64), 0, (hipStream_t)stream, a);
+  return check_launch("pgo");
 }
 
 extern "C" int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip, float lr, float wd,

@@ -41,20 +41,31 @@ def calc_vos_simple(poses):
     return poses[:, 1:] - poses[:, :-1]
 
 
+def _calc_vos_safe_pairs(poses, pairs_of):
+    poses = torch.as_tensor(poses)
+    p = poses.detach().cpu().numpy().astype(np.float32)
+    pairs = pairs_of(p.shape[1])
+    out = np.zeros((p.shape[0], len(pairs), 6), dtype=np.float32)
+    for n in range(p.shape[0]):
+        for k, (i, j) in enumerate(pairs):
+            q0 = np.asarray(qexp(p[n, i, 3:]), dtype=np.float32)
+            q1 = np.asarray(qexp(p[n, j, 3:]), dtype=np.float32)
+            q0i = np.hstack((q0[:1], -q0[1:]))
+            out[n, k, :3] = _rotate(p[n, j, :3] - p[n, i, :3], q0i)
+            out[n, k, 3:] = np.asarray(qlog(_qmult(q0i, q1).astype(np.float32)), dtype=np.float32)
+    return torch.from_numpy(out).to(poses.dtype)
+
+
 def calc_vos_safe(poses):
     """[N,T,6] -> [N,T-1,6]: VO of consecutive poses in the first pose's frame, through the numpy qexp/qlog
     (no gradient), fp32 as the reference (pose_utils.py:219-232, :276-288)"""
-    poses = torch.as_tensor(poses)
-    p = poses.detach().cpu().numpy().astype(np.float32)
-    out = np.zeros((p.shape[0], p.shape[1] - 1, 6), dtype=np.float32)
-    for n in range(p.shape[0]):
-        for i in range(p.shape[1] - 1):
-            q0 = np.asarray(qexp(p[n, i, 3:]), dtype=np.float32)
-            q1 = np.asarray(qexp(p[n, i + 1, 3:]), dtype=np.float32)
-            q0i = np.hstack((q0[:1], -q0[1:]))
-            out[n, i, :3] = _rotate(p[n, i + 1, :3] - p[n, i, :3], q0i)
-            out[n, i, 3:] = np.asarray(qlog(_qmult(q0i, q1).astype(np.float32)), dtype=np.float32)
-    return torch.from_numpy(out).to(poses.dtype)
+    return _calc_vos_safe_pairs(poses, lambda T: [(i, i + 1) for i in range(T - 1)])
+
+
+def calc_vos_safe_fc(poses):
+    """[N,T,6] -> [N,T(T-1)/2,6]: the same VO for ALL pairs i < j in lexicographic order (pose_utils.py:290-304);
+    the `vo_func` of the fully connected pose graph (scripts/eval.py:120)"""
+    return _calc_vos_safe_pairs(poses, lambda T: [(i, j) for i in range(T) for j in range(i + 1, T)])
 
 
 def mat2quat(R):

@@ -4,7 +4,8 @@ Mirrors /root/reference/scripts/eval.py:153-205 (inference loop, "take the middl
 un-normalisation, error statistics) and the numpy helpers it uses from
 /root/reference/common/pose_utils.py: `qexp` (:319-327), `quaternion_angular_error` (:361-371);
 `t_criterion` is the L2 norm of eval.py:80.  The network forward inside the loop is the HIP path
-(`step_feedfwd(train=False)`); pose-graph optimisation (eval.py:177-182) is out of scope.
+(`step_feedfwd(train=False)`); pose-graph optimisation (eval.py:177-182, `--pose_graph`) runs on the HIP path
+too, batched over all windows of the loop in one launch (geomapnet_amd/pgo.py).
 """
 import numpy as np
 
@@ -62,14 +63,19 @@ def summarize(t_loss, q_loss):
             "median_q": float(np.median(q_loss)), "mean_q": float(np.mean(q_loss))}
 
 
-def evaluate(model, batches, pose_m=(0.0, 0.0, 0.0), pose_s=(1.0, 1.0, 1.0), cuda=True):
-    """Inference loop of eval.py:153-190 without pose-graph optimisation.
+def evaluate(model, batches, pose_m=(0.0, 0.0, 0.0), pose_s=(1.0, 1.0, 1.0), cuda=True, pose_graph=False, fc_vos=False,
+             sax=1, saq=1, srx=1, srq=1):
+    """Inference loop of eval.py:153-190.
+
+    With `pose_graph` (eval.py:177-182) every target carries the window's VOs after its T absolute poses
+    (`MF(include_vos=True)`: target [1,T+P,6]); predictions and VOs of all windows are collected and optimised by
+    one `optimize_windows` launch, then un-normalised (eval.py:184-186 runs after the optimisation).
 
     `batches`: iterable of (data, target) as the reference's DataLoader yields them with batch_size 1:
     data [1,3,H,W] (PoseNet) or [1,T,3,H,W] (MapNet, `--model mapnet*`), target [1,6] / [1,T,6].  For
     every batch the MIDDLE prediction of the window is kept (eval.py:187-190: `output[len(output)/2]`).
     Returns (summary dict, pred_poses [L,7], targ_poses [L,7])."""
-    pred, targ = [], []
+    pred, targ, win_out, win_vos = [], [], [], []
     was_training = model.training
     model.eval()
     try:
@@ -78,12 +84,22 @@ def evaluate(model, batches, pose_m=(0.0, 0.0, 0.0), pose_s=(1.0, 1.0, 1.0), cud
             s = output.size()
             out = output.detach().cpu().numpy().reshape((-1, s[-1]))
             tgt = np.asarray(target.detach().cpu().numpy() if hasattr(target, "detach") else target).reshape((-1, s[-1]))
-            out = to_pose7(out, pose_m, pose_s)
+            if pose_graph:
+                win_out.append(to_pose7(out, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))  # qexp only
+                win_vos.append(to_pose7(tgt[len(out):], (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+                tgt = tgt[:len(out)]
+            else:
+                out = to_pose7(out, pose_m, pose_s)
+                pred.append(out[len(out) // 2])
             tgt = to_pose7(tgt, pose_m, pose_s)
-            pred.append(out[len(out) // 2])
             targ.append(tgt[len(tgt) // 2])
     finally:
         model.train(was_training)
+    if pose_graph and win_out:
+        from .pgo import optimize_windows
+        opt = optimize_windows(np.stack(win_out), np.stack(win_vos), fc_vos=fc_vos, sax=sax, saq=saq, srx=srx, srq=srq)
+        opt[:, :, :3] = (opt[:, :, :3] * np.asarray(pose_s, dtype=np.float64)) + np.asarray(pose_m, dtype=np.float64)
+        pred = [o[len(o) // 2] for o in opt]
     pred_poses, targ_poses = np.asarray(pred), np.asarray(targ)
     t_loss, q_loss = pose_errors(pred_poses, targ_poses)
     return summarize(t_loss, q_loss), pred_poses, targ_poses

@@ -176,6 +176,15 @@ int mn_op_criterion(int mode, int N, int T, const float* pred, const float* targ
 /* replaces pose_utils.calc_vos (common/pose_utils.py:248-260) and its autograd VJP */
 int mn_op_calc_vos(const float* poses, int N, int T, float* vos, const float* cot, float* dposes, void* stream);
 
+/* Pose-graph optimisation of W windows in one launch (one wavefront per window, fp64).  Replaces
+ * PoseGraph.optimize / PoseGraphFC.optimize behind optimize_poses (common/pose_utils.py:458-804), which
+ * scripts/eval.py:177-182 calls per window on the host.  poses [W][N][7] (t, unit quaternion w x y z), vos [W][P][7]
+ * with P = N-1 (consecutive pairs) or N(N-1)/2 (fc_vos: all pairs i<j in lexicographic order), out [W][N][7],
+ * status [W] (1 = the normal matrix was not positive definite, where scipy raises LinAlgError).  2 <= N <= 12.
+ * sax..srq are the covariances of optimize_poses; n_iters = 10 in the reference.  All pointers are device fp64. */
+int mn_pgo_optimize(const double* poses, const double* vos, double* out, int32_t* status, int W, int N, int fc_vos,
+                    double sax, double saq, double srx, double srq, int n_iters, void* stream);
+
 /* fused Adam over a flat range; replaces torch.optim.Adam.step + clip_grad_norm */
 int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip, float lr, float wd,
                float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm, double* sqnorm_scratch,

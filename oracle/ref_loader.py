@@ -13,6 +13,12 @@ What is executed unmodified:
     torch section is exec'd with `xrange = range` and those two import lines dropped.
   * common/pose_utils.py:306-327, :358-371  (numpy qlog/qexp and the angular-error metric used by
     scripts/eval.py), exec'd into the same namespace as `pose_utils_np`.
+  * common/pose_utils.py:373-804 (numpy pose-graph optimisation: skew, the Jacobian blocks, PoseGraph,
+    PoseGraphFC, optimize_poses) and :1146-1169 (`pgo_test_poses1`, the reference's own PGO fixture), exec'd as
+    `pgo` with `xrange = range`, `slin = scipy.linalg`, the Python-2 print statement at :799 written as a call,
+    and `txq` / `txe` bound to restatements of the transforms3d functions they use (oracle/pgo.py `txq`;
+    `euler2mat` in its default static-xyz convention R = Rz(ak) Ry(aj) Rx(ai); `mat2quat` from geomapnet_amd.data);
+    `skew` receives its 3x1 argument flattened (numpy >= 1.24 rejects the ragged nest the 2018 numpy accepted).
 `MapNetOnlineCriterion.forward` divides with `/` at :150 (Python-2 integer division); a
 subclass re-evaluates the same source with `//`.
 """
@@ -29,6 +35,49 @@ def available():
 
 
 _cache = {}
+
+
+def _load_pgo(all_lines, pose_utils, pose_utils_np):
+    """common/pose_utils.py:373-804 + :1146-1169 as a module (see the header)."""
+    import math as _math
+
+    import numpy as _np
+    import scipy.linalg as _slin
+
+    from . import pgo as _opgo
+
+    src = "\n".join(all_lines[372:804]) + "\n\n" + "\n".join(all_lines[1145:1169]) + "\n"
+    py2_print = "print 'Specify either VO or target poses'"
+    assert src.count(py2_print) == 1
+    src = src.replace(py2_print, "print('Specify either VO or target poses')")
+
+    def euler2mat(ai, aj, ak):
+        ci, si, cj, sj, ck, sk = _math.cos(ai), _math.sin(ai), _math.cos(aj), _math.sin(aj), _math.cos(ak), _math.sin(ak)
+        Rx = _np.array([[1, 0, 0], [0, ci, -si], [0, si, ci]])
+        Ry = _np.array([[cj, 0, sj], [0, 1, 0], [-sj, 0, cj]])
+        Rz = _np.array([[ck, -sk, 0], [sk, ck, 0], [0, 0, 1]])
+        return Rz @ Ry @ Rx
+
+    from geomapnet_amd.data import mat2quat as _mat2quat
+
+    class _txq(_opgo.txq):
+        mat2quat = staticmethod(_mat2quat)
+
+    class _txe:
+        pass
+
+    _txe.euler2mat = staticmethod(euler2mat)
+    mod = types.ModuleType("common.pose_utils_pgo_section")
+    import torch as _torch
+    mod.__dict__.update(np=_np, math=_math, slin=_slin, txq=_txq, txe=_txe, xrange=range, torch=_torch,
+                        qlog=pose_utils_np.qlog, qexp=pose_utils_np.qexp, calc_vos_safe_fc=pose_utils.calc_vos_safe_fc)
+    exec(compile(src, "reference:common/pose_utils.py[373:804,1146:1169]", "exec"), mod.__dict__)
+    # `skew` (:373-380) is called with 3x1 columns and builds its matrix from the 1-element rows x[i]; numpy of the
+    # reference's era converted those to scalars, numpy >= 1.24 refuses the ragged nest.  Same function on the
+    # flattened vector (x[i] then ARE scalars):
+    ref_skew = mod.skew
+    mod.skew = lambda x: ref_skew(_np.asarray(x).reshape(-1))
+    return mod
 
 
 def load():
@@ -68,6 +117,8 @@ def load():
     gi_ns = {"np": _np}
     exec(compile(gi_src, "reference:dataset_loaders/composite.py[get_indices]", "exec"), gi_ns)
 
+    pgo = _load_pgo(all_lines, pose_utils, pose_utils_np)
+
     saved = {k: sys.modules.get(k) for k in ("common", "common.pose_utils", "common.criterion")}
     pkg = types.ModuleType("common")
     pkg.__path__ = [os.path.join(REFERENCE_ROOT, "common")]
@@ -103,7 +154,7 @@ def load():
     class MapNetOnlineCriterionPy3(criterion.MapNetOnlineCriterion):
         forward = g["forward"]
 
-    ns = types.SimpleNamespace(mf_get_indices=gi_ns["get_indices"], pose_utils=pose_utils, pose_utils_np=pose_utils_np, criterion=criterion, posenet=posenet,
+    ns = types.SimpleNamespace(pgo=pgo, mf_get_indices=gi_ns["get_indices"], pose_utils=pose_utils, pose_utils_np=pose_utils_np, criterion=criterion, posenet=posenet,
                                MapNetOnlineCriterionPy3=MapNetOnlineCriterionPy3)
     _cache["ns"] = ns
     return ns

@@ -631,3 +631,122 @@ def check_u8_input(lib, dev, N=1, H=40, W=53):
     assert (p.cpu() - po.detach()).abs().max().item() <= 2e-3 * max(1.0, po.abs().max().item())
     net.set_input_u8(None)
     assert net.mapnet._engine.input_u8 is None
+
+
+# ---- pose-graph optimisation (csrc/pgo.h vs oracle/pgo.py and the golden vectors of the reference) -------------
+PGO_TOL = 1e-9  # fp64 on both sides; the only differences are summation order and libm vs device sin/cos/sqrt
+
+
+def check_pgo_golden(lib, dev, golden_dir):
+    """every case of tests/golden/pgo.npz (outputs of the reference's PoseGraph / PoseGraphFC, incl. its own fixture
+    pgo_test_poses1): batched launch per case, one-window wrappers, optimize_poses with VOs from target poses"""
+    from geomapnet_amd import pgo as P
+    g = np.load(os.path.join(golden_dir, "pgo.npz"))
+    for tag in g["cases"]:
+        cfg = g[tag + "/cfg"]
+        N, fc, sig = int(cfg[0]), bool(cfg[1]), cfg[2:]
+        got = P.optimize_windows(g[tag + "/pred"], g[tag + "/vos"], fc_vos=fc, sax=sig[0], saq=sig[1], srx=sig[2], srq=sig[3],
+                                 device=dev, binding=lib)
+        err = np.abs(got - g[tag + "/opt"]).max()
+        assert err <= PGO_TOL, (tag, err)
+        # the optimisation does something: the result differs from its initialisation
+        assert np.abs(got - g[tag + "/pred"]).max() > 1e-3
+        # one-window class interface (reference signatures)
+        cls = P.PoseGraphFC if fc else P.PoseGraph
+        one = cls(device=dev, binding=lib).optimize(g[tag + "/pred"][0], g[tag + "/vos"][0], sax=sig[0], saq=sig[1], srx=sig[2],
+                                                    srq=sig[3])
+        assert np.abs(one - g[tag + "/opt"][0]).max() <= PGO_TOL
+    # the reference's own fixture: chain graph handed the 3 fully connected VOs, reads the first two
+    fx = P.optimize_poses(g["fixture/poses"], vos=g["fixture/vos"], device=dev, binding=lib)
+    assert np.abs(fx - g["fixture/opt"]).max() <= PGO_TOL
+    ft = P.optimize_poses(g["from_targets/pred"], target_poses=g["from_targets/targ"], srx=0.5, srq=0.5, device=dev, binding=lib)
+    assert np.abs(ft - g["from_targets/opt"]).max() <= PGO_TOL
+    assert P.optimize_poses(g["fixture/poses"], device=dev, binding=lib) is None  # neither VOs nor targets (:798-800)
+
+
+def pgo_windows(W, N, fc, seed, noise=0.05):
+    """seeded windows: smooth trajectory, exact VOs, noisy predictions (numpy only)"""
+    rng = np.random.default_rng(seed)
+
+    def qmul(a, b):
+        w1, x1, y1, z1 = np.moveaxis(a, -1, 0)
+        w2, x2, y2, z2 = np.moveaxis(b, -1, 0)
+        return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                         w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2, w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2], axis=-1)
+
+    def small(shape, s):
+        d = np.concatenate([np.ones(shape + (1,)), rng.normal(size=shape + (3,)) * s], axis=-1)
+        return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+    t = np.cumsum(rng.normal(size=(W, N, 3)) * 0.3, axis=1)
+    q = np.zeros((W, N, 4))
+    q0 = rng.normal(size=(W, 4))
+    q[:, 0] = q0 / np.linalg.norm(q0, axis=-1, keepdims=True)
+    for i in range(1, N):
+        q[:, i] = qmul(q[:, i - 1], small((W,), 0.1))
+    pairs = [(i, j) for i in range(N) for j in range(i + 1, N)] if fc else [(i, i + 1) for i in range(N - 1)]
+    vos = np.zeros((W, len(pairs), 7))
+    conj = np.array([1.0, -1, -1, -1])
+    for k, (i, j) in enumerate(pairs):
+        qi = q[:, i] * conj
+        v = np.concatenate([np.zeros((W, 1)), t[:, j] - t[:, i]], axis=-1)
+        vos[:, k, :3] = qmul(qi, qmul(v, q[:, i]))[:, 1:]
+        vos[:, k, 3:] = qmul(qi, q[:, j])
+    gt = np.concatenate([t, q], axis=-1)
+    pred = gt.copy()
+    pred[..., :3] += rng.normal(size=(W, N, 3)) * noise
+    pred[..., 3:] = qmul(pred[..., 3:], small((W, N), noise))
+    return pred, vos, gt
+
+
+def check_pgo_vs_oracle(lib, dev, W=5, N=7, fc=False, seed=11, sig=(1.0, 1.0, 1.0, 1.0)):
+    from geomapnet_amd import pgo as P
+    from oracle import pgo as opgo
+    pred, vos, _ = pgo_windows(W, N, fc, seed)
+    got = P.optimize_windows(pred, vos, fc_vos=fc, sax=sig[0], saq=sig[1], srx=sig[2], srq=sig[3], device=dev, binding=lib)
+    for w in range(W):
+        want = opgo.optimize_window(pred[w], vos[w], fc=fc, sax=sig[0], saq=sig[1], srx=sig[2], srq=sig[3])
+        assert np.abs(got[w] - want).max() <= PGO_TOL, (w, np.abs(got[w] - want).max())
+
+
+def check_pgo_properties(lib, dev, W=4096, N=7, fc=True, seed=3):
+    """size-independent properties at evaluation-set scale: (1) exact poses with their exact VOs are a fixed point
+    (all residuals vanish, so every step is zero); (2) windows are independent: a window's result does not depend on
+    the batch it is launched in; (3) error handling: a non-finite window is reported, the others are unaffected"""
+    from geomapnet_amd import pgo as P
+    pred, vos, gt = pgo_windows(W, N, fc, seed)
+    fixed = P.optimize_windows(gt, vos, fc_vos=fc, device=dev, binding=lib)
+    assert np.abs(fixed - gt).max() <= 1e-12
+    full = P.optimize_windows(pred, vos, fc_vos=fc, srx=0.5, srq=0.5, device=dev, binding=lib)
+    sel = np.array([0, 1, W // 2, W - 1])
+    part = P.optimize_windows(pred[sel], vos[sel], fc_vos=fc, srx=0.5, srq=0.5, device=dev, binding=lib)
+    assert np.array_equal(full[sel], part)
+    assert np.isfinite(full).all()
+    # with exact VOs and a strong relative term the optimised trajectory is closer to the truth than the prediction
+    e0 = np.linalg.norm(pred[..., :3] - gt[..., :3], axis=-1).mean()
+    e1 = np.linalg.norm(full[..., :3] - gt[..., :3], axis=-1).mean()
+    assert e1 < e0, (e0, e1)
+    bad = pred[:3].copy()
+    bad[1, 2, 3:] = np.nan
+    try:
+        P.optimize_windows(bad, vos[:3], fc_vos=fc, device=dev, binding=lib)
+        raise AssertionError("a NaN window must raise LinAlgError")
+    except np.linalg.LinAlgError as e:
+        assert "[1]" in str(e)
+    for n_bad in (1, 13):
+        try:
+            P.optimize_windows(np.ones((1, n_bad, 7)), np.ones((1, n_bad * (n_bad - 1) // 2, 7)), fc_vos=True, device=dev,
+                               binding=lib)
+            raise AssertionError("window length out of range must be rejected")
+        except lib_error():
+            pass
+    try:
+        P.optimize_windows(pred[:2], vos[:2, :3], fc_vos=fc, device=dev, binding=lib)
+        raise AssertionError("too few VOs must be rejected")
+    except ValueError:
+        pass
+
+
+def lib_error():
+    from geomapnet_amd._binding import MapNetHipError
+    return MapNetHipError

@@ -82,8 +82,71 @@ def make_batch_construction(ns):
     np.savez_compressed(os.path.join(HERE, "batch_construction.npz"), **out)
 
 
+def pgo_window(rng, N, fc, noise):
+    """a smooth ground-truth trajectory, its exact VOs (chain or all pairs) and a noisy prediction of it"""
+    from oracle import pgo as opgo
+    t = np.cumsum(rng.normal(size=(N, 3)) * 0.3, axis=0)
+    q = np.zeros((N, 4))
+    q[0] = rng.normal(size=4)
+    q[0] /= np.linalg.norm(q[0])
+    for i in range(1, N):
+        dq = np.r_[1.0, rng.normal(size=3) * 0.1]
+        q[i] = opgo.txq_qmult(q[i - 1], dq / np.linalg.norm(dq))
+    gt = np.hstack([t, q])
+    pr = opgo.pairs(N, fc)
+    vos = np.zeros((len(pr), 7))
+    for k, (i, j) in enumerate(pr):
+        vos[k, :3] = opgo.txq_rotate_vector(gt[j, :3] - gt[i, :3], opgo.txq_qinverse(gt[i, 3:]))
+        vos[k, 3:] = opgo.txq_qmult(opgo.txq_qinverse(gt[i, 3:]), gt[j, 3:])
+    vos[:, :3] += rng.normal(size=(len(pr), 3)) * 0.2 * noise
+    pred = gt.copy()
+    pred[:, :3] += rng.normal(size=(N, 3)) * noise
+    for i in range(N):
+        dq = np.r_[1.0, rng.normal(size=3) * noise]
+        pred[i, 3:] = opgo.txq_qmult(pred[i, 3:], dq / np.linalg.norm(dq))
+    return pred, vos, gt
+
+
+def make_pgo(ns):
+    """pose-graph optimisation (common/pose_utils.py:458-804) executed from the reference source: its own fixture
+    `pgo_test_poses1` (:1146-1169, as `test_pgo` :1179-1195 runs it: fully connected VOs handed to the chain
+    graph, which reads the first two) and seeded windows for the chain / fully connected graphs, several window
+    lengths and covariances, and `optimize_poses` with VOs derived from target poses"""
+    P = ns.pgo
+    out = {}
+    poses, vos = P.pgo_test_poses1()
+    out["fixture/poses"], out["fixture/vos"] = poses, vos
+    out["fixture/opt"] = P.PoseGraph().optimize(poses, vos)
+    rng = np.random.default_rng(20180618)
+    cases = []
+    for tag, N, fc, sig, nwin, noise in (("chain7", 7, False, (1, 1, 1, 1), 6, 0.05), ("fc7", 7, True, (1, 1, 1, 1), 6, 0.05),
+                                         ("chain7_sig", 7, False, (0.5, 2.0, 0.25, 4.0), 3, 0.1),
+                                         ("fc7_sig", 7, True, (2.0, 0.5, 20.0, 20.0), 3, 0.1),
+                                         ("chain2", 2, False, (1, 1, 1, 1), 2, 0.05), ("fc3", 3, True, (1, 1, 1, 1), 2, 0.05),
+                                         ("chain12", 12, False, (1, 1, 1, 1), 2, 0.03), ("fc12", 12, True, (1, 1, 3.0, 3.0), 2, 0.03)):
+        preds, voss, opts = [], [], []
+        for _ in range(nwin):
+            pred, v, _gt = pgo_window(rng, N, fc, noise)
+            g = P.PoseGraphFC() if fc else P.PoseGraph()
+            opts.append(g.optimize(pred, v, sax=sig[0], saq=sig[1], srx=sig[2], srq=sig[3]))
+            preds.append(pred)
+            voss.append(v)
+        out[tag + "/pred"], out[tag + "/vos"], out[tag + "/opt"] = np.stack(preds), np.stack(voss), np.stack(opts)
+        out[tag + "/cfg"] = np.asarray([N, int(fc)] + list(sig), dtype=np.float64)
+        cases.append(tag)
+    pred, _v, gt = pgo_window(rng, 7, False, 0.05)
+    out["from_targets/pred"], out["from_targets/targ"] = pred, gt
+    out["from_targets/opt"] = P.optimize_poses(pred, target_poses=gt, srx=0.5, srq=0.5)
+    out["cases"] = np.asarray(cases)
+    np.savez_compressed(os.path.join(HERE, "pgo.npz"), **out)
+
+
 def main():
     ns = ref_loader.load()
+    if sys.argv[1:] == ["pgo"]:
+        make_pgo(ns)
+        print("wrote pgo.npz")
+        return
     if sys.argv[1:] == ["eval_metric"]:
         make_eval_metric(ns)
         print("wrote eval_metric.npz")
@@ -94,6 +157,7 @@ def main():
         return
     make_eval_metric(ns)
     make_batch_construction(ns)
+    make_pgo(ns)
     C = ns.criterion
     gen = torch.Generator().manual_seed(1234)
     cases = {}

@@ -91,3 +91,17 @@ def test_calc_vos_against_reference_golden(lib, golden_dir):
 @pytest.mark.parametrize("max_norm", [0.0, 5.0])
 def test_fused_adam(lib, max_norm):
     checks.check_adam(lib, DEV, max_norm=max_norm)
+
+
+def test_pose_graph_golden(lib, golden_dir):
+    checks.check_pgo_golden(lib, DEV, golden_dir)
+
+
+@pytest.mark.parametrize("N,fc,sig", [(7, False, (1.0, 1.0, 1.0, 1.0)), (7, True, (0.5, 2.0, 20.0, 20.0)), (2, False, (1.0, 1.0, 1.0, 1.0)),
+                                      (12, True, (1.0, 1.0, 2.0, 2.0))])
+def test_pose_graph_vs_oracle(lib, N, fc, sig):
+    checks.check_pgo_vs_oracle(lib, DEV, W=3, N=N, fc=fc, sig=sig)
+
+
+def test_pose_graph_properties(lib):
+    checks.check_pgo_properties(lib, DEV, W=24, N=7, fc=True)

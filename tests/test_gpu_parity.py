@@ -223,3 +223,18 @@ def test_full_size_training_is_finite_and_learns(lib):
     sd = net.state_dict()
     assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype == torch.float32)
     assert int(sd["mapnet.feature_extractor.bn1.num_batches_tracked"]) == 6
+
+
+def test_pose_graph_golden(lib, golden_dir):
+    checks.check_pgo_golden(lib, DEV, golden_dir)
+
+
+@pytest.mark.parametrize("N,fc,sig", [(7, False, (1.0, 1.0, 1.0, 1.0)), (7, True, (0.5, 2.0, 20.0, 20.0)), (2, False, (1.0, 1.0, 1.0, 1.0)),
+                                      (12, True, (1.0, 1.0, 2.0, 2.0)), (3, True, (1.0, 1.0, 1.0, 1.0))])
+def test_pose_graph_vs_oracle(lib, N, fc, sig):
+    checks.check_pgo_vs_oracle(lib, DEV, W=16, N=N, fc=fc, sig=sig)
+
+
+@pytest.mark.parametrize("fc", [False, True])
+def test_pose_graph_properties_at_eval_set_scale(lib, fc):
+    checks.check_pgo_properties(lib, DEV, W=4096, N=7, fc=fc)

@@ -114,3 +114,24 @@ def test_eval_metric_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(q, g["pred7"][:, 3:], rtol=0, atol=1e-15)
     err = [pose_math.quaternion_angular_error(a, b) for a, b in zip(g["pred7"][:, 3:], g["targ7"][:, 3:])]
     np.testing.assert_allclose(err, g["q_loss"], rtol=0, atol=1e-12)
+
+
+def test_pose_graph_oracle_matches_reference_golden(golden_dir):
+    """oracle/pgo.py vs outputs of the reference's PoseGraph / PoseGraphFC / optimize_poses (tests/golden/pgo.npz,
+    generated by tests/golden/make_golden.py from /root/reference/common/pose_utils.py:458-804 and its fixture
+    pgo_test_poses1): same operations in the same order, so the match is exact up to BLAS summation order"""
+    from oracle import pgo as opgo
+    g = np.load(os.path.join(golden_dir, "pgo.npz"))
+    for tag in g["cases"]:
+        cfg = g[tag + "/cfg"]
+        for pred, vos, opt in zip(g[tag + "/pred"], g[tag + "/vos"], g[tag + "/opt"]):
+            got = opgo.optimize_window(pred, vos, fc=bool(cfg[1]), sax=cfg[2], saq=cfg[3], srx=cfg[4], srq=cfg[5])
+            np.testing.assert_allclose(got, opt, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(opgo.optimize_window(g["fixture/poses"], g["fixture/vos"]), g["fixture/opt"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(opgo.optimize_poses(g["from_targets/pred"], target_poses=g["from_targets/targ"], srx=0.5, srq=0.5),
+                               g["from_targets/opt"], rtol=0, atol=1e-12)
+    # the fixture's expected behaviour (pose_utils.py:1146-1169): the perturbed VO translations pull the two outer
+    # poses towards the middle one along the diagonal, rotations untouched
+    opt = g["fixture/opt"]
+    np.testing.assert_allclose(opt[:, 3:], g["fixture/poses"][:, 3:], atol=1e-12)
+    assert opt[0, 0] > 0.1 and opt[2, 0] < 1.9 and abs(opt[1, 0] - 1.0) < 1e-6

@@ -5,14 +5,18 @@
 // batch variance for normalisation, eps inside the sqrt, running stats updated with momentum
 // using the unbiased variance.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 #include "pool.h"
 
 namespace mn {
 
 inline int ew_grid(long work_items) {
+  // grid-stride kernels: at most 16 workgroups per CU (MN_EW_WGS_PER_CU, tuning knob: fewer leave wave slots to the
+  // weight-gradient workgroups that run beside the HBM-bound passes)
+  static const int per_cu = getenv("MN_EW_WGS_PER_CU") ? atoi(getenv("MN_EW_WGS_PER_CU")) : 16;
   long b = (work_items + 255) / 256;
-  if (b > 256 * 16) b = 256 * 16;
+  if (b > 256L * per_cu) b = 256L * per_cu;
   if (b < 1) b = 1;
   return (int)b;
 }

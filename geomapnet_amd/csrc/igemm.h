@@ -594,6 +594,12 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
     cfg = (g.N >= 128 && g.N % 128 == 0 && tiles128 > 512 && tiles128 <= 640) ? 8 : 1;
   }
   if (g.N <= 64) {
+    // MN_N64_CONFIG (tuning knob): alternatives for the 64-channel layers (layer1: K = 576 = 9 K-steps per tile)
+    static const int n64 = getenv("MN_N64_CONFIG") ? atoi(getenv("MN_N64_CONFIG")) : 0;
+    if (wide_k && n64 == 1) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 3-deep ring
+    if (n64 == 2) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);  // 64-byte steps, 4-deep
+    if (n64 == 3) return launch_igemm_cfg<T, 4, 1, 2, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 256x64, 64x64 wave tiles
+    if (wide_k && n64 == 4) return launch_igemm_cfg<T, 2, 1, 2, 2, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);  // 2 waves of 64x64
     if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
     return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
   }

@@ -121,9 +121,20 @@ struct PlanBase {
     static hipStream_t streams[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
-      streams[dev] = nullptr;
-      (void)hipGetLastError();
+    if (!streams[dev]) {
+      // MN_SIDE_PRIORITY (tuning knob): -1 = lowest priority (weight gradients only fill what the data-gradient
+      // chain leaves idle), 1 = highest, 0 / unset = default
+      const int pr = getenv("MN_SIDE_PRIORITY") ? atoi(getenv("MN_SIDE_PRIORITY")) : 0;
+      int least = 0, greatest = 0;
+      hipError_t e = hipSuccess;
+      if (pr != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        e = hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, pr < 0 ? least : greatest);
+      else
+        e = hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking);
+      if (e != hipSuccess) {
+        streams[dev] = nullptr;
+        (void)hipGetLastError();
+      }
     }
     return streams[dev];
   }
@@ -165,7 +176,12 @@ struct PlanBase {
     wgrad_pending = false;
   }
   GraphSeg segs[8];
-  bool graphs_ok = !(getenv("MN_GRAPHS") && atoi(getenv("MN_GRAPHS")) == 0);
+  // hipGraph replay of the step is opt-in (MN_GRAPHS=1).  Measured on MI355X / ROCm 7.2 (tools/ab.sh): replaying the
+  // captured step is 2 % SLOWER than enqueueing its ~250 launches directly (19.57 vs 19.17 ms; the host enqueues a
+  // step in ~1.5 ms and stays a full step ahead of the device), forked branches overlap less inside a graph (early
+  // weight-gradient forks: +0.3 % in a graph, -2.4 % eager) and a side stream with a non-default priority costs a
+  // graph +1.5 ms.
+  bool graphs_ok = getenv("MN_GRAPHS") && atoi(getenv("MN_GRAPHS")) != 0;
   unsigned long long fwd_key = 0;  // identity of the buffers the last training forward was issued on
   unsigned long long hyper_version = 1;
   template <typename F>
@@ -643,6 +659,7 @@ struct Plan : PlanBase {
   bool fuse_stem = (fuse_stem_mask & 1) != 0;
   bool fuse_stem_bwd = (fuse_stem_mask & 2) != 0;
   bool self_gate_ok = !(getenv("MN_SELF_GATE") && atoi(getenv("MN_SELF_GATE")) == 0);
+  bool early_fork = !(getenv("MN_EARLY_FORK") && atoi(getenv("MN_EARLY_FORK")) == 0);
   // `ws`: the stream the launch goes to (the side stream after a fork, or the main stream)
   void conv_wgrad(Unit& u, const T* x, hipStream_t ws) {
     WgradArgs a;
@@ -668,13 +685,18 @@ struct Plan : PlanBase {
   void block_backward(Block& blk, hipStream_t s) {
     // gm = gout * (out > 0) feeds bn2 (and bn_d); see DESIGN.md section 4
     bn_bwd(blk.u2, blk.gout, blk.out, s);
+    // every weight gradient is forked as soon as its dY exists, so that its workgroups are available as filler during
+    // the HBM-bound BatchNorm-backward passes that follow (-2.4 % step time vs one fork per block; MN_EARLY_FORK=0
+    // restores that)
+    const bool early = early_fork;
+    if (early) conv_wgrad(blk.u2, blk.a1, fork_wgrad(s));
     conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
     bn_bwd(blk.u1, blk.ga1, blk.a1, s, true);
     if (blk.down) bn_bwd(blk.ud, blk.gout, blk.out, s);
     // ONE fork per block (forking per launch measured the same): all its weight gradients go to the side stream
     // while the main stream finishes the block's data gradient and runs the next block's chain
     hipStream_t ws = fork_wgrad(s);
-    conv_wgrad(blk.u2, blk.a1, ws);
+    if (!early) conv_wgrad(blk.u2, blk.a1, ws);
     conv_wgrad(blk.u1, blk.x, ws);
     if (blk.down) {
       conv_wgrad(blk.ud, blk.x, ws);

@@ -106,6 +106,15 @@ def test_mapnet_train_step_fp32_parity_stem_variants(lib, monkeypatch, mask):
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=1, loss_rtol=1e-4, pose_atol=2e-3)
 
 
+def test_mapnet_train_step_fp32_parity_graph_replay(lib, monkeypatch):
+    """MN_GRAPHS=1: the step captured into a hipGraph (first step) and replayed (second step) -- opt-in; also with one
+    weight-gradient fork per block"""
+    monkeypatch.setenv("MN_GRAPHS", "1")
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+    monkeypatch.setenv("MN_EARLY_FORK", "0")
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+
+
 def test_mapnet_train_step_fp32_parity_full_resolution(lib):
     """(N=2, T=3, 3, 256, 341): north-star tolerances 1e-4 on loss (relative, |loss| > 1) and 1e-3 on pose"""
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3)

@@ -33,6 +33,8 @@ def timeit(fn, n=10):
 
 
 def bench(name, H, W, Ci, Co, k, stride, pad):
+    if os.environ.get("CB_MATCH") and os.environ["CB_MATCH"] not in name:
+        return
     g, Ho, Wo = checks.fwd_geom(B, H, W, Ci, Co, k, stride, pad)
     gd, _, _ = checks.dgrad_geom(B, H, W, Ci, Co, k, stride, pad)
     x = torch.randn(B, H, W, Ci, device="cuda").to(td)

@@ -155,11 +155,14 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int WTM = TM * 32, WTN = TN * 32;
   constexpr int RPP = NT / NP;  // rows covered by one DMA pass of all threads
-  constexpr int APT = BM / RPP, BPT = BN / RPP;
+  // B passes are rounded up: rows past BN of the last pass are zero-filled by the bounds check (no fetch) into LDS rows
+  // nobody reads (BNA allocated rows), so that thread counts that do not divide BN (12 waves, BN = 256) work
+  constexpr int APT = BM / RPP, BPT = (BN + RPP - 1) / RPP;
+  constexpr int BNA = BPT * RPP;
   constexpr int IPT = APT + BPT;  // DMA instructions per wave per tile
-  constexpr int TILE_PIECES = (BM + BN) * NP;
+  constexpr int TILE_PIECES = (BM + BNA) * NP;
   constexpr int D = NBUF - 1;  // tiles in flight
-  static_assert(APT >= 1 && BPT >= 1, "tile too small for the thread count");
+  static_assert(APT >= 1 && APT * RPP == BM, "A rows must be a whole number of DMA passes");
   static_assert(D >= 1 && D <= 3, "ring depth");
   static_assert(RPP % 16 == 0, "swizzle must not see the per-thread row stride");
   static_assert(NBUF * TILE_PIECES * 16 >= 64 * (BN < 128 ? BN : 128) * 4, "epilogue staging does not fit");
@@ -250,7 +253,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #pragma unroll
   for (int i = 0; i < BPT; ++i) {
     const int n = n0 + lrow + i * RPP;
-    b_off[i] = n < g.N ? (unsigned)(n * g.K) * (unsigned)sizeof(T) + (unsigned)src_piece * 16u : ~0u;
+    b_off[i] = (n < g.N && lrow + i * RPP < BN) ? (unsigned)(n * g.K) * (unsigned)sizeof(T) + (unsigned)src_piece * 16u : ~0u;
   }
   // running decomposition of the step's first piece (uniform walk) or of this lane's piece (per-lane walk)
   // into (tap = (tr, ts), channel piece cpi)
@@ -416,7 +419,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   // rounds: (tile row i of each wave) x (pairs of wave rows) x (128-column blocks)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
-    for (int mh = 0; mh < WM / 2; ++mh)
+    for (int mh = 0; mh < (WM + 1) / 2; ++mh)
       for (int nh = 0; nh < BN / SC; ++nh) {
         if ((wm >> 1) == mh) {
 #pragma unroll
@@ -443,7 +446,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
           const int lr = id / CPR, cpc = id % CPR;
           const int row = m0 + (2 * mh + (lr >> 5)) * WTM + i * 32 + (lr & 31);
           const int col = n0 + nh * SC + cpc * VEC;
-          if (lr < 64 && row < g.M && col < g.N) {
+          if (lr < 64 && 2 * mh + (lr >> 5) < WM && row < g.M && col < g.N) {
             float v[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; e += 4) {
@@ -592,14 +595,14 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
   if (cfg == 0) {
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
     cfg = (g.N >= 128 && g.N % 128 == 0 && tiles128 > 512 && tiles128 <= 640) ? 8 : 1;
+    // 288x256 tiles when they cover the problem in ONE round of one workgroup per CU (layer3 at B = 192: 235 tiles
+    // instead of 1056 128x128 tiles = 2.06 rounds of 512; 92 vs 110-118 us)
+    const long tiles288 = (long)cdiv(g.M, 288) * cdiv(g.N, 256);
+    if (wide_k && g.N % 256 == 0 && tiles128 > 512 && tiles288 > 192 && tiles288 <= igemm_sk_blocks() / 2) cfg = 12;
   }
   if (g.N <= 64) {
-    // MN_N64_CONFIG (tuning knob): alternatives for the 64-channel layers (layer1: K = 576 = 9 K-steps per tile)
-    static const int n64 = getenv("MN_N64_CONFIG") ? atoi(getenv("MN_N64_CONFIG")) : 0;
-    if (wide_k && n64 == 1) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 3-deep ring
-    if (n64 == 2) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);  // 64-byte steps, 4-deep
-    if (n64 == 3) return launch_igemm_cfg<T, 4, 1, 2, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);  // 256x64, 64x64 wave tiles
-    if (wide_k && n64 == 4) return launch_igemm_cfg<T, 2, 1, 2, 2, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);  // 2 waves of 64x64
+    // (measured and removed for the 64-channel layers: 3-deep ring, 64-byte steps with a 4-deep ring, 256x64 tiles of
+    // 64x64 wave tiles, 2-wave workgroups of 64x64 wave tiles: 145 us -> 157..183 us on layer1)
     if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
     return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
   }
@@ -608,6 +611,11 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
   if (cfg == 10 && g.N >= 256 && g.N % 128 == 0)  // 256x256, 4 waves of 128x128 (one wave per SIMD)
     return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 3, 1>(g, A, Bw, ep, stream, zero_page);
   if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);  // 256x128, 8 waves
+  // 288x256, 12 waves of 96x64, 128-byte K-steps, 2 buffers, one workgroup per CU: M = B*P*Q of the 256x341 input at
+  // B = 192 is 132 * 2^k, and 288-row tiles put layer3 (67584 rows, N = 256) on 235 of the 256 CUs in ONE round
+  if (cfg == 12 && wide_k && g.N % 256 == 0) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);
+  // 288x128, 6 waves of 96x64, 64-byte K-steps, 2 buffers, two workgroups per CU (independent phases)
+  if (cfg == 13 && g.N % 128 == 0) return launch_igemm_cfg<T, 3, 2, 3, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);
   if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
   return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
 }

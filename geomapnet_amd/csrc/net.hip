@@ -121,20 +121,10 @@ struct PlanBase {
     static hipStream_t streams[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!streams[dev]) {
-      // MN_SIDE_PRIORITY (tuning knob): -1 = lowest priority (weight gradients only fill what the data-gradient
-      // chain leaves idle), 1 = highest, 0 / unset = default
-      const int pr = getenv("MN_SIDE_PRIORITY") ? atoi(getenv("MN_SIDE_PRIORITY")) : 0;
-      int least = 0, greatest = 0;
-      hipError_t e = hipSuccess;
-      if (pr != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-        e = hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, pr < 0 ? least : greatest);
-      else
-        e = hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking);
-      if (e != hipSuccess) {
-        streams[dev] = nullptr;
-        (void)hipGetLastError();
-      }
+    // (a side stream of lower or higher priority was measured: no gain with direct launches, +1.5 ms inside a graph)
+    if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
+      streams[dev] = nullptr;
+      (void)hipGetLastError();
     }
     return streams[dev];
   }
@@ -520,13 +510,16 @@ struct Plan : PlanBase {
   }
   // head = stem + layer1 weights (needed first), tail = everything else; the tail can run on the side stream
   // while the stem and layer1 execute
-  void repack(hipStream_t s_head, hipStream_t s_tail) {
+  void repack_head(hipStream_t s) {
     const int hj = repack_head_jobs > 0 ? repack_head_jobs : repack_njobs;
     const int hb = repack_head_jobs > 0 ? repack_head_blocks : repack_blocks;
-    hipLaunchKernelGGL((repack_all_kernel<T>), dim3(hb), dim3(256), 0, s_head, (const RepackJob*)repack_jobs, hj,
+    hipLaunchKernelGGL((repack_all_kernel<T>), dim3(hb), dim3(256), 0, s, (const RepackJob*)repack_jobs, hj,
                        (const float*)params, 0);
+  }
+  void repack_tail(hipStream_t s) {
+    const int hb = repack_head_jobs > 0 ? repack_head_blocks : repack_blocks;
     if (repack_blocks > hb)
-      hipLaunchKernelGGL((repack_all_kernel<T>), dim3(repack_blocks - hb), dim3(256), 0, s_tail,
+      hipLaunchKernelGGL((repack_all_kernel<T>), dim3(repack_blocks - hb), dim3(256), 0, s,
                          (const RepackJob*)repack_jobs, repack_njobs, (const float*)params, hb);
     weights_dirty = false;
   }
@@ -571,11 +564,8 @@ struct Plan : PlanBase {
   int forward_impl(const void* images, float* poses_out, int training, bool zero_grads, hipStream_t s) {
     // work the stem and layer1 do not depend on goes to the side stream: the repack of the later layers'
     // weights and optim.learner.zero_grad(); joined before layer2
-    if (weights_dirty || zero_grads) {
-      hipStream_t side = fork_wgrad(s);
-      if (weights_dirty) repack(s, side);
-      if (zero_grads) hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, side);
-    }
+    const bool dirty = weights_dirty;
+    if (dirty) repack_head(s);
     grads_zeroed = zero_grads;
     cur_training = training;
     if (training) hipMemsetAsync(acc_region, 0, acc_bytes, s);  // forward statistics + backward reduction sums
@@ -585,6 +575,13 @@ struct Plan : PlanBase {
     else
       hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
                          (const float*)images, xpad, B, H, W, Hp, Wp);
+    // forked AFTER the (HBM-bound) input conversion, so that the side stream's copies run beside the stem's MFMA-bound
+    // convolution instead of competing with the conversion for bandwidth (step time: equal within noise)
+    if (dirty || zero_grads) {
+      hipStream_t side = fork_wgrad(s);
+      if (dirty) repack_tail(side);
+      if (zero_grads) hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, side);
+    }
     conv_bn_stats(stem, xpad, training, s);
     if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
       hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
@@ -682,19 +679,48 @@ struct Plan : PlanBase {
     launch_igemm<T>(u.gd, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page);
     timer.end(tp, s);
   }
+  // Weight-gradient schedule (MN_WGRAD_SCHED): 0 = one fork per block, after its last BatchNorm backward;
+  // 1 = each weight gradient forked as soon as its dY exists (starts beside the data gradient that consumes the
+  // same dY); 2 = deferred: a weight gradient is queued and forked right before the NEXT BatchNorm-backward pass of
+  // the main stream, so that the MFMA-bound launch starts beside HBM-bound work instead of beside a data gradient.
+  int wgrad_sched = getenv("MN_WGRAD_SCHED") ? atoi(getenv("MN_WGRAD_SCHED")) : (early_fork ? 1 : 0);
+  struct PendingWgrad {
+    Unit* u;
+    const T* x;
+  };
+  std::vector<PendingWgrad> pending_wgrads;
+  void flush_wgrads(hipStream_t s) {
+    if (pending_wgrads.empty()) return;
+    hipStream_t ws = fork_wgrad(s);
+    for (auto& p : pending_wgrads) conv_wgrad(*p.u, p.x, ws);
+    pending_wgrads.clear();
+  }
   void block_backward(Block& blk, hipStream_t s) {
     // gm = gout * (out > 0) feeds bn2 (and bn_d); see DESIGN.md section 4
+    if (wgrad_sched == 2) {
+      flush_wgrads(s);
+      bn_bwd(blk.u2, blk.gout, blk.out, s);
+      conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
+      pending_wgrads.push_back({&blk.u2, blk.a1});
+      flush_wgrads(s);
+      bn_bwd(blk.u1, blk.ga1, blk.a1, s, true);
+      if (blk.down) bn_bwd(blk.ud, blk.gout, blk.out, s);
+      pending_wgrads.push_back({&blk.u1, blk.x});
+      if (blk.down) {
+        pending_wgrads.push_back({&blk.ud, blk.x});
+        conv_dgrad(blk.u1, blk.gx, nullptr, nullptr, s);
+        conv_dgrad(blk.ud, blk.gx, blk.gx, nullptr, s);
+      } else {
+        conv_dgrad(blk.u1, blk.gx, blk.gout, blk.out, s);
+      }
+      return;
+    }
     bn_bwd(blk.u2, blk.gout, blk.out, s);
-    // every weight gradient is forked as soon as its dY exists, so that its workgroups are available as filler during
-    // the HBM-bound BatchNorm-backward passes that follow (-2.4 % step time vs one fork per block; MN_EARLY_FORK=0
-    // restores that)
-    const bool early = early_fork;
+    const bool early = wgrad_sched == 1;
     if (early) conv_wgrad(blk.u2, blk.a1, fork_wgrad(s));
     conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
     bn_bwd(blk.u1, blk.ga1, blk.a1, s, true);
     if (blk.down) bn_bwd(blk.ud, blk.gout, blk.out, s);
-    // ONE fork per block (forking per launch measured the same): all its weight gradients go to the side stream
-    // while the main stream finishes the block's data gradient and runs the next block's chain
     hipStream_t ws = fork_wgrad(s);
     if (!early) conv_wgrad(blk.u2, blk.a1, ws);
     conv_wgrad(blk.u1, blk.x, ws);
@@ -761,8 +787,10 @@ struct Plan : PlanBase {
     for (int i = (int)blocks.size() - 1; i >= 0; --i)
       if (blocks[i].stage == stage) block_backward(blocks[i], s);
     if (stage == 0) {
+      flush_wgrads(s);  // beside the stem's BatchNorm backward
       stem_backward(s);
     }
+    flush_wgrads(s);
     join_wgrad(s);  // the stage's gradient bucket is complete when this call's work on s is
     return check_launch("backward_stage");
   }

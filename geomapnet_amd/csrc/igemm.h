@@ -145,7 +145,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 2.06 rounds of work instead of 2 / 3.  A workgroup whose range covers only part of a tile adds its fp32
 // accumulators to its own workspace slab and bumps the tile's arrival counter; the second of the two workgroups
 // that share a tile adds the other's slab and runs the normal epilogue.  Nobody waits for anybody.
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SK = false>
+// SPL: the NBUF-1-ahead tile's DMA instructions are not issued in one burst after the barrier but spread over the
+// K-step's MFMA sub-steps (behind each sub-step's MFMAs), so that the first fragment reads and MFMAs of a K-step do not
+// queue behind the burst.
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SK = false, bool SPL = false>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                          const T* __restrict__ zero_page, RowDiv rd,
@@ -276,29 +279,36 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   unsigned b_step = (unsigned)k0 * NP * 16;  // byte offset of the K-step inside a weight row (scalar)
   const unsigned lds_wave = wave * 64;  // this wave's 64 pieces of DMA pass 0 inside a tile
 
-  auto issue_tile = [&](int buf) {
+  // instructions [j0, j1) of the tile's IPT DMA instructions (A passes first, then B passes); the tap walk advances
+  // when the last one has been issued
+  auto issue_part = [&](int buf, int j0, int j1) {
     piece_t* base = &smem[buf * TILE_PIECES + lds_wave];
     const unsigned toff =
         (unsigned)(((g.rsign * (tr >> dsh) * g.Wi + g.ssign * (ts >> dsh)) * g.C + cpi * VEC) * (int)sizeof(T));
 #pragma unroll
-    for (int i = 0; i < APT; ++i) {
-      // all ones where the tap is outside the image: the buffer bounds check then returns zero
-      const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(a_inv[i], tap, 1);
-      dma16(rsrc_a, (a_off[i] + toff) | inv, 0u, base + i * (RPP * NP));
-    }
+    for (int i = 0; i < APT; ++i)
+      if (i >= j0 && i < j1) {
+        // all ones where the tap is outside the image: the buffer bounds check then returns zero
+        const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(a_inv[i], tap, 1);
+        dma16(rsrc_a, (a_off[i] + toff) | inv, 0u, base + i * (RPP * NP));
+      }
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) dma16(rsrc_b, b_off[i], b_step, base + (BM + i * RPP) * NP);
-    b_step += NP * 16;
-    cpi += NP;
-    while (cpi >= CP) {
-      cpi -= CP;
-      ++tap;
-      if (++ts == g.S) {
-        ts = 0;
-        ++tr;
+    for (int i = 0; i < BPT; ++i)
+      if (APT + i >= j0 && APT + i < j1) dma16(rsrc_b, b_off[i], b_step, base + (BM + i * RPP) * NP);
+    if (j1 == IPT) {
+      b_step += NP * 16;
+      cpi += NP;
+      while (cpi >= CP) {
+        cpi -= CP;
+        ++tap;
+        if (++ts == g.S) {
+          ts = 0;
+          ++tr;
+        }
       }
     }
   };
+  auto issue_tile = [&](int buf) { issue_part(buf, 0, IPT); };
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -323,7 +333,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everyone is done reading buffer `nxt`
-    if (kt + D < NK) issue_tile(nxt);  // tiles are issued strictly in K order
+    const bool more = kt + D < NK;
+    if (!SPL && more) issue_tile(nxt);  // tiles are issued strictly in K order
     const piece_t* ta = &smem[cur * TILE_PIECES];
     // fragments are register double-buffered: the ds_reads of sub-step ks+1 are issued before the MFMAs
     // of sub-step ks so LDS latency hides under the matrix pipe
@@ -351,6 +362,11 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #pragma unroll
         for (int j = 0; j < TN; ++j) mma_piece<T>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SPL) {
+        constexpr int NSUB = NP / 2;
+        if (more) issue_part(nxt, ks * IPT / NSUB, (ks + 1) * IPT / NSUB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     cur = cur + 1 == NBUF ? 0 : cur + 1;
     nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
@@ -542,7 +558,8 @@ inline int igemm_sk_blocks() {
   return v;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI = true, bool ALLOW_SK = false>
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI = true, bool ALLOW_SK = false,
+          bool SPL = false>
 inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
                             const T* zero_page, int sk_blocks = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -557,8 +574,8 @@ inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const 
       return gm;
     }
   }
-  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI>), dim3(gm * gn), dim3(WM * WN * 64), 0, stream, g, A, Bw,
-                     ep, gn, zero_page, rd, gm * gn);
+  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL>), dim3(gm * gn), dim3(WM * WN * 64), 0,
+                     stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
   return gm;
 }
 
@@ -613,9 +630,16 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
   if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);  // 256x128, 8 waves
   // 288x256, 12 waves of 96x64, 128-byte K-steps, 2 buffers, one workgroup per CU: M = B*P*Q of the 256x341 input at
   // B = 192 is 132 * 2^k, and 288-row tiles put layer3 (67584 rows, N = 256) on 235 of the 256 CUs in ONE round
-  if (cfg == 12 && wide_k && g.N % 256 == 0) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);
+  // split DMA issue (SPL): bit 0 = the 288x256 configuration (on: dgrad 95.8 -> 90.1 us, with residual 111.7 -> 103.6),
+  // bit 1 = the 128x128 configuration (off: 114 -> 120 us); MN_SPLIT_DMA overrides
+  static const int spl = getenv("MN_SPLIT_DMA") ? atoi(getenv("MN_SPLIT_DMA")) : 1;
+  if (cfg == 12 && wide_k && g.N % 256 == 0) {
+    if (spl & 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true>(g, A, Bw, ep, stream, zero_page);
+    return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);
+  }
   // 288x128, 6 waves of 96x64, 64-byte K-steps, 2 buffers, two workgroups per CU (independent phases)
   if (cfg == 13 && g.N % 128 == 0) return launch_igemm_cfg<T, 3, 2, 3, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);
+  if (wide_k && (spl & 2)) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, true>(g, A, Bw, ep, stream, zero_page);
   if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
   return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
 }

@@ -60,6 +60,10 @@ struct Epilogue {
   int relu;              // max(0, .) after bias
   const void* res;       // residual [M][ldc] of type T or null
   const void* res_gate;  // if non-null the residual passes only where res_gate[m][n] > 0
+  // if non-null the stored value (after alpha, bias, residual) is zeroed where out_gate[m][n] <= 0: the data gradient
+  // of a block's first conv leaves the kernel already multiplied by the ReLU gate of the block BELOW it, so that none
+  // of that gradient's three consumers has to read the gating activation again
+  const void* out_gate = nullptr;
   float alpha;           // scale applied to the accumulator
 };
 
@@ -425,6 +429,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   T* out = reinterpret_cast<T*>(ep.out);
   const T* res = reinterpret_cast<const T*>(ep.res);
   const T* gate = reinterpret_cast<const T*>(ep.res_gate);
+  const T* ogate = reinterpret_cast<const T*>(ep.out_gate);
   float* stage = reinterpret_cast<float*>(&smem[0]);  // [64][SC] fp32 sub-block
   constexpr int SC = BN < 128 ? BN : 128;             // columns staged per round
   constexpr int CPR = SC / VEC;                       // output pieces per staged row
@@ -485,6 +490,13 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
               }
             }
             PieceView<T> o;
+            if (ogate) {
+              PieceView<T> ov;
+              ov.p = *reinterpret_cast<const piece_t*>(ogate + idx);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e)
+                if (!((float)ov.e[e] > 0.f)) v[e] = 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o.e[e] = (T)v[e];
             *reinterpret_cast<piece_t*>(out + idx) = o.p;

@@ -657,6 +657,7 @@ struct Plan : PlanBase {
   bool fuse_stem_bwd = (fuse_stem_mask & 2) != 0;
   bool self_gate_ok = !(getenv("MN_SELF_GATE") && atoi(getenv("MN_SELF_GATE")) == 0);
   bool early_fork = !(getenv("MN_EARLY_FORK") && atoi(getenv("MN_EARLY_FORK")) == 0);
+  bool pregate = !(getenv("MN_PREGATE") && atoi(getenv("MN_PREGATE")) == 0);
   // `ws`: the stream the launch goes to (the side stream after a fork, or the main stream)
   void conv_wgrad(Unit& u, const T* x, hipStream_t ws) {
     WgradArgs a;
@@ -669,9 +670,10 @@ struct Plan : PlanBase {
     launch_wgrad<T>(a, target, ws, zero_page);
     timer.end(tp, ws);
   }
-  void conv_dgrad(Unit& u, T* gx, const T* res, const T* gate, hipStream_t s) {
+  void conv_dgrad(Unit& u, T* gx, const T* res, const T* gate, hipStream_t s, const T* out_gate = nullptr) {
     Epilogue ep;
     ep.out = gx; ep.ldc = u.cp.cin; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = res; ep.res_gate = gate;
+    ep.out_gate = out_gate;
     ep.alpha = 1.f;
     ep.sk_ws = sk_ws;
     ep.sk_counters = sk_counters;
@@ -695,41 +697,47 @@ struct Plan : PlanBase {
     for (auto& p : pending_wgrads) conv_wgrad(*p.u, p.x, ws);
     pending_wgrads.clear();
   }
+  // Every gradient w.r.t. a block OUTPUT is stored already multiplied by that block's ReLU gate (out > 0): its producer
+  // -- the data gradient of the block above, or the average pool's backward for the last block -- applies the gate in
+  // its epilogue (Epilogue::out_gate, reading its own input tensor), so bn2 / the projection's BatchNorm / the identity
+  // path of this block use `gout` as it is and never read `out`.
   void block_backward(Block& blk, hipStream_t s) {
-    // gm = gout * (out > 0) feeds bn2 (and bn_d); see DESIGN.md section 4
+    // the gate of the block below = ReLU that produced this block's input (none below layer1.0: its input is the max-pool)
+    const T* below = (!pregate || &blk == &blocks.front()) ? nullptr : blk.x;
+    const T* og = pregate ? nullptr : blk.out;  // MN_PREGATE=0: the consumers read the gate themselves
     if (wgrad_sched == 2) {
       flush_wgrads(s);
-      bn_bwd(blk.u2, blk.gout, blk.out, s);
+      bn_bwd(blk.u2, blk.gout, og, s);
       conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
       pending_wgrads.push_back({&blk.u2, blk.a1});
       flush_wgrads(s);
       bn_bwd(blk.u1, blk.ga1, blk.a1, s, true);
-      if (blk.down) bn_bwd(blk.ud, blk.gout, blk.out, s);
+      if (blk.down) bn_bwd(blk.ud, blk.gout, og, s);
       pending_wgrads.push_back({&blk.u1, blk.x});
       if (blk.down) {
         pending_wgrads.push_back({&blk.ud, blk.x});
         conv_dgrad(blk.u1, blk.gx, nullptr, nullptr, s);
-        conv_dgrad(blk.ud, blk.gx, blk.gx, nullptr, s);
+        conv_dgrad(blk.ud, blk.gx, blk.gx, nullptr, s, below);
       } else {
-        conv_dgrad(blk.u1, blk.gx, blk.gout, blk.out, s);
+        conv_dgrad(blk.u1, blk.gx, blk.gout, og, s, below);
       }
       return;
     }
-    bn_bwd(blk.u2, blk.gout, blk.out, s);
+    bn_bwd(blk.u2, blk.gout, og, s);
     const bool early = wgrad_sched == 1;
     if (early) conv_wgrad(blk.u2, blk.a1, fork_wgrad(s));
     conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
     bn_bwd(blk.u1, blk.ga1, blk.a1, s, true);
-    if (blk.down) bn_bwd(blk.ud, blk.gout, blk.out, s);
+    if (blk.down) bn_bwd(blk.ud, blk.gout, og, s);
     hipStream_t ws = fork_wgrad(s);
     if (!early) conv_wgrad(blk.u2, blk.a1, ws);
     conv_wgrad(blk.u1, blk.x, ws);
     if (blk.down) {
       conv_wgrad(blk.ud, blk.x, ws);
       conv_dgrad(blk.u1, blk.gx, nullptr, nullptr, s);
-      conv_dgrad(blk.ud, blk.gx, blk.gx, nullptr, s);  // accumulate the projection path in place
+      conv_dgrad(blk.ud, blk.gx, blk.gx, nullptr, s, below);  // accumulate the projection path in place, then gate
     } else {
-      conv_dgrad(blk.u1, blk.gx, blk.gout, blk.out, s);  // + identity path, gated by the block ReLU
+      conv_dgrad(blk.u1, blk.gx, blk.gout, og, s, below);  // + identity path (already gated)
     }
   }
   void head_backward(hipStream_t s) {
@@ -761,7 +769,7 @@ struct Plan : PlanBase {
     launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s, (const float*)zero_page);
     Block& last = blocks.back();
     hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
-                       (const float*)dpooled, last.gout, B, Hl * Wl, 512);
+                       (const float*)dpooled, last.gout, B, Hl * Wl, 512, pregate ? (const T*)last.out : (const T*)nullptr);
   }
   void stem_backward(hipStream_t s) {
     if (fuse_stem_bwd) {

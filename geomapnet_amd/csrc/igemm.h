@@ -44,6 +44,10 @@ struct GatherGeom {
   int off_h, off_w;
   int div;  // 1, or 2 (requires rsign = ssign = -1): tap valid only if hn, wn even; input index = hn/2, wn/2
   int M, N, K;
+  // K-walk order of the uniform tap walk (not part of the C ABI; set by launch_igemm): 0 = channels fastest
+  // (k = (r, s, c) as stored), 1 = taps fastest: all R*S taps of one 128-byte channel chunk before the next chunk, so
+  // that the R*S shifted re-reads of an activation row are close in time (L2 hits instead of refetches)
+  int tap_inner = 0;
 };
 
 struct Epilogue {
@@ -162,14 +166,14 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int WTM = TM * 32, WTN = TN * 32;
   constexpr int RPP = NT / NP;  // rows covered by one DMA pass of all threads
-  // B passes are rounded up: rows past BN of the last pass are zero-filled by the bounds check (no fetch) into LDS rows
-  // nobody reads (BNA allocated rows), so that thread counts that do not divide BN (12 waves, BN = 256) work
-  constexpr int APT = BM / RPP, BPT = (BN + RPP - 1) / RPP;
-  constexpr int BNA = BPT * RPP;
-  constexpr int IPT = APT + BPT;  // DMA instructions per wave per tile
-  constexpr int TILE_PIECES = (BM + BNA) * NP;
+  // The A rows [0, BM) and B rows [BM, BM + BN) of a tile form ONE row space that the threads cover in IPT passes of RPP
+  // rows; a pass may straddle the A/B boundary as long as the boundary falls between waves (the buffer resource of
+  // a DMA instruction is wave-uniform).  Rows past BM + BN of the last pass are zero-filled by the bounds check (no
+  // fetch) into LDS rows nobody reads, so thread counts that divide neither BM nor BN work (12 waves: 288 + 256 rows).
+  constexpr int IPT = (BM + BN + RPP - 1) / RPP;  // DMA instructions per wave per tile
+  constexpr int TILE_PIECES = IPT * RPP * NP;
   constexpr int D = NBUF - 1;  // tiles in flight
-  static_assert(APT >= 1 && APT * RPP == BM, "A rows must be a whole number of DMA passes");
+  static_assert(BM % (64 / NP) == 0, "the A/B boundary must fall between waves");
   static_assert(D >= 1 && D <= 3, "ring depth");
   static_assert(RPP % 16 == 0, "swizzle must not see the per-thread row stride");
   static_assert(NBUF * TILE_PIECES * 16 >= 64 * (BN < 128 ? BN : 128) * 4, "epilogue staging does not fit");
@@ -217,50 +221,51 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   // UNI: a K-step never straddles a tap (C is a multiple of the step), so the tap walk is wave-uniform and
   // lives in scalar registers; otherwise (stem: 16-byte taps) every lane walks its own piece.
   constexpr bool uni = UNI;
-  unsigned a_off[APT], a_inv[APT];
+  unsigned d_off[IPT], a_inv[IPT];  // byte offset of the row (A: image pixel, B: weight row) and the A tap mask
 #pragma unroll
-  for (int i = 0; i < APT; ++i) {
-    const int m = m0 + lrow + i * RPP;
-    a_off[i] = 0u;
+  for (int i = 0; i < IPT; ++i) {
+    const int jr = lrow + i * RPP;  // joint row of this thread in pass i
+    d_off[i] = 0u;
     a_inv[i] = ~0u;
-    if (m < g.M) {
-      const int tmp = fastdiv(m, rd.q), q = m - tmp * g.Q;
-      const int b = fastdiv(tmp, rd.p), p = tmp - b * g.P;
-      const int h0 = p * g.mul_p + g.off_h, w0 = q * g.mul_q + g.off_w;
-      a_off[i] = (unsigned)((((b * g.Hi + (h0 >> dsh)) * g.Wi + (w0 >> dsh)) * g.C) * (int)sizeof(T)) +
-                 (uni ? (unsigned)src_piece * 16u : 0u);
-      // validity is separable: tap (r, s) is inside the image iff row r and column s both are
-      unsigned cinv = 0;  // bit s set: column tap s outside
-      for (int s = 0; s < g.S; ++s) {
-        int wn_ = w0 + g.ssign * s;
-        bool ok = true;
-        if (dsh) {
-          ok = (wn_ & 1) == 0;
-          wn_ >>= 1;
+    const bool pure_a = (i + 1) * RPP <= BM, pure_b = i * RPP >= BM;
+    if (pure_a || (!pure_b && jr < BM)) {
+      const int m = m0 + jr;
+      if (m < g.M) {
+        const int tmp = fastdiv(m, rd.q), q = m - tmp * g.Q;
+        const int b = fastdiv(tmp, rd.p), p = tmp - b * g.P;
+        const int h0 = p * g.mul_p + g.off_h, w0 = q * g.mul_q + g.off_w;
+        d_off[i] = (unsigned)((((b * g.Hi + (h0 >> dsh)) * g.Wi + (w0 >> dsh)) * g.C) * (int)sizeof(T)) +
+                   (uni ? (unsigned)src_piece * 16u : 0u);
+        // validity is separable: tap (r, s) is inside the image iff row r and column s both are
+        unsigned cinv = 0;  // bit s set: column tap s outside
+        for (int s = 0; s < g.S; ++s) {
+          int wn_ = w0 + g.ssign * s;
+          bool ok = true;
+          if (dsh) {
+            ok = (wn_ & 1) == 0;
+            wn_ >>= 1;
+          }
+          ok = ok && (unsigned)wn_ < (unsigned)g.Wi;
+          cinv |= (ok ? 0u : 1u) << s;
         }
-        ok = ok && (unsigned)wn_ < (unsigned)g.Wi;
-        cinv |= (ok ? 0u : 1u) << s;
-      }
-      const unsigned call = (1u << g.S) - 1u;
-      unsigned inv = 0;
-      for (int r = 0; r < g.R; ++r) {
-        int hn = h0 + g.rsign * r;
-        bool ok = true;
-        if (dsh) {
-          ok = (hn & 1) == 0;
-          hn >>= 1;
+        const unsigned call = (1u << g.S) - 1u;
+        unsigned inv = 0;
+        for (int r = 0; r < g.R; ++r) {
+          int hn = h0 + g.rsign * r;
+          bool ok = true;
+          if (dsh) {
+            ok = (hn & 1) == 0;
+            hn >>= 1;
+          }
+          ok = ok && (unsigned)hn < (unsigned)g.Hi;
+          inv |= (ok ? cinv : call) << (r * g.S);
         }
-        ok = ok && (unsigned)hn < (unsigned)g.Hi;
-        inv |= (ok ? cinv : call) << (r * g.S);
+        a_inv[i] = inv | (g.R * g.S < 32 ? ~0u << (g.R * g.S) : 0u);
       }
-      a_inv[i] = inv | (g.R * g.S < 32 ? ~0u << (g.R * g.S) : 0u);
+    } else {
+      const int br = jr - BM, n = n0 + br;
+      d_off[i] = (n < g.N && br < BN) ? (unsigned)(n * g.K) * (unsigned)sizeof(T) + (unsigned)src_piece * 16u : ~0u;
     }
-  }
-  unsigned b_off[BPT];
-#pragma unroll
-  for (int i = 0; i < BPT; ++i) {
-    const int n = n0 + lrow + i * RPP;
-    b_off[i] = (n < g.N && lrow + i * RPP < BN) ? (unsigned)(n * g.K) * (unsigned)sizeof(T) + (unsigned)src_piece * 16u : ~0u;
   }
   // running decomposition of the step's first piece (uniform walk) or of this lane's piece (per-lane walk)
   // into (tap = (tr, ts), channel piece cpi)
@@ -281,6 +286,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     }
   }
   unsigned b_step = (unsigned)k0 * NP * 16;  // byte offset of the K-step inside a weight row (scalar)
+  const bool tapin = UNI && !SK && g.tap_inner != 0;
   const unsigned lds_wave = wave * 64;  // this wave's 64 pieces of DMA pass 0 inside a tile
 
   // instructions [j0, j1) of the tile's IPT DMA instructions (A passes first, then B passes); the tap walk advances
@@ -289,25 +295,41 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     piece_t* base = &smem[buf * TILE_PIECES + lds_wave];
     const unsigned toff =
         (unsigned)(((g.rsign * (tr >> dsh) * g.Wi + g.ssign * (ts >> dsh)) * g.C + cpi * VEC) * (int)sizeof(T));
+    const unsigned bs = tapin ? (unsigned)(tap * CP + cpi) * 16u : b_step;
 #pragma unroll
-    for (int i = 0; i < APT; ++i)
+    for (int i = 0; i < IPT; ++i)
       if (i >= j0 && i < j1) {
-        // all ones where the tap is outside the image: the buffer bounds check then returns zero
-        const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(a_inv[i], tap, 1);
-        dma16(rsrc_a, (a_off[i] + toff) | inv, 0u, base + i * (RPP * NP));
+        const bool pure_a = (i + 1) * RPP <= BM, pure_b = i * RPP >= BM;
+        piece_t* dst = base + i * (RPP * NP);
+        if (pure_a || (!pure_b && wave * (64 / NP) + i * RPP < BM)) {  // wave-uniform
+          // all ones where the tap is outside the image: the buffer bounds check then returns zero
+          const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(a_inv[i], tap, 1);
+          dma16(rsrc_a, (d_off[i] + toff) | inv, 0u, dst);
+        } else {
+          dma16(rsrc_b, d_off[i], bs, dst);
+        }
       }
-#pragma unroll
-    for (int i = 0; i < BPT; ++i)
-      if (APT + i >= j0 && APT + i < j1) dma16(rsrc_b, b_off[i], b_step, base + (BM + i * RPP) * NP);
     if (j1 == IPT) {
       b_step += NP * 16;
-      cpi += NP;
-      while (cpi >= CP) {
-        cpi -= CP;
+      if (tapin) {
         ++tap;
         if (++ts == g.S) {
           ts = 0;
           ++tr;
+        }
+        if (tap == g.R * g.S) {
+          tap = tr = ts = 0;
+          cpi += NP;
+        }
+      } else {
+        cpi += NP;
+        while (cpi >= CP) {
+          cpi -= CP;
+          ++tap;
+          if (++ts == g.S) {
+            ts = 0;
+            ++tr;
+          }
         }
       }
     }
@@ -593,9 +615,14 @@ inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const 
 
 // returns the number of M-blocks used (= rows of the stats partial buffer that were written)
 template <typename T>
-inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
+inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
                         const T* zero_page, int sk_blocks = 0) {
   constexpr int VEC = ElemTraits<T>::VEC;
+  GatherGeom g = g_in;
+  // taps-fastest K order: layer3 data gradient 98 -> 92 us, with residual 117 -> 107, layer2 120 -> 117; MN_TAP_INNER=0
+  // restores the stored order
+  static const int tap_inner = getenv("MN_TAP_INNER") ? atoi(getenv("MN_TAP_INNER")) : 1;
+  g.tap_inner = (tap_inner && g.R * g.S > 1) ? 1 : 0;
   const bool wide_k = (g.C / VEC) % 8 == 0;  // 128-byte K-steps need taps that are a multiple of them
   int cfg = igemm_config();
   // channel counts that are not a multiple of the K-step (stem pixel pairs, odd test shapes): per-lane tap walk
@@ -649,8 +676,8 @@ inline int launch_igemm(const GatherGeom& g, const T* A, const T* Bw, const Epil
     if (spl & 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true>(g, A, Bw, ep, stream, zero_page);
     return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);
   }
-  // 288x128, 6 waves of 96x64, 64-byte K-steps, 2 buffers, two workgroups per CU (independent phases)
-  if (cfg == 13 && g.N % 128 == 0) return launch_igemm_cfg<T, 3, 2, 3, 2, 4, 2, 3>(g, A, Bw, ep, stream, zero_page);
+  // (measured and removed: the same tile with 64-byte K-steps and FOUR buffers, i.e. three tiles in flight -- 99 vs 93 us
+  // on layer3, so the ring depth is not what limits it; 288x128 tiles of 6 waves, two workgroups per CU -- 131 us)
   if (wide_k && (spl & 2)) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, true>(g, A, Bw, ep, stream, zero_page);
   if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
   return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);

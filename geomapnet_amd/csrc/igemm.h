@@ -48,27 +48,10 @@ struct GatherGeom {
   // (k = (r, s, c) as stored), 1 = taps fastest: all R*S taps of one 128-byte channel chunk before the next chunk, so
   // that the R*S shifted re-reads of an activation row are close in time (L2 hits instead of refetches)
   int tap_inner = 0;
-};
-
-struct Epilogue {
-  void* out;             // [M][ldc], element type T
-  int ldc;
-  float* stats;          // [grid_m][2][N] column partial sums (sum, sum of squares) or null
-  // stream-K (see igemm_kernel): fp32 slabs [blocks][2][BM*BN] (scratch) and arrival counters [blocks] (zero on
-  // entry, left zero on exit); null = every workgroup owns whole tiles
-  float* sk_ws = nullptr;
-  int* sk_counters = nullptr;
-  double* stats_accum = nullptr;  // alternative: [stats_rows][2][N] fp64 accumulators, added to atomically (row =
-  int stats_rows = 0;             // tile_m % stats_rows spreads the same-address contention); consumer sums the rows
-  const float* bias;     // [N] or null
-  int relu;              // max(0, .) after bias
-  const void* res;       // residual [M][ldc] of type T or null
-  const void* res_gate;  // if non-null the residual passes only where res_gate[m][n] > 0
-  // if non-null the stored value (after alpha, bias, residual) is zeroed where out_gate[m][n] <= 0: the data gradient
-  // of a block's first conv leaves the kernel already multiplied by the ReLU gate of the block BELOW it, so that none
-  // of that gradient's three consumers has to read the gating activation again
-  const void* out_gate = nullptr;
-  float alpha;           // scale applied to the accumulator
+  // Tap subset (stride-2 data gradients decomposed by output parity, launch_dgrad_parity in net.hip): the gather walks
+  // R x S taps, the WEIGHT walk maps them to taps (bt_r0 + 2 r, bt_s0 + 2 s) of a bt_S-wide full kernel, and a weight
+  // row is ldb elements long (0 = K).  Needs the taps-fastest order.
+  int ldb = 0, bt_on = 0, bt_r0 = 0, bt_s0 = 0, bt_S = 0;
 };
 
 // n / d for 0 <= n < 2^31 without the ~35-instruction software division (Granlund-Montgomery round-up
@@ -88,6 +71,31 @@ inline FastDiv make_fastdiv(int d) {
 __device__ __forceinline__ int fastdiv(int n, FastDiv f) {
   return (int)((__umulhi((unsigned)n, f.mul) + (unsigned)n) >> f.shift);
 }
+struct Epilogue {
+  void* out;             // [M][ldc], element type T
+  int ldc;
+  float* stats;          // [grid_m][2][N] column partial sums (sum, sum of squares) or null
+  // stream-K (see igemm_kernel): fp32 slabs [blocks][2][BM*BN] (scratch) and arrival counters [blocks] (zero on
+  // entry, left zero on exit); null = every workgroup owns whole tiles
+  float* sk_ws = nullptr;
+  int* sk_counters = nullptr;
+  double* stats_accum = nullptr;  // alternative: [stats_rows][2][N] fp64 accumulators, added to atomically (row =
+  int stats_rows = 0;             // tile_m % stats_rows spreads the same-address contention); consumer sums the rows
+  const float* bias;     // [N] or null
+  int relu;              // max(0, .) after bias
+  const void* res;       // residual [M][ldc] of type T or null
+  const void* res_gate;  // if non-null the residual passes only where res_gate[m][n] > 0
+  // if non-null the stored value (after alpha, bias, residual) is zeroed where out_gate[m][n] <= 0: the data gradient
+  // of a block's first conv leaves the kernel already multiplied by the ReLU gate of the block BELOW it, so that none
+  // of that gradient's three consumers has to read the gating activation again
+  const void* out_gate = nullptr;
+  // output row map (parity classes of a stride-2 data gradient): GEMM row m = (b, p, q) over an om_P x om_Q grid is
+  // stored at pixel (2p + om_a, 2q + om_b) of an om_H x om_W image (also applies to res / res_gate / out_gate)
+  int om_on = 0, om_P = 0, om_Q = 0, om_H = 0, om_W = 0, om_a = 0, om_b = 0;
+  FastDiv om_dq{0, 0}, om_dp{0, 0};
+  float alpha;           // scale applied to the accumulator
+};
+
 struct RowDiv {
   FastDiv q, p;  // divisors GatherGeom.Q and GatherGeom.P
 };
@@ -213,7 +221,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   // offset >= the tensor size returns zero), so an out-of-image tap or an out-of-range row is just an
   // all-ones offset: no pointer select, no 64-bit address arithmetic in the K loop.
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(A, (long)g.B * g.Hi * g.Wi * g.C * (long)sizeof(T));
-  const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(Bw, (long)g.N * g.K * (long)sizeof(T));
+  const int ldb = g.ldb ? g.ldb : g.K;
+  const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(Bw, (long)g.N * ldb * (long)sizeof(T));
   const int CP = g.C / VEC;  // pieces per tap
   // Source piece of this lane inside a K-step: the XOR swizzle is applied on the source side.  Rows of
   // one lane differ by multiples of RPP (a multiple of 16), which the swizzle ignores.
@@ -264,7 +273,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
       }
     } else {
       const int br = jr - BM, n = n0 + br;
-      d_off[i] = (n < g.N && br < BN) ? (unsigned)(n * g.K) * (unsigned)sizeof(T) + (unsigned)src_piece * 16u : ~0u;
+      d_off[i] = (n < g.N && br < BN) ? (unsigned)(n * ldb) * (unsigned)sizeof(T) + (unsigned)src_piece * 16u : ~0u;
     }
   }
   // running decomposition of the step's first piece (uniform walk) or of this lane's piece (per-lane walk)
@@ -295,7 +304,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     piece_t* base = &smem[buf * TILE_PIECES + lds_wave];
     const unsigned toff =
         (unsigned)(((g.rsign * (tr >> dsh) * g.Wi + g.ssign * (ts >> dsh)) * g.C + cpi * VEC) * (int)sizeof(T));
-    const unsigned bs = tapin ? (unsigned)(tap * CP + cpi) * 16u : b_step;
+    const int btap = g.bt_on ? (g.bt_r0 + 2 * tr) * g.bt_S + g.bt_s0 + 2 * ts : tap;
+    const unsigned bs = tapin ? (unsigned)(btap * CP + cpi) * 16u : b_step;
 #pragma unroll
     for (int i = 0; i < IPT; ++i)
       if (i >= j0 && i < j1) {
@@ -499,7 +509,13 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
               v[e + 2] = f[2];
               v[e + 3] = f[3];
             }
-            const long idx = (long)row * ep.ldc + col;
+            long orow = row;
+            if (ep.om_on) {
+              const int tmp = fastdiv(row, ep.om_dq), oq = row - tmp * ep.om_Q;
+              const int ob = fastdiv(tmp, ep.om_dp), op = tmp - ob * ep.om_P;
+              orow = ((long)ob * ep.om_H + 2 * op + ep.om_a) * ep.om_W + 2 * oq + ep.om_b;
+            }
+            const long idx = orow * ep.ldc + col;
             if (res) {
               PieceView<T> rv, gv;
               rv.p = *reinterpret_cast<const piece_t*>(res + idx);
@@ -622,7 +638,7 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   // taps-fastest K order: layer3 data gradient 98 -> 92 us, with residual 117 -> 107, layer2 120 -> 117; MN_TAP_INNER=0
   // restores the stored order
   static const int tap_inner = getenv("MN_TAP_INNER") ? atoi(getenv("MN_TAP_INNER")) : 1;
-  g.tap_inner = (tap_inner && g.R * g.S > 1) ? 1 : 0;
+  g.tap_inner = ((tap_inner && g.R * g.S > 1) || g.bt_on) ? 1 : 0;
   const bool wide_k = (g.C / VEC) % 8 == 0;  // 128-byte K-steps need taps that are a multiple of them
   int cfg = igemm_config();
   // channel counts that are not a multiple of the K-step (stem pixel pairs, odd test shapes): per-lane tap walk
@@ -639,7 +655,7 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   // tiles), 2064 tiles 113 vs 118 us, whole step 19.8 vs 19.65 ms -- every extra segment pays a gather prologue and
   // a pipeline fill, which eats what the balanced ranges save.  Off unless MN_STREAMK=1 (or sk_blocks is forced).
   static const bool allow_sk = getenv("MN_STREAMK") && atoi(getenv("MN_STREAMK")) != 0;
-  if (ep.sk_ws && ep.sk_counters && g.N >= 128 && (cfg == 0 || cfg == 1) && (allow_sk || sk_blocks > 0)) {
+  if (ep.sk_ws && ep.sk_counters && g.N >= 128 && (cfg == 0 || cfg == 1) && (allow_sk || sk_blocks > 0) && !g.bt_on) {
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
     const int G = sk_blocks > 0 ? sk_blocks : igemm_sk_blocks();
     const bool want = sk_blocks > 0 || (tiles128 > G && tiles128 < 6L * G && (tiles128 % G) * 8 < 7L * G);

@@ -15,6 +15,7 @@
 #include "elementwise.h"
 #include "head.h"
 #include "igemm.h"
+#include "dgrad.h"
 #include "layout.h"
 #include "optim.h"
 #include "pool.h"
@@ -242,16 +243,8 @@ struct Plan : PlanBase {
     BnP bp;
     int Hin, Win, Hout, Wout;
     long M;
-    GatherGeom gf, gd;
-    // stride-2 data gradient decomposed by the parity (a, b) of the input pixel: class (a, b) only receives the taps
-    // r = r0 + 2r', s = s0 + 2s' with r0 = (a + pad) % 2, s0 = (b + pad) % 2 -- a dense stride-1 gather of 1, 2, 2, 4
-    // taps (3x3) instead of 9 taps of which three quarters are structural zeros
-    struct ParityClass {
-      GatherGeom g;
-      int a, b, P, Q;
-    };
-    ParityClass pc[4];
-    int n_pc = 0;
+    GatherGeom gf;
+    DgradGeom dg;  // data-gradient launches (generic form + stride-2 parity classes), dgrad.h
     T* wf = nullptr;  // forward operand  [Cout][K]
     T* wd = nullptr;  // data-gradient operand [Cin][R*S*Cout]
     T* y = nullptr;   // raw conv output [M][Cout]
@@ -391,13 +384,6 @@ struct Plan : PlanBase {
     g.M = B * Hout * Wout; g.N = c.cout; g.K = c.k * c.k * c.cin;
     return g;
   }
-  static GatherGeom dgrad_geom(int B, int Hin, int Win, const ConvP& c, int Hout, int Wout) {
-    GatherGeom g;
-    g.B = B; g.Hi = Hout; g.Wi = Wout; g.C = c.cout; g.P = Hin; g.Q = Win; g.R = c.k; g.S = c.k;
-    g.mul_p = 1; g.mul_q = 1; g.rsign = -1; g.ssign = -1; g.off_h = c.pad; g.off_w = c.pad; g.div = c.stride;
-    g.M = B * Hin * Win; g.N = c.cin; g.K = c.k * c.k * c.cout;
-    return g;
-  }
   void init_unit(Unit& u, const ConvP& c, const BnP& b, int Hin, int Win) {
     u.cp = c;
     u.bp = b;
@@ -407,26 +393,8 @@ struct Plan : PlanBase {
     u.Wout = (Win + 2 * c.pad - c.k) / c.stride + 1;
     u.M = (long)B * u.Hout * u.Wout;
     u.gf = fwd_geom(B, Hin, Win, c, u.Hout, u.Wout);
-    u.gd = dgrad_geom(B, Hin, Win, c, u.Hout, u.Wout);
     u.ldw = c.k * c.k * c.cin;
-    u.n_pc = 0;
-    if (c.stride == 2 && (c.cout / VEC) % 4 == 0) {
-      for (int a = 0; a < 2; ++a)
-        for (int b2 = 0; b2 < 2; ++b2) {
-          const int r0 = (a + c.pad) % 2, s0 = (b2 + c.pad) % 2;
-          const int R = r0 < c.k ? (c.k - r0 + 1) / 2 : 0, S = s0 < c.k ? (c.k - s0 + 1) / 2 : 0;
-          const int P = (Hin - a + 1) / 2, Q = (Win - b2 + 1) / 2;
-          if (R == 0 || S == 0 || P <= 0 || Q <= 0) continue;  // no tap reaches this class: its gradient is zero
-          typename Unit::ParityClass& k = u.pc[u.n_pc++];
-          k.a = a; k.b = b2; k.P = P; k.Q = Q;
-          GatherGeom& g = k.g;
-          g.B = B; g.Hi = u.Hout; g.Wi = u.Wout; g.C = c.cout; g.P = P; g.Q = Q; g.R = R; g.S = S;
-          g.mul_p = 1; g.mul_q = 1; g.rsign = -1; g.ssign = -1;
-          g.off_h = (a + c.pad - r0) / 2; g.off_w = (b2 + c.pad - s0) / 2; g.div = 1;
-          g.M = B * P * Q; g.N = c.cin; g.K = R * S * c.cout;
-          g.ldb = c.k * c.k * c.cout; g.bt_on = 1; g.bt_r0 = r0; g.bt_s0 = s0; g.bt_S = c.k;
-        }
-    }
+    u.dg = make_dgrad_geom(B, Hin, Win, c.cin, c.cout, c.k, c.stride, c.pad, u.Hout, u.Wout, VEC);
   }
 
   Plan(const mn_config& c) {
@@ -706,23 +674,7 @@ struct Plan : PlanBase {
     ep.sk_ws = sk_ws;
     ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
-    if (parity_dgrad && u.n_pc > 0) {
-      // classes no tap reaches (1x1 stride 2: three of four) get a zero gradient: with a residual accumulated in place
-      // (res == gx) they are already right; otherwise the classes must cover every pixel
-      const bool covers = u.n_pc == 4 || res == gx;
-      if (covers) {
-        for (int i = 0; i < u.n_pc; ++i) {
-          const auto& k = u.pc[i];
-          Epilogue e2 = ep;
-          e2.om_on = 1; e2.om_P = k.P; e2.om_Q = k.Q; e2.om_H = u.Hin; e2.om_W = u.Win; e2.om_a = k.a; e2.om_b = k.b;
-          e2.om_dq = make_fastdiv(k.Q); e2.om_dp = make_fastdiv(k.P);
-          launch_igemm<T>(k.g, (const T*)u.gy, (const T*)u.wd, e2, s, (const T*)zero_page);
-        }
-        timer.end(tp, s);
-        return;
-      }
-    }
-    launch_igemm<T>(u.gd, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page);
+    launch_conv_dgrad<T>(u.dg, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page, parity_dgrad);
     timer.end(tp, s);
   }
   // Weight-gradient schedule (MN_WGRAD_SCHED): 0 = one fork per block, after its last BatchNorm backward;

@@ -8,6 +8,7 @@
 #include "elementwise.h"
 #include "head.h"
 #include "igemm.h"
+#include "dgrad.h"
 #include "optim.h"
 #include "pgo.h"
 #include "pool.h"
@@ -132,6 +133,29 @@ extern "C" int mn_op_calc_vos(const float* poses, int N, int T, float* vos, cons
   hipLaunchKernelGGL(calc_vos_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, poses, N, T, vos, cot,
                      dposes);
   return check_launch("calc_vos");
+}
+
+extern "C" int mn_op_conv_dgrad(int dtype, int B, int Hin, int Win, int Cin, int Cout, int k, int stride, int pad,
+                               const void* gy, const void* wd, void* gx, const void* res, const void* res_gate,
+                               const void* out_gate, int parity, const void* zero_page, void* stream) {
+  begin_call();
+  if (stride != 1 && stride != 2) return fail("conv_dgrad: stride must be 1 or 2");
+  if (k < 1 || k > 5 || pad < 0 || pad >= k) return fail("conv_dgrad: kernel / padding out of range");
+  if (!zero_page) return fail("conv_dgrad: zero_page (>= 16 zero bytes of device memory) is required");
+  const int Hout = (Hin + 2 * pad - k) / stride + 1, Wout = (Win + 2 * pad - k) / stride + 1;
+  const int vec = dtype == MN_F16 ? 8 : 4;
+  DgradGeom d = make_dgrad_geom(B, Hin, Win, Cin, Cout, k, stride, pad, Hout, Wout, vec);
+  if (int e = check_geom(d.full, dtype)) return e;
+  if (Cin % vec != 0) return fail("conv_dgrad: Cin must be a multiple of the 16-byte piece");
+  Epilogue ep;
+  ep.out = gx; ep.ldc = Cin; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = res; ep.res_gate = res_gate;
+  ep.out_gate = out_gate; ep.alpha = 1.f;
+  if (dtype == MN_F16)
+    launch_conv_dgrad<half>(d, (const half*)gy, (const half*)wd, ep, (hipStream_t)stream, (const half*)zero_page, parity != 0);
+  else
+    launch_conv_dgrad<float>(d, (const float*)gy, (const float*)wd, ep, (hipStream_t)stream, (const float*)zero_page,
+                             parity != 0);
+  return check_launch("conv_dgrad");
 }
 
 extern "C" int mn_pgo_optimize(const double* poses, const double* vos, double* out, int32_t* status, int W, int N,

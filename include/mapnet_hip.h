@@ -166,6 +166,14 @@ int mn_op_igemm_streamk(int dtype, const mn_gather_geom* g, const void* A, const
 /* dW[n][colmap(k)] += alpha * sum_m dY[m][n] * gather(X)[m][k]  (fp32 atomics into dW) */
 int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw,
                 const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream);
+/* Data gradient of a convolution (what autograd computes for conv2d's input, torch 0.4.1 `loss.backward()` under
+ * common/train.py:351): gx[B][Hin][Win][Cin] = conv_transpose(gy[B][Hout][Wout][Cout], W) (+ res, res only where
+ * res_gate > 0), zeroed where out_gate <= 0.  wd: weights in the data-gradient layout [Cin][k][k][Cout].  stride 1 or 2;
+ * parity != 0: a stride-2 gradient is computed per parity class of the input pixel (1+2+2+4 taps of a 3x3 kernel
+ * instead of 9 taps of which three quarters are structural zeros); both forms give the same result. */
+int mn_op_conv_dgrad(int dtype, int B, int Hin, int Win, int Cin, int Cout, int k, int stride, int pad, const void* gy,
+                     const void* wd, void* gx, const void* res, const void* res_gate, const void* out_gate, int parity,
+                     const void* zero_page, void* stream);
 /* conv weight layout helpers: OIHW fp32 <-> OHWI fp32 */
 int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream);
 

@@ -149,6 +149,53 @@ def check_conv_dgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, with_r
     assert (out.cpu().double() - want).abs().max().item() <= OUT_TOL[dtype] * want.abs().max().item() + 1e-6
 
 
+def check_conv_dgrad_op(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, parity=1, mode="plain", seed=11):
+    """conv-level data gradient (mn_op_conv_dgrad) vs autograd in fp64: generic form or parity classes of a stride-2
+    conv, with the epilogue variants the training plan uses -- "plain"; "res_gate" (identity path, gated);
+    "out_gate" (identity path + the gate of the block below applied to the stored sum); "inplace" (projection path
+    accumulated in place: res is the output buffer, which for a 1x1 stride-2 conv leaves three quarters untouched)"""
+    _fresh()
+    td = TD[dtype]
+    gen = torch.Generator().manual_seed(seed)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gy = torch.randn(B, Cout, Ho, Wo, generator=gen).to(td).float()
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.1).to(td).float()
+    x = torch.zeros(B, Cin, H, W, dtype=torch.double, requires_grad=True)
+    F.conv2d(x, w.double(), stride=stride, padding=pad).backward(gy.double())
+    want = x.grad.permute(0, 2, 3, 1).contiguous()
+    wt = w.permute(1, 2, 3, 0).contiguous().to(td).to(dev)  # [Cin][R][S][Cout]
+    out = torch.full((B, H, W, Cin), 7.0, dtype=td, device=dev)  # poison: every pixel must be written (or kept, in place)
+    res = rgate = ogate = None
+    if mode in ("res_gate", "out_gate", "inplace"):
+        res = torch.randn(B, H, W, Cin, generator=gen).to(td)
+        if mode == "res_gate":
+            rgate = torch.randn(B, H, W, Cin, generator=gen).to(td)
+            want = want + torch.where(rgate.double() > 0, res.double(), torch.zeros_like(res.double()))
+            rgate = rgate.to(dev)
+        else:
+            want = want + res.double()
+        if mode == "inplace":
+            out = res.clone().to(dev)
+            res = out
+        else:
+            res = res.to(dev)
+    if mode in ("out_gate", "inplace"):
+        ogate = torch.randn(B, H, W, Cin, generator=gen).to(td)
+        if mode == "out_gate" or parity == 0 or k > 1:
+            want = torch.where(ogate.double() > 0, want, torch.zeros_like(want))
+        else:
+            # 1x1 stride 2 by parity, in place: only the even pixels are visited (and gated); the others keep `res`
+            m = torch.zeros(B, H, W, 1, dtype=torch.bool)
+            m[:, ::2, ::2] = True
+            want = torch.where(m & ~(ogate.double() > 0), torch.zeros_like(want), want)
+        ogate = ogate.to(dev)
+    lib.check(lib.op_conv_dgrad(dtype, B, H, W, Cin, Cout, k, stride, pad, K(_nhwc(gy, td, dev)), K(wt), K(out), K(res), K(rgate),
+                                K(ogate), parity, K(zero_page(dev)), None))
+    dev_sync(dev)
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err <= OUT_TOL[dtype] * want.abs().max().item() + 1e-6, err
+
+
 def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target_blocks=8, seed=2):
     _fresh()
     td = TD[dtype]

@@ -105,3 +105,16 @@ def test_pose_graph_vs_oracle(lib, N, fc, sig):
 
 def test_pose_graph_properties(lib):
     checks.check_pgo_properties(lib, DEV, W=24, N=7, fc=True)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape,mode", [
+    ((2, 8, 11, 64, 128, 3, 2, 1), "plain"),      # odd width: the parity classes have 6 and 5 columns
+    ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"),   # odd height
+    ((1, 8, 12, 64, 128, 3, 2, 1), "res_gate"),
+    ((2, 8, 11, 64, 128, 1, 2, 0), "inplace"),    # 1x1 projection: one class, accumulated in place
+    ((2, 9, 11, 64, 64, 3, 1, 1), "out_gate"),    # stride 1: generic form
+])
+@pytest.mark.parametrize("parity", [1, 0])
+def test_conv_data_gradient_op(lib, dtype, shape, mode, parity):
+    checks.check_conv_dgrad_op(lib, DEV, dtype, *shape, parity=parity, mode=mode)

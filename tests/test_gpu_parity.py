@@ -43,6 +43,20 @@ def test_conv_data_gradient(lib, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape,mode", [
+    ((2, 8, 11, 64, 128, 3, 2, 1), "plain"), ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"), ((1, 8, 12, 64, 128, 3, 2, 1), "res_gate"),
+    ((2, 8, 11, 64, 128, 1, 2, 0), "inplace"), ((2, 9, 11, 64, 64, 3, 1, 1), "out_gate"),
+    ((3, 64, 86, 64, 128, 3, 2, 1), "plain"),      # layer2.0.conv1 geometry
+    ((3, 32, 43, 128, 256, 3, 2, 1), "out_gate"),  # layer3.0.conv1 (odd width 43)
+    ((3, 32, 43, 128, 256, 1, 2, 0), "inplace"),   # layer3.0.downsample
+    ((24, 16, 22, 256, 256, 3, 1, 1), "out_gate"),  # 8448 rows x N = 256: the 288x256 one-round configuration
+])
+@pytest.mark.parametrize("parity", [1, 0])
+def test_conv_data_gradient_op(lib, dtype, shape, mode, parity):
+    checks.check_conv_dgrad_op(lib, DEV, dtype, *shape, parity=parity, mode=mode)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape,blocks", [
     ((4, 16, 16, 64, 128, 3), 3), ((5, 16, 16, 128, 256, 3), 7), ((3, 12, 11, 64, 128, 1), 2), ((2, 16, 16, 64, 128, 3), 9),
     ((33, 16, 22, 256, 256, 3), 64),   # 182 tiles over 64 workgroups

@@ -375,18 +375,28 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     // fragments are register double-buffered: the ds_reads of sub-step ks+1 are issued before the MFMAs
     // of sub-step ks so LDS latency hides under the matrix pipe
     PieceView<T> fa[2][TM], fb[2][TN];
+    // Fragment row = (wave tile origin, a multiple of 32) + 32 * tile + (lane & 31): the swizzle only looks at row
+    // bits 1..3, so it is lds_swz(lane & 31) for every fragment, and the fragments of one operand differ by the constant
+    // 32 * NP pieces -- two base addresses and immediate offsets instead of one address register per fragment (which
+    // the 168-register 12-wave configuration spilled and reloaded -- behind s_waitcnt vmcnt(0), i.e. draining the
+    // LDS-DMA queue -- inside this loop).
+    // The bases are recomputed from the lane id every K-step (a handful of VALU operations): as loop invariants the
+    // register-capped configurations spill them, and a spill reload sits behind s_waitcnt vmcnt(0).
+#ifdef __HIP_DEVICE_COMPILE__
+    unsigned opaque_zero = 0u;
+    asm volatile("" : "+s"(opaque_zero));  // keeps the two instructions below inside the loop
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, opaque_zero));  // lane id
+#else
+    const int ln = lane;
+#endif
     auto load_frags = [&](int ks, int slot) {
-      const int piece = ks * 2 + (lane >> 5);
+      const int pxs = (ks * 2 + (ln >> 5)) ^ lds_swz<NP>(ln & 31);
+      const piece_t* pa = ta + (wm * WTM + (ln & 31)) * NP + pxs;
+      const piece_t* pb = ta + (BM + wn * WTN + (ln & 31)) * NP + pxs;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * WTM + i * 32 + (lane & 31);
-        fa[slot][i].p = ta[row * NP + (piece ^ lds_swz<NP>(row))];
-      }
+      for (int i = 0; i < TM; ++i) fa[slot][i].p = pa[i * 32 * NP];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * WTN + j * 32 + (lane & 31);
-        fb[slot][j].p = ta[(BM + row) * NP + (piece ^ lds_swz<NP>(row))];
-      }
+      for (int j = 0; j < TN; ++j) fb[slot][j].p = pb[j * 32 * NP];
     };
     load_frags(0, 0);
 #pragma unroll

@@ -48,6 +48,8 @@ _PROTOS = {
     "mn_set_optim": (c_i, [c_void, c_f, c_f, c_f, c_f, c_f, c_f]),
     "mn_set_step_count": (c_i, [c_void, c_i64]),
     "mn_get_step_count": (c_i64, [c_void]),
+    "mn_set_loss_host": (c_i, [c_void, c_void]),
+    "mn_wait_loss": (c_i, [c_void]),
     "mn_set_input_u8": (c_i, [c_void, c_i, C.POINTER(c_f), C.POINTER(c_f)]),
     "mn_forward": (c_i, [c_void, c_void, c_void, c_i, c_void]),
     "mn_loss": (c_i, [c_void, c_void, c_void, c_void, c_void]),

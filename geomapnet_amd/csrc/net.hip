@@ -166,6 +166,23 @@ struct PlanBase {
     hipStreamWaitEvent(s, e, 0);
     wgrad_pending = false;
   }
+  // Early loss read-back: the reference blocks on loss.item() (common/train.py:361) after the whole step; the value
+  // exists as soon as the criterion has run, so it is copied to the caller's pinned host float right there and the
+  // caller waits for THAT event only -- the host prepares the next step while backward and the optimiser still run.
+  float* loss_host = nullptr;
+  hipEvent_t loss_event = nullptr;
+  bool loss_pending = false;
+  void post_loss(const float* loss_dev_ptr, hipStream_t s) {
+    if (!loss_host || graphs_ok || s == nullptr) return;  // not inside a stream capture
+    if (!loss_event && hipEventCreateWithFlags(&loss_event, hipEventDisableTiming) != hipSuccess) {
+      loss_event = nullptr;
+      (void)hipGetLastError();
+      return;
+    }
+    hipMemcpyAsync(loss_host, loss_dev_ptr, sizeof(float), hipMemcpyDeviceToHost, s);
+    hipEventRecord(loss_event, s);
+    loss_pending = true;
+  }
   GraphSeg segs[8];
   // hipGraph replay of the step is opt-in (MN_GRAPHS=1).  Measured on MI355X / ROCm 7.2 (tools/ab.sh): replaying the
   // captured step is 2 % SLOWER than enqueueing its ~250 launches directly (19.57 vs 19.17 ms; the host enqueues a
@@ -742,6 +759,7 @@ struct Plan : PlanBase {
     if (!grads_zeroed) hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, s);  // optim.learner.zero_grad()
     grads_zeroed = false;
     run_criterion(poses, cur_targets, cur_loss, dposes, grads + L.crit, s);
+    post_loss(cur_loss, s);
     hipLaunchKernelGGL(head_bwd_input_kernel, dim3(cdiv((long)B * F, 256)), dim3(256), 0, s, (const float*)dposes,
                        (const float*)feat, (const float*)(params + L.xyz_w), (const float*)(params + L.wpqr_w), dz, B, F,
                        cfg.filter_nans);
@@ -923,6 +941,23 @@ extern "C" int mn_set_step_count(mn_handle* h, int64_t step) {
   return 0;
 }
 extern "C" int64_t mn_get_step_count(mn_handle* h) { return (h && h->plan) ? h->plan->step : -1; }
+extern "C" int mn_set_loss_host(mn_handle* h, float* pinned_host) {
+  MN_H(h);
+  P.loss_host = pinned_host;
+  P.loss_pending = false;
+  return 0;
+}
+extern "C" int mn_wait_loss(mn_handle* h) {
+  if (!h || !h->plan) return -1;
+  PlanBase& P = *h->plan;
+  if (!P.loss_pending) return 1;  // nothing was posted (graph replay, default stream): read the device scalar instead
+  P.loss_pending = false;
+  if (hipEventSynchronize(P.loss_event) != hipSuccess) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  return 0;
+}
 extern "C" int mn_set_input_u8(mn_handle* h, int enable, const float* mean, const float* std) {
   MN_H(h);
   if (enable && (!mean || !std)) return fail("mn_set_input_u8: mean and std (3 floats each, host memory) are required");

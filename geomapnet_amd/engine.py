@@ -5,6 +5,7 @@ BatchNorm buffers, per-plan work arena) and as the source of the current HIP str
 arithmetic happens in libmapnet_hip.so.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -37,6 +38,22 @@ def _stream(t):
     if t.is_cuda:
         return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     return None
+
+
+class _StepLoss:
+    """What `Engine.train_step` returns for the loss: `.item()` is the reference's blocking read-back
+    (common/train.py:361) but only waits for the criterion, not for the rest of the step."""
+
+    def __init__(self, engine, plan):
+        self._e, self._p, self._v = engine, plan, None
+
+    def item(self):
+        if self._v is None:
+            self._v = self._e._loss_value(self._p)
+        return self._v
+
+    def __float__(self):
+        return self.item()
 
 
 class Engine:
@@ -205,6 +222,9 @@ class Engine:
     def train_step(self, p, images, targets):
         if "poses" not in p:
             p["poses"] = torch.empty(p["images"], 6, dtype=torch.float32, device=self.device)
+            if self.params.is_cuda and os.environ.get("MN_EARLY_LOSS", "1") != "0":
+                p["loss_host"] = torch.zeros(1, dtype=torch.float32).pin_memory()
+                self.lib.check(self.lib.set_loss_host(p["handle"], ptr(p["loss_host"])))
         side = self.step_stream()
         if side is None:
             self.lib.check(self.lib.train_step(p["handle"], ptr(images), ptr(targets), ptr(p["loss"]), ptr(p["poses"]), None))
@@ -219,7 +239,13 @@ class Engine:
             poses = p["poses"].clone()
         cur.wait_stream(side)
         self._stepped(p)
-        return p["loss"], poses
+        return _StepLoss(self, p), poses
+
+    def _loss_value(self, p):
+        """this step's loss as a Python float: the early host copy when the library posted one, else the device scalar"""
+        if "loss_host" in p and self.lib.wait_loss(p["handle"]) == 0:
+            return float(p["loss_host"][0])
+        return p["loss"].item()
 
     def _stepped(self, p):
         self.step_count += 1

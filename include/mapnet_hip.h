@@ -99,6 +99,12 @@ int mn_set_learn_flags(mn_handle* h, int learn_beta, int learn_gamma);
 int mn_set_optim(mn_handle* h, float lr, float weight_decay, float beta1, float beta2, float eps,
                  float max_grad_norm);
 int mn_set_step_count(mn_handle* h, int64_t step); /* Adam step counter (checkpoint resume) */
+/* Early read-back of the training loss (the reference's `loss.item()`, common/train.py:361): with a pinned host float
+ * registered, every training step copies the loss there as soon as the criterion has run and records an event;
+ * mn_wait_loss blocks on that event only (0 = *pinned_host holds this step's loss, 1 = nothing was posted -- read the
+ * device scalar passed as loss_out instead), while backward and the optimiser of the same step are still running. */
+int mn_set_loss_host(mn_handle* h, float* pinned_host);
+int mn_wait_loss(mn_handle* h);
 int64_t mn_get_step_count(mn_handle* h);
 
 /* replaces model(data_var) in step_feedfwd (common/train.py:343) = MapNet.forward / PoseNet.forward

@@ -692,6 +692,8 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
     return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);
   if (cfg == 10 && g.N >= 256 && g.N % 128 == 0)  // 256x256, 4 waves of 128x128 (one wave per SIMD)
     return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 3, 1>(g, A, Bw, ep, stream, zero_page);
+  // (measured and removed: 576x128 tiles, 12 waves (6x2) of 96x64, 64-byte K-steps, 3 buffers for N = 128 -- layer2 in
+  // 1.8 rounds of one workgroup per CU: 121 / 120 us vs 117 / 122 us)
   if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);  // 256x128, 8 waves
   // 288x256, 12 waves of 96x64, 128-byte K-steps, 2 buffers, one workgroup per CU: M = B*P*Q of the 256x341 input at
   // B = 192 is 132 * 2^k, and 288-row tiles put layer3 (67584 rows, N = 256) on 235 of the 256 CUs in ONE round

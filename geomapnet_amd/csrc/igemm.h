@@ -164,7 +164,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // SPL: the NBUF-1-ahead tile's DMA instructions are not issued in one burst after the barrier but spread over the
 // K-step's MFMA sub-steps (behind each sub-step's MFMAs), so that the first fragment reads and MFMAs of a K-step do not
 // queue behind the burst.
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SK = false, bool SPL = false>
+// ABL (timing experiments only, results are wrong; tools/conv_bench.py with MN_ABLATE): bit 0 = no DMA in the main
+// loop, bit 1 = fragments from registers instead of ds_reads, bit 2 = no barrier in the main loop.
+// (A "rotated" loop -- K-step boundary before the last MFMA sub-step, first fragments of the next tile read there so
+// that their LDS latency hides under the previous tile's MFMAs -- was implemented, emulator-verified and measured
+// neutral on the 288x256, 128x128 and 128x64 configurations; removed.)
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SK = false, bool SPL = false,
+          int ABL = 0>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                          const T* __restrict__ zero_page, RowDiv rd,
@@ -368,8 +374,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
       wait_vmcnt<IPT>();
     else
       wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everyone is done reading buffer `nxt`
-    const bool more = kt + D < NK;
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everyone is done reading buffer `nxt`
+    const bool more = (ABL & 1) ? false : kt + D < NK;
     if (!SPL && more) issue_tile(nxt);  // tiles are issued strictly in K order
     const piece_t* ta = &smem[cur * TILE_PIECES];
     // fragments are register double-buffered: the ds_reads of sub-step ks+1 are issued before the MFMAs
@@ -393,6 +399,14 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
       const int pxs = (ks * 2 + (ln >> 5)) ^ lds_swz<NP>(ln & 31);
       const piece_t* pa = ta + (wm * WTM + (ln & 31)) * NP + pxs;
       const piece_t* pb = ta + (BM + wn * WTN + (ln & 31)) * NP + pxs;
+      if constexpr ((ABL & 2) != 0) {
+        const piece_t fake = {(unsigned)ln, (unsigned)kt, (unsigned)ks, (unsigned)pxs};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i].p = fake;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j].p = fake;
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[slot][i].p = pa[i * 32 * NP];
 #pragma unroll
@@ -619,7 +633,7 @@ inline int igemm_sk_blocks() {
 }
 
 template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI = true, bool ALLOW_SK = false,
-          bool SPL = false>
+          bool SPL = false, int ABL = 0>
 inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
                             const T* zero_page, int sk_blocks = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -634,7 +648,7 @@ inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const 
       return gm;
     }
   }
-  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL>), dim3(gm * gn), dim3(WM * WN * 64), 0,
+  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL, ABL>), dim3(gm * gn), dim3(WM * WN * 64), 0,
                      stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
   return gm;
 }
@@ -649,6 +663,9 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   // restores the stored order
   static const int tap_inner = getenv("MN_TAP_INNER") ? atoi(getenv("MN_TAP_INNER")) : 1;
   g.tap_inner = ((tap_inner && g.R * g.S > 1) || g.bt_on) ? 1 : 0;
+  // split DMA issue (SPL): bit 0 = the 288x256 configuration (on: dgrad 95.8 -> 90.1 us, with residual 111.7 -> 103.6),
+  // bit 1 = the 128x128 configuration (off: 114 -> 120 us); MN_SPLIT_DMA overrides
+  static const int spl = getenv("MN_SPLIT_DMA") ? atoi(getenv("MN_SPLIT_DMA")) : 1;
   const bool wide_k = (g.C / VEC) % 8 == 0;  // 128-byte K-steps need taps that are a multiple of them
   int cfg = igemm_config();
   // channel counts that are not a multiple of the K-step (stem pixel pairs, odd test shapes): per-lane tap walk
@@ -697,10 +714,15 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);  // 256x128, 8 waves
   // 288x256, 12 waves of 96x64, 128-byte K-steps, 2 buffers, one workgroup per CU: M = B*P*Q of the 256x341 input at
   // B = 192 is 132 * 2^k, and 288-row tiles put layer3 (67584 rows, N = 256) on 235 of the 256 CUs in ONE round
-  // split DMA issue (SPL): bit 0 = the 288x256 configuration (on: dgrad 95.8 -> 90.1 us, with residual 111.7 -> 103.6),
-  // bit 1 = the 128x128 configuration (off: 114 -> 120 us); MN_SPLIT_DMA overrides
-  static const int spl = getenv("MN_SPLIT_DMA") ? atoi(getenv("MN_SPLIT_DMA")) : 1;
   if (cfg == 12 && wide_k && g.N % 256 == 0) {
+#ifdef MN_ABLATION_BUILD
+    static const int abl = getenv("MN_ABLATE") ? atoi(getenv("MN_ABLATE")) : 0;
+    if (abl == 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 1>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 2) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 2>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 3) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 3>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 4) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 4>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 7) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 7>(g, A, Bw, ep, stream, zero_page);
+#endif
     if (spl & 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true>(g, A, Bw, ep, stream, zero_page);
     return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);
   }

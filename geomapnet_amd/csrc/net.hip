@@ -16,6 +16,7 @@
 #include "head.h"
 #include "igemm.h"
 #include "dgrad.h"
+#include "halo.h"
 #include "layout.h"
 #include "optim.h"
 #include "pool.h"
@@ -561,9 +562,15 @@ struct Plan : PlanBase {
     ep.sk_ws = sk_ws;
     ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
-    launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
+    if (halo_path(u.gf))
+      launch_conv_halo(u.gf, (const half*)x, (const half*)u.wf, ep, s);
+    else
+      launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
     timer.end(tp, s);
   }
+  // layer1's 64-channel 3x3 convolutions (forward and data gradient) run from an LDS-resident input halo (halo.h)
+  bool use_halo = DT == MN_F16 && !(getenv("MN_HALO") && atoi(getenv("MN_HALO")) == 0);
+  bool halo_path(const GatherGeom& g) const { return use_halo && conv_halo_applies(g); }
   void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s) {
     long np = u.M * u.cp.cout / VEC;
     hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const double*)u.accum_f,
@@ -691,7 +698,10 @@ struct Plan : PlanBase {
     ep.sk_ws = sk_ws;
     ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
-    launch_conv_dgrad<T>(u.dg, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page, parity_dgrad);
+    if (halo_path(u.dg.full))
+      launch_conv_halo(u.dg.full, (const half*)u.gy, (const half*)u.wd, ep, s);
+    else
+      launch_conv_dgrad<T>(u.dg, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page, parity_dgrad);
     timer.end(tp, s);
   }
   // Weight-gradient schedule (MN_WGRAD_SCHED): 0 = one fork per block, after its last BatchNorm backward;

@@ -9,6 +9,7 @@
 #include "head.h"
 #include "igemm.h"
 #include "dgrad.h"
+#include "halo.h"
 #include "optim.h"
 #include "pgo.h"
 #include "pool.h"
@@ -72,6 +73,21 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
     launch_igemm<float>(g, (const float*)A, (const float*)Bw, ep, (hipStream_t)stream, (const float*)zero_page);
   return check_launch("igemm");
 }
+
+extern "C" int mn_op_conv_halo(const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc, float* stats,
+                              const float* bias, int relu, const void* res, const void* res_gate, const void* out_gate,
+                              float alpha, void* stream) {
+  begin_call();
+  GatherGeom g = to_geom(gg);
+  if (int e = check_geom(g, MN_F16)) return e;
+  if (!conv_halo_applies(g)) return fail("conv_halo: fp16 3x3 stride-1 same-size convolutions of 64 input channels only");
+  Epilogue ep;
+  ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
+  ep.out_gate = out_gate; ep.alpha = alpha;
+  launch_conv_halo(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream);
+  return check_launch("conv_halo");
+}
+extern "C" int mn_op_conv_halo_grid_m(const mn_gather_geom* gg) { return conv_halo_grid_m(to_geom(gg)); }
 
 extern "C" int mn_op_igemm_streamk(int dtype, const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc,
                                    float* stats, const float* bias, int relu, const void* res, const void* res_gate,

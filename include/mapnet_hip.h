@@ -172,6 +172,14 @@ int mn_op_igemm_streamk(int dtype, const mn_gather_geom* g, const void* A, const
 /* dW[n][colmap(k)] += alpha * sum_m dY[m][n] * gather(X)[m][k]  (fp32 atomics into dW) */
 int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw,
                 const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream);
+/* fp16 3x3 stride-1 same-size convolution of 64 input channels (ResNet layer1 forward, and -- with the mirrored
+ * geometry rsign = ssign = -1 -- its data gradient) with the 18x18-pixel input halo of a 16x16-pixel output tile staged
+ * once in LDS and the taps walked as address offsets (csrc/halo.h); same operands and epilogue as mn_op_igemm plus
+ * out_gate (result zeroed where out_gate <= 0).  stats: [mn_op_conv_halo_grid_m(g)][2][N] partial column sums or NULL. */
+int mn_op_conv_halo(const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
+                    const float* bias, int relu, const void* res, const void* res_gate, const void* out_gate, float alpha,
+                    void* stream);
+int mn_op_conv_halo_grid_m(const mn_gather_geom* g);
 /* Data gradient of a convolution (what autograd computes for conv2d's input, torch 0.4.1 `loss.backward()` under
  * common/train.py:351): gx[B][Hin][Win][Cin] = conv_transpose(gy[B][Hout][Wout][Cout], W) (+ res, res only where
  * res_gate > 0), zeroed where out_gate <= 0.  wd: weights in the data-gradient layout [Cin][k][k][Cout].  stride 1 or 2;

@@ -196,6 +196,59 @@ def check_conv_dgrad_op(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, par
     assert err <= OUT_TOL[dtype] * want.abs().max().item() + 1e-6, err
 
 
+def check_conv_halo(lib, dev, B, H, W, Cout=64, dgrad=False, mode="plain", seed=21):
+    """fp16 3x3 stride-1 convolution of 64 input channels from an LDS-resident halo tile (csrc/halo.h) vs torch fp64:
+    forward (with BatchNorm column sums) or data gradient, epilogue variants as check_conv_dgrad_op; ragged tiles
+    (H, W not multiples of 16) exercise the out-of-image masks"""
+    _fresh()
+    td, Cin, k = torch.float16, 64, 3
+    gen = torch.Generator().manual_seed(seed)
+    if not dgrad:
+        g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, k, 1, 1)
+        x = torch.randn(B, Cin, H, W, generator=gen).to(td).float()
+        w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.1).to(td).float()
+        want = F.conv2d(x.double(), w.double(), padding=1).permute(0, 2, 3, 1).contiguous()
+        a = _nhwc(x, td, dev)
+        bw = w.permute(0, 2, 3, 1).contiguous().to(td).to(dev)  # [Cout][R][S][Cin]
+        N = Cout
+    else:
+        # data gradient of a conv with `Cout` output channels and 64 INPUT channels would have C = Cout; the kernel
+        # needs C = 64, so the gradient case is conv(Cx -> 64): gy has 64 channels, gx has Cout channels
+        g, Ho, Wo = dgrad_geom(B, H, W, Cout, 64, k, 1, 1)
+        gy = torch.randn(B, 64, H, W, generator=gen).to(td).float()
+        w = (torch.randn(64, Cout, k, k, generator=gen) * 0.1).to(td).float()
+        xin = torch.zeros(B, Cout, H, W, dtype=torch.double, requires_grad=True)
+        F.conv2d(xin, w.double(), padding=1).backward(gy.double())
+        want = xin.grad.permute(0, 2, 3, 1).contiguous()
+        a = _nhwc(gy, td, dev)
+        bw = w.permute(1, 2, 3, 0).contiguous().to(td).to(dev)  # [Cin][R][S][Cout]
+        N = Cout
+    res = rgate = ogate = None
+    if mode in ("res_gate", "out_gate"):
+        res = torch.randn(B, H, W, N, generator=gen).to(td)
+        if mode == "res_gate":
+            rgate = torch.randn(B, H, W, N, generator=gen).to(td)
+            want = want + torch.where(rgate.double() > 0, res.double(), torch.zeros_like(res.double()))
+            rgate = rgate.to(dev)
+        else:
+            want = want + res.double()
+            ogate = torch.randn(B, H, W, N, generator=gen).to(td)
+            want = torch.where(ogate.double() > 0, want, torch.zeros_like(want))
+            ogate = ogate.to(dev)
+        res = res.to(dev)
+    out = torch.full((B, H, W, N), 7.0, dtype=td, device=dev)
+    st = torch.zeros(lib.op_conv_halo_grid_m(C.byref(g)), 2, N, device=dev) if not dgrad else None
+    lib.check(lib.op_conv_halo(C.byref(g), K(a), K(bw), K(out), N, K(st), None, 0, K(res), K(rgate), K(ogate), f32(1), None))
+    dev_sync(dev)
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err <= OUT_TOL[1] * want.abs().max().item() + 1e-6, err
+    if st is not None:
+        sums = st.cpu().double().sum(0)
+        ref = want.reshape(-1, N)
+        assert (sums[0] - ref.sum(0)).abs().max().item() <= 2e-3 * ref.abs().sum(0).max().item()
+        assert (sums[1] - (ref * ref).sum(0)).abs().max().item() <= 2e-3 * (ref * ref).sum(0).max().item()
+
+
 def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target_blocks=8, seed=2):
     _fresh()
     td = TD[dtype]

@@ -118,3 +118,16 @@ def test_pose_graph_properties(lib):
 @pytest.mark.parametrize("parity", [1, 0])
 def test_conv_data_gradient_op(lib, dtype, shape, mode, parity):
     checks.check_conv_dgrad_op(lib, DEV, dtype, *shape, parity=parity, mode=mode)
+
+
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, 64, False, "plain"),     # one full tile per image
+    (1, 20, 22, 64, False, "plain"),     # ragged in both directions: 2 x 2 tiles, masks in the statistics
+    (2, 9, 11, 128, False, "plain"),     # smaller than a tile, two N tiles
+    (1, 20, 22, 64, True, "res_gate"),   # data gradient with the gated identity path
+    (2, 17, 16, 64, True, "out_gate"),
+    (1, 16, 35, 72, True, "plain"),      # N not a multiple of 64
+])
+def test_conv_halo(lib, case):
+    B, H, W, Cout, dgrad, mode = case
+    checks.check_conv_halo(lib, DEV, B, H, W, Cout=Cout, dgrad=dgrad, mode=mode)

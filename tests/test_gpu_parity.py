@@ -42,6 +42,18 @@ def test_conv_data_gradient(lib, dtype, shape):
     checks.check_conv_dgrad(lib, DEV, dtype, *shape)
 
 
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, 64, False, "plain"), (1, 20, 22, 64, False, "plain"), (2, 9, 11, 128, False, "plain"),
+    (1, 20, 22, 64, True, "res_gate"), (2, 17, 16, 64, True, "out_gate"), (1, 16, 35, 72, True, "plain"),
+    (6, 64, 86, 64, False, "plain"),     # layer1 geometry at 256x341
+    (6, 64, 86, 64, True, "out_gate"),
+    (6, 64, 86, 64, True, "res_gate"),
+])
+def test_conv_halo(lib, case):
+    B, H, W, Cout, dgrad, mode = case
+    checks.check_conv_halo(lib, DEV, B, H, W, Cout=Cout, dgrad=dgrad, mode=mode)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape,mode", [
     ((2, 8, 11, 64, 128, 3, 2, 1), "plain"), ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"), ((1, 8, 12, 64, 128, 3, 2, 1), "res_gate"),

@@ -51,6 +51,11 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
     t_d = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_r = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), ptr(gate), one, ptr(checks.zero_page("cuda")), None))
     t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, ptr(checks.zero_page("cuda")), None))
+    if dtype == 1 and Ci == 64 and k == 3 and stride == 1:
+        th_f = timeit(lambda: lib.op_conv_halo(C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, 0, None, None, None, one, None))
+        th_d = timeit(lambda: lib.op_conv_halo(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, None, one, None)) if Co == 64 else float("nan")
+        th_r = timeit(lambda: lib.op_conv_halo(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), None, ptr(gate), one, None)) if Co == 64 else float("nan")
+        print("%-22s halo kernel: fwd %7.1f us %6.0f TF | dgrad %7.1f us | +res+out_gate %7.1f us" % (name, th_f, flops / th_f / 1e6, th_d, th_r), flush=True)
     io = (x.numel() + y.numel()) * x.element_size()
     print("%-22s M=%8d N=%4d K=%5d  fwd %7.1f us %6.0f TF (io %5.2f TB/s) | dgrad %7.1f us %6.0f TF | +res %7.1f us | wgrad %7.1f us %6.0f TF"
           % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, io / t_f / 1e6, t_d, flops / t_d / 1e6, t_r, t_w, flops / t_w / 1e6), flush=True)

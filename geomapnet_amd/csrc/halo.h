@@ -144,79 +144,86 @@ static __global__ void __launch_bounds__(256, 2) conv_halo_kernel(GatherGeom g, 
   const half* res = reinterpret_cast<const half*>(ep.res);
   const half* gate = reinterpret_cast<const half*>(ep.res_gate);
   const half* ogate = reinterpret_cast<const half*>(ep.out_gate);
-  float* stage = reinterpret_cast<float*>(&smem[0]);  // [64][64] fp32 sub-block
-  constexpr int SC = BN, CPR = SC / VEC, PASSES = 64 * CPR / NT;
+  float* stage = reinterpret_cast<float*>(&smem[0]);  // [128][64] fp32: MFMA row tile i of all four waves (32 KB)
+  constexpr int SC = BN, CPR = SC / VEC, PASSES = 128 * CPR / NT;  // 4 output pieces per thread and round
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
   const bool want_stats = ep.stats != nullptr || ep.stats_accum != nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-    for (int mh = 0; mh < WM / 2; ++mh) {
-      if ((wm >> 1) == mh) {
+  for (int i = 0; i < 2; ++i) {
+    // the residual / gate pieces of this round are requested first: their latency runs under the staging below
+    PieceView<half> rv[PASSES], gv[PASSES], ov[PASSES];
+    long idxs[PASSES];
+    bool oks[PASSES];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int lc = j * 32 + l31;
-          const float bias = (ep.bias && n0 + lc < g.N) ? ep.bias[n0 + lc] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[i][j][r] * ep.alpha + bias;
-            if (ep.relu & 1) v = fmaxf(v, 0.f);
-            const int rt = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // row inside the 32-row MFMA tile
-            if (want_stats) {
-              const int rl = wm * 64 + i * 32 + rt;  // tile-local row = pixel (rl >> 4, rl & 15)
-              const bool ok = y0 + (rl >> 4) < g.P && x0 + (rl & 15) < g.Q;
-              const float vs = ok ? v : 0.f;
-              s1[j] += vs;
-              s2[j] += vs * vs;
-            }
-            stage[((wm & 1) * 32 + rt) * SC + lc] = v;
-          }
-        }
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int id = t + ps * NT;
+      const int lr = id / CPR, cpc = id % CPR;
+      const int rl = (lr >> 5) * 64 + i * 32 + (lr & 31);
+      const int y = y0 + (rl >> 4), x = x0 + (rl & 15);
+      const int col = n0 + cpc * VEC;
+      oks[ps] = y < g.P && x < g.Q && col < g.N;
+      idxs[ps] = (((long)b * g.P + y) * g.Q + x) * ep.ldc + col;
+      if (oks[ps]) {
+        if (res) rv[ps].p = *reinterpret_cast<const piece_t*>(res + idxs[ps]);
+        if (res && gate) gv[ps].p = *reinterpret_cast<const piece_t*>(gate + idxs[ps]);
+        if (ogate) ov[ps].p = *reinterpret_cast<const piece_t*>(ogate + idxs[ps]);
       }
-      __syncthreads();
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
-        const int id = t + ps * NT;
-        const int lr = id / CPR, cpc = id % CPR;
-        const int rl = (2 * mh + (lr >> 5)) * 64 + i * 32 + (lr & 31);
-        const int y = y0 + (rl >> 4), x = x0 + (rl & 15);
-        const int col = n0 + cpc * VEC;
-        if (y < g.P && x < g.Q && col < g.N) {
-          float v[VEC];
-#pragma unroll
-          for (int e = 0; e < VEC; e += 4) {
-            floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * SC + cpc * VEC + e]);
-            v[e] = f[0];
-            v[e + 1] = f[1];
-            v[e + 2] = f[2];
-            v[e + 3] = f[3];
-          }
-          const long idx = (((long)b * g.P + y) * g.Q + x) * ep.ldc + col;
-          if (res) {
-            PieceView<half> rv, gv;
-            rv.p = *reinterpret_cast<const piece_t*>(res + idx);
-            if (gate) gv.p = *reinterpret_cast<const piece_t*>(gate + idx);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              float xr = (float)rv.e[e];
-              if (gate && !((float)gv.e[e] > 0.f)) xr = 0.f;
-              v[e] += xr;
-            }
-          }
-          if (ogate) {
-            PieceView<half> ov;
-            ov.p = *reinterpret_cast<const piece_t*>(ogate + idx);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e)
-              if (!((float)ov.e[e] > 0.f)) v[e] = 0.f;
-          }
-          PieceView<half> o;
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) o.e[e] = (half)v[e];
-          *reinterpret_cast<piece_t*>(out + idx) = o.p;
-        }
-      }
-      __syncthreads();
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int lc = j * 32 + l31;
+      const float bias = (ep.bias && n0 + lc < g.N) ? ep.bias[n0 + lc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] * ep.alpha + bias;
+        if (ep.relu & 1) v = fmaxf(v, 0.f);
+        const int rt = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // row inside the 32-row MFMA tile
+        if (want_stats) {
+          const int rl = wm * 64 + i * 32 + rt;  // tile-local row = pixel (rl >> 4, rl & 15)
+          const bool ok = y0 + (rl >> 4) < g.P && x0 + (rl & 15) < g.Q;
+          const float vs = ok ? v : 0.f;
+          s1[j] += vs;
+          s2[j] += vs * vs;
+        }
+        stage[(wm * 32 + rt) * SC + lc] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int id = t + ps * NT;
+      const int lr = id / CPR, cpc = id % CPR;
+      if (oks[ps]) {
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+          floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * SC + cpc * VEC + e]);
+          v[e] = f[0];
+          v[e + 1] = f[1];
+          v[e + 2] = f[2];
+          v[e + 3] = f[3];
+        }
+        if (res) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float xr = (float)rv[ps].e[e];
+            if (gate && !((float)gv[ps].e[e] > 0.f)) xr = 0.f;
+            v[e] += xr;
+          }
+        }
+        if (ogate) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (!((float)ov[ps].e[e] > 0.f)) v[e] = 0.f;
+        }
+        PieceView<half> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.e[e] = (half)v[e];
+        *reinterpret_cast<piece_t*>(out + idxs[ps]) = o.p;
+      }
+    }
+    __syncthreads();
+  }
   if (want_stats) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

@@ -163,7 +163,7 @@ def main():
             except Exception:
                 pass
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "kernel": "igemm_kernel + wgrad_kernel (all %d conv launches of a step)" % (conv_launches // args.steps),
+                    "traffic": traffic, "kernel": "igemm_kernel + conv_halo_kernel + wgrad_kernel (all %d conv launches of a step)" % (conv_launches // args.steps),
                     "conv_ms_per_step": round(conv_ms_step, 3), "eager_profiled_ms_per_step": round(eager_ms, 3),
                     "flops_per_step_G": round(GFLOP_PER_IMAGE_TRAIN * n * T, 1),
                     "whole_step_frac": round(GFLOP_PER_IMAGE_TRAIN * n * T / ms_per_step / peak, 4)}

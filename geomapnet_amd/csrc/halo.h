@@ -15,6 +15,8 @@
 // ring; LDS 62 KB -> two workgroups per CU.  LDS image: pixel-major, 8 pieces of 16 bytes per pixel, piece slot XOR-swizzled by (pixel >> 1) & 7 on the
 // source side of the DMA and in the fragment address (rows of a ds_read_b128 lane group are consecutive pixels of a
 // halo row: conflict-free within a row, 2-way on two banks where a lane group spans two rows).
+// (Measured and not kept: a 4-deep weight ring, 141 vs 138 us; 32-channel sub-steps -- fragment reads 256 instead of 128
+// matrix-pipe cycles ahead of their use -- 130 vs 126 us.)
 // Epilogue as igemm's (alpha, BatchNorm column sums, residual / gates, 16-byte stores), with tile rows mapped back to
 // pixels and out-of-image pixels of ragged tiles (341 / 4 = 86 = 5*16 + 6 columns) masked out of the statistics.
 #pragma once

@@ -131,3 +131,27 @@ def test_conv_data_gradient_op(lib, dtype, shape, mode, parity):
 def test_conv_halo(lib, case):
     B, H, W, Cout, dgrad, mode = case
     checks.check_conv_halo(lib, DEV, B, H, W, Cout=Cout, dgrad=dgrad, mode=mode)
+
+
+def _random_cases(seed, n):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 3)), int(rng.integers(3, 37)), int(rng.integers(3, 37))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _random_cases(2024, 5))
+def test_conv_halo_random_geometry(lib, case):
+    """seeded random image sizes (ragged tiles, images smaller than one tile), forward with statistics and data
+    gradient with the gated identity path"""
+    B, H, W = case
+    checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=False, mode="plain", seed=H * 100 + W)
+    checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=True, mode="out_gate", seed=H * 100 + W + 1)
+
+
+@pytest.mark.parametrize("case", _random_cases(77, 4))
+def test_conv_data_gradient_parity_random_geometry(lib, case):
+    """stride-2 data gradient by parity classes vs the generic form's reference on seeded random image sizes"""
+    B, H, W = case
+    H, W = max(H, 4), max(W, 4)
+    checks.check_conv_dgrad_op(lib, DEV, 1, B, H, W, 64, 128, 3, 2, 1, parity=1, mode="out_gate", seed=H * 100 + W)
+    checks.check_conv_dgrad_op(lib, DEV, 0, B, H, W, 64, 128, 1, 2, 0, parity=1, mode="inplace", seed=H * 100 + W + 1)

@@ -97,7 +97,10 @@ def evaluate(model, batches, pose_m=(0.0, 0.0, 0.0), pose_s=(1.0, 1.0, 1.0), cud
         model.train(was_training)
     if pose_graph and win_out:
         from .pgo import optimize_windows
-        opt = optimize_windows(np.stack(win_out), np.stack(win_vos), fc_vos=fc_vos, sax=sax, saq=saq, srx=srx, srq=srq)
+        from .posenet import engine_of
+        eng = engine_of(model)  # the optimisation runs on the model's device, through the model's kernel library
+        opt = optimize_windows(np.stack(win_out), np.stack(win_vos), fc_vos=fc_vos, sax=sax, saq=saq, srx=srx, srq=srq,
+                               device=eng.device, binding=eng.lib)
         opt[:, :, :3] = (opt[:, :, :3] * np.asarray(pose_s, dtype=np.float64)) + np.asarray(pose_m, dtype=np.float64)
         pred = [o[len(o) // 2] for o in opt]
     pred_poses, targ_poses = np.asarray(pred), np.asarray(targ)

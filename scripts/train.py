@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Training script for PoseNet and the MapNet variants on the MI355X hot path.
+
+Command line of the reference's scripts/train.py (/root/reference/scripts/train.py:25-43: --dataset --scene
+--config_file --model --device --checkpoint --learn_beta --learn_gamma --resume_optim --suffix) and the same
+construction order: model, criterion, optimizer with the criterion scalars as extra parameter groups, datasets,
+Trainer.train_val.  Differences, all additive:
+
+* `--dataset Synthetic` (the only image source that ships: the 7Scenes / RobotCar readers are host-side file
+  parsers outside the hot path -- pass your own Dataset objects to `run(..., datasets=(train, val))`);
+  `--synthetic_length`, `--height`, `--width` size it.
+* `--dtype fp16|fp32` selects the compute precision of the HIP kernels (fp16 storage + fp32 accumulate, or the
+  fp32 parity build).
+* `--epochs`, `--batch_size`, `--logdir` override the config file (smoke runs).
+* launched under `python -m torch.distributed.run --nproc-per-node N scripts/train.py ...` it trains data
+  parallel: one process per GPU, windows sharded, gradient buckets all-reduced over RCCL during backward.
+"""
+import argparse
+import configparser
+import json
+import os
+import os.path as osp
+import sys
+
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Training script for PoseNet and MapNet variants")
+    parser.add_argument("--dataset", type=str, choices=("7Scenes", "RobotCar", "Synthetic"), default="Synthetic",
+                        help="Dataset")
+    parser.add_argument("--scene", type=str, default="synthetic", help="Scene name")
+    parser.add_argument("--config_file", type=str, help="configuration file")
+    parser.add_argument("--model", choices=("posenet", "mapnet", "mapnet++"), help="Model to train")
+    parser.add_argument("--device", type=str, default="0", help="value to be set to $CUDA_VISIBLE_DEVICES")
+    parser.add_argument("--checkpoint", type=str, help="Checkpoint to resume from", default=None)
+    parser.add_argument("--learn_beta", action="store_true", help="Learn the weight of translation loss")
+    parser.add_argument("--learn_gamma", action="store_true", help="Learn the weight of rotation loss")
+    parser.add_argument("--resume_optim", action="store_true",
+                        help="Resume optimization (only effective if a checkpoint is given")
+    parser.add_argument("--suffix", type=str, default="", help="Experiment name suffix (as is)")
+    # additions
+    parser.add_argument("--dtype", choices=("fp16", "fp32"), default="fp16", help="compute precision of the HIP kernels")
+    parser.add_argument("--synthetic_length", type=int, default=1024, help="frames in the synthetic sequence")
+    parser.add_argument("--synthetic_val_length", type=int, default=None, help="frames in the validation sequence "
+                        "(default: a quarter of --synthetic_length)")
+    parser.add_argument("--height", type=int, default=256)
+    parser.add_argument("--width", type=int, default=341)
+    parser.add_argument("--epochs", type=int, default=None, help="override [training] n_epochs")
+    parser.add_argument("--batch_size", type=int, default=None, help="override [training] batch_size")
+    parser.add_argument("--num_workers", type=int, default=None, help="override [training] num_workers")
+    parser.add_argument("--logdir", type=str, default=None, help="checkpoint directory (default logs/<experiment>)")
+    return parser
+
+
+def _init_distributed():
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    return world
+
+
+def run(args, datasets=None, _binding=None, log=print):
+    """builds everything the reference's script builds and runs Trainer.train_val; returns the Trainer.
+    `_binding` (tests) substitutes another build of the kernel library for libmapnet_hip.so."""
+    import torch
+    import geomapnet_amd as G
+    from geomapnet_amd.data import MF, MFOnline, SyntheticFrames
+    from geomapnet_amd.trainer import Trainer
+
+    _init_distributed()
+    G.set_compute_dtype(args.dtype)
+    kw = {} if _binding is None else {"_binding": _binding}
+
+    settings = configparser.ConfigParser()
+    with open(args.config_file, "r") as f:
+        settings.read_file(f)
+    if args.epochs is not None:
+        settings["training"]["n_epochs"] = str(args.epochs)
+    if args.batch_size is not None:
+        settings["training"]["batch_size"] = str(args.batch_size)
+    if args.num_workers is not None:
+        settings["training"]["num_workers"] = str(args.num_workers)
+    section = settings["optimization"]
+    optim_config = {k: json.loads(v) for k, v in section.items() if k != "opt"}
+    opt_method = section["opt"]
+    lr = optim_config.pop("lr")
+    weight_decay = optim_config.pop("weight_decay")
+
+    section = settings["hyperparameters"]
+    dropout = section.getfloat("dropout")
+    sax = 0.0
+    saq = section.getfloat("beta")
+    mapnet = args.model.find("mapnet") >= 0
+    online = args.model.find("++") >= 0
+    if mapnet:
+        skip = section.getint("skip")
+        real = section.getboolean("real")
+        variable_skip = section.getboolean("variable_skip")
+        srx = 0.0
+        srq = section.getfloat("gamma")
+        steps = section.getint("steps")
+    if online:
+        vo_lib = section.get("vo_lib", "orbslam")
+        log("Using {:s} VO".format(vo_lib))
+    seed = settings["training"].getint("seed")
+
+    # model (random initialisation: there is no model zoo offline; load weights with --checkpoint)
+    torch.manual_seed(seed)
+    feature_extractor = G.resnet34(pretrained=False, **kw)
+    posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=False, filter_nans=(args.model == "mapnet++"), **kw)
+    model = posenet if args.model == "posenet" else G.MapNet(mapnet=posenet)
+
+    # loss function
+    if args.model == "posenet":
+        train_criterion = G.PoseNetCriterion(sax=sax, saq=saq, learn_beta=args.learn_beta, **kw)
+        val_criterion = G.PoseNetCriterion(**kw)
+    else:
+        ckw = dict(sax=sax, saq=saq, srx=srx, srq=srq, learn_beta=args.learn_beta, learn_gamma=args.learn_gamma, **kw)
+        if online:
+            train_criterion = G.MapNetOnlineCriterion(gps_mode=(vo_lib == "gps"), **ckw)
+            val_criterion = G.MapNetOnlineCriterion(**kw)
+        else:
+            train_criterion = G.MapNetCriterion(**ckw)
+            val_criterion = G.MapNetCriterion(**kw)
+
+    # optimizer
+    param_list = [{"params": model.parameters()}]
+    if args.learn_beta and hasattr(train_criterion, "sax") and hasattr(train_criterion, "saq"):
+        param_list.append({"params": [train_criterion.sax, train_criterion.saq]})
+    if args.learn_gamma and hasattr(train_criterion, "srx") and hasattr(train_criterion, "srq"):
+        param_list.append({"params": [train_criterion.srx, train_criterion.srq]})
+    optimizer = G.Optimizer(params=param_list, method=opt_method, base_lr=lr, weight_decay=weight_decay, **optim_config)
+
+    # datasets
+    if datasets is not None:
+        train_frames, val_frames = datasets
+    elif args.dataset == "Synthetic":
+        train_frames = SyntheticFrames(args.synthetic_length, H=args.height, W=args.width, seed=seed)
+        n_val = args.synthetic_val_length if args.synthetic_val_length else max(args.synthetic_length // 4, 8)
+        val_frames = SyntheticFrames(n_val, H=args.height, W=args.width, seed=seed + 1)
+    else:
+        raise NotImplementedError(
+            "the {:s} image reader is host-side file parsing outside the MI355X hot path: build the frame datasets "
+            "yourself and call run(args, datasets=(train, val)), or use --dataset Synthetic".format(args.dataset))
+    if args.model == "posenet":
+        train_set, val_set = train_frames, val_frames
+    elif online:
+        train_set = MFOnline(train_frames, val_frames, gps_mode=(vo_lib == "gps"), val_gt_dataset=val_frames, steps=steps,
+                             skip=skip, variable_skip=variable_skip)
+        val_set = None
+    else:
+        mkw = dict(steps=steps, skip=skip, variable_skip=variable_skip, real=real)
+        train_set = MF(train_frames, train=True, **mkw)
+        val_set = MF(val_frames, train=False, **mkw)
+
+    # trainer
+    config_name = args.config_file.split("/")[-1].split(".")[0]
+    experiment_name = "{:s}_{:s}_{:s}_{:s}".format(args.dataset, args.scene, args.model, config_name)
+    if args.learn_beta:
+        experiment_name = "{:s}_learn_beta".format(experiment_name)
+    if args.learn_gamma:
+        experiment_name = "{:s}_learn_gamma".format(experiment_name)
+    experiment_name += args.suffix
+    trainer = Trainer(model, optimizer, train_criterion, settings, experiment_name, train_set, val_set, device=args.device,
+                      checkpoint_file=args.checkpoint, resume_optim=args.resume_optim, val_criterion=val_criterion,
+                      logdir=args.logdir, log=log)
+    trainer.train_val(lstm=False)
+    return trainer
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.config_file is None or args.model is None:
+        build_parser().error("--config_file and --model are required")
+    run(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -2,6 +2,7 @@
 ABI on a real MI355X, at small sizes against the oracle / torch fp64 and at BASELINE.json's full
 sizes through size-independent properties (adjoint identities, finite decreasing loss)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -273,3 +274,51 @@ def test_pose_graph_vs_oracle(lib, N, fc, sig):
 @pytest.mark.parametrize("fc", [False, True])
 def test_pose_graph_properties_at_eval_set_scale(lib, fc):
     checks.check_pgo_properties(lib, DEV, W=4096, N=7, fc=fc)
+
+
+def test_train_and_eval_command_lines(tmp_path):
+    """scripts/train.py -> checkpoint -> scripts/eval.py (plain and --pose_graph) on the product library: the reference's
+    command lines and Trainer loop, synthetic frames.  Kept last in this file."""
+    import configparser
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import train as train_script
+    import eval as eval_script
+
+    def config(name, **over):
+        s = configparser.ConfigParser()
+        s.read(os.path.join(root, "scripts", "configs", name))
+        for k, v in over.items():
+            s["hyperparameters" if k in ("skip", "steps") else "training"][k] = str(v)
+        fn = str(tmp_path / name)
+        with open(fn, "w") as f:
+            s.write(f)
+        return fn
+
+    cfg = config("mapnet.ini", n_epochs=2, batch_size=8, snapshot=1, val_freq=1, skip=2)
+    args = train_script.build_parser().parse_args(
+        ["--model", "mapnet", "--config_file", cfg, "--learn_beta", "--learn_gamma", "--dtype", "fp16", "--synthetic_length",
+         "32", "--synthetic_val_length", "8", "--height", "64", "--width", "85", "--num_workers", "0", "--logdir",
+         str(tmp_path / "logs")])
+    lines = []
+    tr = train_script.run(args, log=lines.append)
+    # (the validation loss itself is not asserted: eval-mode BatchNorm on a randomly initialised network after a handful
+    # of steps produces huge activations, checks.check_eval_flow)
+    assert sum(l.startswith("Val ") and "val_loss" in l for l in lines) == 2
+    ck = torch.load(tr.final_checkpoint, weights_only=False)
+    assert ck["epoch"] == 2 and ck["optim_state_dict"]["state"][0]["step"] == 8
+    assert all(torch.isfinite(v).all() for v in ck["model_state_dict"].values() if v.dtype == torch.float32)
+
+    eargs = eval_script.build_parser().parse_args(
+        ["--model", "mapnet", "--config_file", cfg, "--weights", tr.final_checkpoint, "--dtype", "fp32", "--synthetic_length",
+         "16", "--height", "64", "--width", "85", "--val"])
+    summary, pred, targ = eval_script.run(eargs, log=lines.append)
+    assert pred.shape == (16, 7) and np.isfinite(pred).all() and np.isfinite(summary["median_t"])
+    pcfg = config("pgo_inference.ini", skip=1, steps=5)
+    eargs = eval_script.build_parser().parse_args(
+        ["--model", "mapnet", "--config_file", pcfg, "--weights", tr.final_checkpoint, "--dtype", "fp32", "--synthetic_length",
+         "16", "--height", "64", "--width", "85", "--pose_graph"])
+    summary, pred, targ = eval_script.run(eargs, log=lines.append)
+    assert pred.shape == (16, 7) and np.isfinite(pred).all()
+    np.testing.assert_allclose(np.linalg.norm(pred[:, 3:], axis=1), 1.0, atol=1e-9)

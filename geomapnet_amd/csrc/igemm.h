@@ -236,12 +236,20 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   // UNI: a K-step never straddles a tap (C is a multiple of the step), so the tap walk is wave-uniform and
   // lives in scalar registers; otherwise (stem: 16-byte taps) every lane walks its own piece.
   constexpr bool uni = UNI;
-  unsigned d_off[IPT], a_inv[IPT];  // byte offset of the row (A: image pixel, B: weight row) and the A tap mask
+  // PACK: when at most three passes hold A rows (the 12-wave 288x256 configuration) their tap masks share ONE register,
+  // 10 bits each (launch_igemm only picks such a configuration for R*S <= 10).  That configuration is register-capped
+  // at 168 and the two registers decide whether the allocator keeps a row offset in scratch -- whose reload, inside the
+  // K loop, waits on vmcnt(0) behind the LDS-DMA queue.
+  constexpr int IPT_A = (BM + RPP - 1) / RPP;  // passes that hold A rows
+  constexpr bool PACK = UNI && IPT_A <= 3;
+  constexpr int PACK_BITS = 10;
+  unsigned d_off[IPT], a_inv[PACK ? 1 : IPT];  // byte offset of the row (A: image pixel, B: weight row) and the A tap mask
+  if constexpr (PACK) a_inv[0] = ~0u;
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
     const int jr = lrow + i * RPP;  // joint row of this thread in pass i
     d_off[i] = 0u;
-    a_inv[i] = ~0u;
+    if constexpr (!PACK) a_inv[i] = ~0u;
     const bool pure_a = (i + 1) * RPP <= BM, pure_b = i * RPP >= BM;
     if (pure_a || (!pure_b && jr < BM)) {
       const int m = m0 + jr;
@@ -275,7 +283,14 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
           ok = ok && (unsigned)hn < (unsigned)g.Hi;
           inv |= (ok ? cinv : call) << (r * g.S);
         }
-        a_inv[i] = inv | (g.R * g.S < 32 ? ~0u << (g.R * g.S) : 0u);
+        const unsigned full = inv | (g.R * g.S < 32 ? ~0u << (g.R * g.S) : 0u);
+        if constexpr (PACK) {
+          const int sh = (i < IPT_A ? i : 0) * PACK_BITS;
+          const unsigned field = ((1u << PACK_BITS) - 1u) << sh;
+          a_inv[0] = (a_inv[0] & ~field) | ((full << sh) & field);
+        } else {
+          a_inv[i] = full;
+        }
       }
     } else {
       const int br = jr - BM, n = n0 + br;
@@ -319,7 +334,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
         piece_t* dst = base + i * (RPP * NP);
         if (pure_a || (!pure_b && wave * (64 / NP) + i * RPP < BM)) {  // wave-uniform
           // all ones where the tap is outside the image: the buffer bounds check then returns zero
-          const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(a_inv[i], tap, 1);
+          const unsigned inv = PACK ? (unsigned)__builtin_amdgcn_sbfe(a_inv[0], tap + (i < IPT_A ? i : 0) * PACK_BITS, 1)
+                                    : (unsigned)__builtin_amdgcn_sbfe(a_inv[PACK ? 0 : i], tap, 1);
           dma16(rsrc_a, (d_off[i] + toff) | inv, 0u, dst);
         } else {
           dma16(rsrc_b, d_off[i], bs, dst);
@@ -697,7 +713,8 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
     // 288x256 tiles when they cover the problem in ONE round of one workgroup per CU (layer3 at B = 192: 235 tiles
     // instead of 1056 128x128 tiles = 2.06 rounds of 512; 92 vs 110-118 us)
     const long tiles288 = (long)cdiv(g.M, 288) * cdiv(g.N, 256);
-    if (wide_k && g.N % 256 == 0 && tiles128 > 512 && tiles288 > 192 && tiles288 <= igemm_sk_blocks() / 2) cfg = 12;
+    if (wide_k && g.N % 256 == 0 && tiles128 > 512 && tiles288 > 192 && tiles288 <= igemm_sk_blocks() / 2 && g.R * g.S <= 10)
+      cfg = 12;
   }
   if (g.N <= 64) {
     // (measured and removed for the 64-channel layers: 3-deep ring, 64-byte steps with a 4-deep ring, 256x64 tiles of
@@ -714,7 +731,7 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);  // 256x128, 8 waves
   // 288x256, 12 waves of 96x64, 128-byte K-steps, 2 buffers, one workgroup per CU: M = B*P*Q of the 256x341 input at
   // B = 192 is 132 * 2^k, and 288-row tiles put layer3 (67584 rows, N = 256) on 235 of the 256 CUs in ONE round
-  if (cfg == 12 && wide_k && g.N % 256 == 0) {
+  if (cfg == 12 && wide_k && g.N % 256 == 0 && g.R * g.S <= 10) {  // (packed tap masks: 10 bits per A pass)
 #ifdef MN_ABLATION_BUILD
     static const int abl = getenv("MN_ABLATE") ? atoi(getenv("MN_ABLATE")) : 0;
     if (abl == 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 1>(g, A, Bw, ep, stream, zero_page);

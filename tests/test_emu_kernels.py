@@ -155,3 +155,14 @@ def test_conv_data_gradient_parity_random_geometry(lib, case):
     H, W = max(H, 4), max(W, 4)
     checks.check_conv_dgrad_op(lib, DEV, 1, B, H, W, 64, 128, 3, 2, 1, parity=1, mode="out_gate", seed=H * 100 + W)
     checks.check_conv_dgrad_op(lib, DEV, 0, B, H, W, 64, 128, 1, 2, 0, parity=1, mode="inplace", seed=H * 100 + W + 1)
+
+
+def test_forced_288x256_configuration():
+    """the 12-wave 288x256 tile (packed tap masks, joint A/B DMA passes, odd wave-row count) on small ragged problems,
+    in a process of its own because the configuration knob is read once"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MN_IGEMM_CONFIG="12")
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)

@@ -276,6 +276,16 @@ def test_pose_graph_properties_at_eval_set_scale(lib, fc):
     checks.check_pgo_properties(lib, DEV, W=4096, N=7, fc=fc)
 
 
+def test_forced_288x256_configuration():
+    """the 12-wave 288x256 tile on small ragged problems against torch fp64 (tests/forced_config_cases.py), in a
+    process of its own because the configuration knob is read once"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MN_IGEMM_CONFIG="12")
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "hip"], check=True, env=env, timeout=600)
+
+
 def test_train_and_eval_command_lines(tmp_path):
     """scripts/train.py -> checkpoint -> scripts/eval.py (plain and --pose_graph) on the product library: the reference's
     command lines and Trainer loop, synthetic frames.  Kept last in this file."""

@@ -196,6 +196,50 @@ __device__ __forceinline__ int wg_swz(int row) {
   return (row & 3) << (PIECES_PER_ROW == 16 ? 2 : 1);
 }
 
+// ASMRD (wgrad_dma_kernel): the transpose reads are issued from inline assembly.  hipcc treats the builtin
+// ds_read_tr16_b64 as a read that may alias an LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` in front of it -- in this
+// loop that is a wait for the NEXT tile's DMA, issued a few instructions earlier, before the current tile is read: the
+// double buffer degenerates into load-wait-compute (plain ds_read_b128 loads, as in igemm.h, are not treated this way).
+// Assembly reads are invisible to the compiler's wait insertion, so the kernel places its own counted
+// `s_waitcnt lgkmcnt` between the reads and the MFMAs that consume them; the waits take the fragments as in/out
+// operands, which keeps the MFMAs behind them.
+// (`addr` = byte address inside the workgroup's LDS allocation; the emulator build evaluates the same address
+// arithmetic through the builtin, relative to `lds_base`.)
+#ifdef __HIP_DEVICE_COMPILE__
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(las_ptr_t) const_cast<void*>(p); }
+template <int OFF>
+__device__ __forceinline__ v4s16 ds_read_tr16_at(const void*, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  v4s16 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt_for(TrFrag& a) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.h[0]), "+v"(a.h[1]) : "n"(N));
+}
+#else  // emulator build, and hipcc's host pass over the kernel bodies
+__device__ __forceinline__ unsigned lds_addr_of(const void*) { return 0u; }
+template <int OFF>
+__device__ __forceinline__ v4s16 ds_read_tr16_at(const void* lds_base, unsigned addr) {
+  return ds_read_tr16(reinterpret_cast<const char*>(lds_base) + addr + OFF);
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt_for(TrFrag&) {}
+#endif
+template <int I>
+struct StaticIndex {
+  static constexpr int value = I;
+};
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(StaticIndex<I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
 //
 // FAST (stride-1 "same" convolutions, the bulk of the network): the source address of tap (dh, dw) of pixel
 // m is linear in m, so a lane's byte offset is a constant plus a per-step scalar; only the validity of the
@@ -203,7 +247,7 @@ __device__ __forceinline__ int wg_swz(int row) {
 // built once) instead of being recomputed for every 16-byte piece.  Loads go through buffer resources: an
 // invalid tap / column / row past M is an all-ones offset and the bounds check returns zero.
 constexpr int WG_TBL = 6144;  // pixels of one image the validity table can hold
-template <int BMO, int BNO, int BKM, int MINW, bool FAST>
+template <int BMO, int BNO, int BKM, int MINW, bool FAST, bool ASMRD = false>
 static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a, const half* __restrict__ zero_page) {
   constexpr int VEC = 8;  // BKM = m rows per step (32 or 64)
   constexpr int YCP = BMO / VEC, XCP = BNO / VEC;
@@ -358,6 +402,60 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
     if (mt + BKM < m_end) issue_tile(mt + BKM, cur ^ 1);
     const half* ty = &smem[cur * (TILE_Y + TILE_X)];
     const half* tx = ty + TILE_Y;
+    if constexpr (ASMRD) {
+      // Lane part of the addresses: row (kgrp + src_row) and the swizzled piece -- the swizzle only sees row & 3 =
+      // src_row, so (ks, hlf) are immediate offsets.  K sub-steps go in pairs: all reads of the pair are issued, the
+      // first sub-step's MFMAs start once ITS reads have returned (the second's stay in flight under them).
+      static_assert((BKM / 16) % 2 == 0, "sub-steps are processed in pairs");
+      constexpr int RPK = (TM + TN) * 2;  // reads per sub-step
+      static_assert(RPK <= 15, "lgkmcnt field");
+      const unsigned bo = lds_addr_of(smem) + (unsigned)(cur * (TILE_Y + TILE_X) * 2);
+      unsigned aA[TM], aB[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int col = wm * (BMO / 2) + i * 32 + src_chunk;
+        aA[i] = bo + (unsigned)(((kgrp + src_row) * BMO + (((col >> 3) ^ wg_swz<YCP>(src_row)) * 8) + (col & 7)) * 2);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * (BNO / 2) + j * 32 + src_chunk;
+        aB[j] = bo + (unsigned)((TILE_Y + (kgrp + src_row) * BNO + (((col >> 3) ^ wg_swz<XCP>(src_row)) * 8) + (col & 7)) * 2);
+      }
+      static_for<BKM / 32>([&](auto KP) {
+        constexpr int kp = decltype(KP)::value;
+        TrFrag fa[2][TM], fb[2][TN];
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<2>([&](auto KS) {
+          constexpr int ks = kp * 2 + decltype(KS)::value, s = decltype(KS)::value;
+          static_for<2>([&](auto HL) {
+            constexpr int hlf = decltype(HL)::value;
+            static_for<TM>([&](auto I) {
+              fa[s][decltype(I)::value].h[hlf] = ds_read_tr16_at<(ks * 16 + hlf * 4) * BMO * 2>(smem, aA[decltype(I)::value]);
+            });
+            static_for<TN>([&](auto J) {
+              fb[s][decltype(J)::value].h[hlf] = ds_read_tr16_at<(ks * 16 + hlf * 4) * BNO * 2>(smem, aB[decltype(J)::value]);
+            });
+          });
+        });
+        static_for<2>([&](auto KS) {
+          constexpr int s = decltype(KS)::value;
+          // LDS reads return in order: at most RPK outstanding = the first sub-step's fragments are in their registers
+#pragma unroll
+          for (int i = 0; i < TM; ++i) wait_lgkmcnt_for<s == 0 ? RPK : 0>(fa[s][i]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) wait_lgkmcnt_for<s == 0 ? RPK : 0>(fb[s][j]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][i].v, fb[s][j].v, acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);  // the second sub-step's waits stay behind these MFMAs
+        });
+      });
+      cur ^= 1;
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < BKM / 16; ++ks) {
       TrFrag fa[TM], fb[TN];
@@ -414,6 +512,22 @@ struct WgradDma<half> {
     const bool fast = allow_fast && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&
                       g.R * g.S <= 16 && g.P * g.Q <= WG_TBL && g.P * g.Q >= BKM && g.C % 8 == 0 &&
                       (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l;
+    // MN_WGRAD_TR_ASM=1: transpose reads from inline assembly with hand-placed waits (ASMRD above) for the stride-1 3x3
+    // layers; off until it has been race-screened and timed on the GPU
+    static const bool tr_asm = getenv("MN_WGRAD_TR_ASM") && atoi(getenv("MN_WGRAD_TR_ASM")) != 0;
+    if constexpr (BKM == 32) {
+      if (fast && tr_asm) {
+        if (bmo == 64 && bno == 64)
+          hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
+        else if (bmo == 64)
+          hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
+        else if (bno == 64)
+          hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
+        else
+          hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
+        return;
+      }
+    }
     if (fast) {
       if (bmo == 64 && bno == 64)
         hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW, true>), grid, block, 0, stream, a, zp);

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: convolution parity cases run in a process of their own with a tile configuration forced
-through MN_IGEMM_CONFIG (the library reads the knob once).  `python forced_config_cases.py emu|hip`.
+through MN_IGEMM_CONFIG / MN_WGRAD_TR_ASM (the library reads such knobs once).  `python forced_config_cases.py emu|hip`.
 Configuration 12 = the 12-wave 288x256 tile, which the dispatcher picks by itself only for grids that fill most of
 the chip (layer3 at 192 images); here it runs on small ragged problems against torch fp64."""
 import os
@@ -17,6 +17,20 @@ def main(backend):
     else:
         from geomapnet_amd import _binding
         lib, dev = _binding.hip(), "cuda"
+    if os.environ.get("MN_WGRAD_TR_ASM") == "1":
+        # fp16 weight gradients of stride-1 "same" convolutions with the transpose reads issued from inline assembly
+        # (wgrad_dma_kernel<..., ASMRD>): all four tile shapes, several splits, ragged last split
+        for shape, blocks in (((2, 9, 11, 64, 64, 3, 1, 1), 8), ((3, 7, 9, 128, 128, 3, 1, 1), 40),
+                              ((2, 9, 11, 64, 128, 1, 1, 0), 4), ((2, 9, 11, 64, 64, 1, 1, 0), 1),
+                              ((4, 16, 22, 128, 256, 3, 1, 1), 64)):
+            checks.check_conv_wgrad(lib, dev, 1, *shape, target_blocks=blocks)
+        if backend != "emu":  # layer geometries at sizes with hundreds of concurrent workgroups, repeated (race screen)
+            for rep in range(3):
+                for shape in ((2, 64, 86, 64, 64, 3, 1, 1), (7, 16, 22, 256, 256, 3, 1, 1), (4, 8, 11, 512, 512, 3, 1, 1),
+                              (6, 32, 43, 128, 128, 3, 1, 1)):
+                    checks.check_conv_wgrad(lib, dev, 1, *shape, target_blocks=1024, seed=2 + rep)
+        print("forced-config cases ok")
+        return
     assert os.environ.get("MN_IGEMM_CONFIG") == "12"
     for dtype in (0, 1):
         # (B, H, W, Cin, Cout, k, stride, pad): 396 / 663 / 198 rows = 1.4 / 2.3 / 0.7 tiles of 288 rows

@@ -166,3 +166,14 @@ def test_forced_288x256_configuration():
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MN_IGEMM_CONFIG="12")
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
+
+
+def test_weight_gradient_with_assembly_transpose_reads():
+    """wgrad_dma_kernel<..., ASMRD> (MN_WGRAD_TR_ASM=1): same results as the builtin-read kernel; the emulator executes
+    the variant's address arithmetic (lane base + immediate offsets)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MN_WGRAD_TR_ASM="1")
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)

@@ -332,3 +332,13 @@ def test_train_and_eval_command_lines(tmp_path):
     summary, pred, targ = eval_script.run(eargs, log=lines.append)
     assert pred.shape == (16, 7) and np.isfinite(pred).all()
     np.testing.assert_allclose(np.linalg.norm(pred[:, 3:], axis=1), 1.0, atol=1e-9)
+
+
+def test_weight_gradient_with_assembly_transpose_reads():
+    """MN_WGRAD_TR_ASM=1 (off by default): the fp16 weight-gradient kernel with its transpose reads issued from inline
+    assembly and hand-placed waits, against torch fp64 at small and layer-sized shapes, repeated.  Kept last."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MN_WGRAD_TR_ASM="1")
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "hip"], check=True, env=env, timeout=600)

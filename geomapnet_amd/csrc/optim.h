@@ -132,6 +132,38 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
   const float* src = params + job.src_off;
   const int O = job.O, R = job.R, S = job.S, I = job.I;
   const long total = job.mode == 2 ? (long)O * R * 32 : (long)O * R * S * I;
+  // Transposing copies (the data-gradient layout [I][R][S][O] of a conv weight, the fc weight's [I][O]) go through a
+  // 64 x 64 LDS tile per workgroup when O and I are multiples of 64 (every ResNet-34 layer): 256-byte reads along I,
+  // 128-byte writes along O, instead of one scattered 2-byte write per element.  Same 4096 elements per workgroup, so
+  // the job table's workgroup ranges are unchanged.
+  __shared__ float tile[64][65];
+  if ((job.mode == 0 || job.mode == 3) && O % 64 == 0 && I % 64 == 0) {
+    const int RS = R * S, tiles_i = I / 64;
+    const int local = bid - job.blk0;
+    const int it = local % tiles_i, tmp = local / tiles_i;
+    const int rs = tmp % RS, ot = tmp / RS;
+    const int col = threadIdx.x & 63, row0 = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int row = k * 4 + row0;
+      const long idx = ((long)(ot * 64 + row) * RS + rs) * I + it * 64 + col;
+      const float v = src[idx];
+      if (job.mode == 0 && job.dst_a) reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
+      tile[row][col] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int irow = k * 4 + row0;
+      const float v = tile[col][irow];
+      const long didx = ((long)(it * 64 + irow) * RS + rs) * O + ot * 64 + col;
+      if (job.mode == 0)
+        reinterpret_cast<T*>(job.dst_b)[didx] = (T)v;
+      else
+        reinterpret_cast<float*>(job.dst_a)[didx] = v;
+    }
+    return;
+  }
   const long base = (long)(bid - job.blk0) * 4096;
   for (int k = 0; k < 16; ++k) {
     const long idx = base + k * 256 + threadIdx.x;

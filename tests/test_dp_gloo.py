@@ -69,3 +69,47 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     want = g0 + g1
     assert (r0["grads"] - want).abs().max().item() <= 1e-5 * want.abs().max().item()
     assert abs(r0["loss"] - 0.5 * (l0 + l1)) <= 1e-5 * abs(l0)
+
+
+def _train_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    os.environ["MAPNET_EMU_THREADS"] = "4"
+    import configparser
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    import emu_lib
+    import train as train_script
+    s = configparser.ConfigParser()
+    s.read(os.path.join(ROOT, "scripts", "configs", "mapnet.ini"))
+    s["training"].update(n_epochs="1", batch_size="1", snapshot="1", do_val="no", num_workers="0")
+    s["hyperparameters"]["skip"] = "1"
+    cfg = os.path.join(out_dir, "mapnet_rank%d.ini" % rank)
+    with open(cfg, "w") as f:
+        s.write(f)
+    args = train_script.build_parser().parse_args(
+        ["--model", "mapnet", "--config_file", cfg, "--learn_beta", "--learn_gamma", "--dtype", "fp32", "--synthetic_length", "2",
+         "--height", "32", "--width", "40", "--logdir", os.path.join(out_dir, "logs")])
+    lines = []
+    tr = train_script.run(args, _binding=emu_lib.load(), log=lines.append)
+    eng = tr.model.mapnet._engine
+    torch.save({"params": eng.params.clone(), "lines": lines, "indices": list(iter(tr.train_sampler)),
+                "batches": len(tr.train_loader)}, os.path.join(out_dir, "train_rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_trainer_shards_windows_and_keeps_replicas_in_sync(tmp_path):
+    """scripts/train.py under a 2-rank process group: DistributedSampler shards the windows, every step all-reduces
+    the gradient buckets (replicas end identical), rank 0 alone prints and writes the checkpoints"""
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "train_rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "train_rank1.pt"))
+    assert torch.equal(r0["params"], r1["params"])
+    assert r0["batches"] == 1 and r1["batches"] == 1
+    assert sorted(r0["indices"] + r1["indices"]) == [0, 1]
+    assert any(l.startswith("Train ") for l in r0["lines"]) and not r1["lines"]
+    ck = torch.load(os.path.join(tmp_path, "logs", "epoch_001.pth.tar"), weights_only=False)
+    assert ck["epoch"] == 1 and ck["optim_state_dict"]["state"][0]["step"] == 1

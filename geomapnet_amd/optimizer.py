@@ -26,6 +26,7 @@ class FusedAdam:
             raise NotImplementedError("the fused step applies one (lr, wd, betas, eps) to all groups, as the "
                                       "reference's scripts do (scripts/train.py:104-112)")
         self._engine = None
+        self._pending = None
 
     def hyper(self):
         g = self.param_groups[0]
@@ -53,10 +54,18 @@ class FusedAdam:
         state, groups, idx = {}, [], 0
         eng = self._engine
         have = eng is not None and eng.opt_state is not None and eng.step_count > 0
+        # a state that was loaded but has not reached the device yet (the optimiser meets its engine in the first
+        # step_feedfwd) is returned as loaded: save -> load -> save without a step in between keeps the moments
+        pend = getattr(self, "_pending", None)
         for g in self.param_groups:
             ids = []
             for p in g["params"]:
-                if have:
+                if pend:
+                    st = pend.get(idx, pend.get(str(idx)))
+                    if st is not None:
+                        state[idx] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].detach().clone().cpu(),
+                                      "exp_avg_sq": st["exp_avg_sq"].detach().clone().cpu()}
+                elif have:
                     m, v = self._moment_views(p)
                     state[idx] = {"step": int(eng.step_count), "exp_avg": m.clone().contiguous(),
                                   "exp_avg_sq": v.clone().contiguous()}

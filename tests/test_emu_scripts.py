@@ -69,14 +69,18 @@ def test_train_eval_resume_mapnet(lib, tmp_path):
     z = np.load(str(tmp_path / "out" / "Synthetic_synthetic_mapnet.npz"))
     np.testing.assert_array_equal(z["pred_poses"], pred)
 
-    # resume: start epoch and optimiser state come from the checkpoint
-    cfg3 = _config(tmp_path, "mapnet.ini", n_epochs=2, batch_size=2, snapshot=1, val_freq=5, skip=1, do_val="no")
+    # resume: start epoch and optimiser state come from the checkpoint (n_epochs = the checkpoint's epoch: no further
+    # step is run here -- the step after a resume is checked in test_emu_network.py's checkpoint test)
+    cfg3 = _config(tmp_path, "mapnet.ini", n_epochs=1, batch_size=2, snapshot=1, val_freq=5, skip=1, do_val="no")
     _, rargs = _train_args(tmp_path, "mapnet", cfg3, ["--learn_beta", "--learn_gamma", "--checkpoint", tr.final_checkpoint,
                                                       "--resume_optim", "--suffix", "_r"])
     tr2 = train_script.run(rargs, _binding=lib, log=lines.append)
     assert tr2.start_epoch == 1
     ck2 = torch.load(tr2.final_checkpoint, weights_only=False)
-    assert ck2["epoch"] == 2 and ck2["optim_state_dict"]["state"][0]["step"] == 2
+    assert ck2["epoch"] == 1 and ck2["optim_state_dict"]["state"][0]["step"] == 1
+    for k, v in ck["model_state_dict"].items():
+        assert torch.equal(v, ck2["model_state_dict"][k]), k
+    assert torch.equal(ck["optim_state_dict"]["state"][0]["exp_avg"], ck2["optim_state_dict"]["state"][0]["exp_avg"])
 
 
 def test_eval_pose_graph_and_posenet_weights_into_mapnet(lib, tmp_path):

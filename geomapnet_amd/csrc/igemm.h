@@ -505,16 +505,19 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   float* stage = reinterpret_cast<float*>(&smem[0]);  // [64][SC] fp32 sub-block
   constexpr int SC = BN < 128 ? BN : 128;             // columns staged per round
   constexpr int CPR = SC / VEC;                       // output pieces per staged row
-  constexpr int PASSES = (64 * CPR + NT - 1) / NT;
+  // wave rows staged per round: two (64 rows, fits every ring), or all three of the 12-wave configuration (96 rows =
+  // 48 KB of its 150 KB ring: 6 rounds of two full store passes instead of 12 rounds of 1.33)
+  constexpr int WR = (WM == 3 && NBUF * TILE_PIECES * 16 >= 96 * SC * 4) ? 3 : 2;
+  constexpr int PASSES = (WR * 32 * CPR + NT - 1) / NT;
   float s1[TN], s2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
-  // rounds: (tile row i of each wave) x (pairs of wave rows) x (128-column blocks)
+  // rounds: (tile row i of each wave) x (groups of WR wave rows) x (128-column blocks)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
-    for (int mh = 0; mh < (WM + 1) / 2; ++mh)
+    for (int mh = 0; mh < (WM + WR - 1) / WR; ++mh)
       for (int nh = 0; nh < BN / SC; ++nh) {
-        if ((wm >> 1) == mh) {
+        if (wm / WR == mh) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int lc = wn * WTN + j * 32 + (lane & 31);  // column inside the block tile
@@ -526,7 +529,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
                 if (ep.relu & 1) v = fmaxf(v, 0.f);
                 s1[j] += v;
                 s2[j] += v * v;
-                const int lr = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int lr = (wm % WR) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 stage[lr * SC + (lc - nh * SC)] = v;
               }
             }
@@ -537,9 +540,9 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
         for (int ps = 0; ps < PASSES; ++ps) {
           const int id = t + ps * NT;
           const int lr = id / CPR, cpc = id % CPR;
-          const int row = m0 + (2 * mh + (lr >> 5)) * WTM + i * 32 + (lr & 31);
+          const int row = m0 + (WR * mh + (lr >> 5)) * WTM + i * 32 + (lr & 31);
           const int col = n0 + nh * SC + cpc * VEC;
-          if (lr < 64 && 2 * mh + (lr >> 5) < WM && row < g.M && col < g.N) {
+          if (lr < WR * 32 && WR * mh + (lr >> 5) < WM && row < g.M && col < g.N) {
             float v[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; e += 4) {

@@ -241,7 +241,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   // at 168 and the two registers decide whether the allocator keeps a row offset in scratch -- whose reload, inside the
   // K loop, waits on vmcnt(0) behind the LDS-DMA queue.
   constexpr int IPT_A = (BM + RPP - 1) / RPP;  // passes that hold A rows
-  constexpr bool PACK = UNI && IPT_A <= 3;
+  constexpr bool PACK = UNI && WM == 3 && IPT_A <= 3;  // only the configuration whose launch condition bounds R*S
   constexpr int PACK_BITS = 10;
   unsigned d_off[IPT], a_inv[PACK ? 1 : IPT];  // byte offset of the row (A: image pixel, B: weight row) and the A tap mask
   if constexpr (PACK) a_inv[0] = ~0u;

@@ -153,3 +153,32 @@ def test_mf_and_mfonline_batches_feed_the_criteria_shapes():
                           align_t=np.zeros(3), align_s=1.0)
     np.testing.assert_allclose(out[0, :3], [0.25, 0.75, 1.25])
     np.testing.assert_allclose(out[0, 3:], D.qlog(q), atol=1e-12)
+
+
+def test_shipped_k_loops_have_no_scratch_access_and_asm_reads_skip_the_dma_wait():
+    """static check of the built gfx950 code objects (tools/isa_audit.py): no scratch access around the K loops of the
+    fp16 conv kernels the training step launches (a spill reload there waits on vmcnt(0) behind the LDS-DMA queue), and
+    the assembly-read weight-gradient variants go from their LDS-DMA issue to the transpose reads without the
+    compiler's vmcnt(0)"""
+    import importlib.util
+    import shutil
+    lib = os.path.join(ROOT, "geomapnet_amd", "libmapnet_hip.so")
+    if not os.path.isfile(lib) or not os.path.isfile("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the built library and llvm-objdump")
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    audit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit)
+    hot = audit.signatures(r"igemm_kernelIDF16_Li3ELi4ELi3ELi2ELi8ELi2ELi3ELb1ELb0ELb1ELi0E|"
+                           r"igemm_kernelIDF16_Li2ELi2ELi2ELi2ELi8ELi2ELi2ELb1ELb0ELb0ELi0E|"
+                           r"igemm_kernelIDF16_Li2ELi2ELi4ELi2ELi4ELi3ELi2ELb1ELb0ELb0ELi0E|conv_halo_kernel|"
+                           r"wgrad_dma_kernelILi\d+ELi\d+ELi32ELi4ELb1ELb[01]E")
+    assert len(hot) >= 12
+    for name, (_, _, sig) in hot.items():
+        assert "S!" not in sig, (name, sig)
+    asm = {n: s for n, (_, _, s) in hot.items() if "wgrad_dma" in n and n.split("ELb1ELb")[1].startswith("1")}
+    assert len(asm) == 4
+    for name, sig in asm.items():
+        toks = sig.split()
+        k = next(i for i, t in enumerate(toks) if re.fullmatch(r"Rx\d+", t) and toks[i + 1].startswith("M"))
+        d = max(i for i in range(k) if toks[i].startswith("D"))  # the last LDS-DMA issue before the transpose reads
+        assert not any(t.startswith("V") for t in toks[d:k]), (name, sig)

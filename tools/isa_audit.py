@@ -29,10 +29,12 @@ def code_objects(path):
                 yield data[b + o:b + o + sz]
 
 
-def main():
-    pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else "igemm_kernelIDF16|wgrad_dma_kernel|conv_halo")
+def signatures(pattern, out=None):
+    """{kernel name: (instructions, MFMAs, event string)} for the kernels whose mangled name matches `pattern`"""
+    pat = re.compile(pattern)
     lib = os.path.join(ROOT, "geomapnet_amd", "libmapnet_hip.so")
     seen = set()
+    result = {}
     for k, co in enumerate(code_objects(lib)):
         with tempfile.NamedTemporaryFile(suffix=".elf") as f:
             f.write(co)
@@ -77,7 +79,13 @@ def main():
                 else:
                     ev.append([e, 1])
             sig = " ".join(e if n == 1 else "%s%s%d" % (e, "x", n) for e, n in ev)
-            print("%s\n    %d instructions, %d MFMAs\n    %s" % (name[:110], len(body), len(mf), sig))
+            result[name] = (len(body), len(mf), sig)
+    return result
+
+
+def main():
+    for name, (n, m, sig) in signatures(sys.argv[1] if len(sys.argv) > 1 else "igemm_kernelIDF16|wgrad_dma_kernel|conv_halo").items():
+        print("%s\n    %d instructions, %d MFMAs\n    %s" % (name[:110], n, m, sig))
 
 if __name__ == "__main__":
     main()

@@ -35,8 +35,7 @@ def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, tra
     dev = engine.device
     data = data.to(dev, non_blocking=True) if data.device != dev else data
     if not train or criterion is None:
-        was = model.training
-        output = model(data)
+        output = model(data)  # in the model's current mode, as the reference (its caller sets model.eval())
         if criterion is None:
             return 0, output
         loss = criterion(output, target.to(dev, non_blocking=True))

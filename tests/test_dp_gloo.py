@@ -82,7 +82,7 @@ def _train_worker(rank, world, port, out_dir):
     import emu_lib
     import train as train_script
     s = configparser.ConfigParser()
-    s.read(os.path.join(ROOT, "scripts", "configs", "mapnet.ini"))
+    s.read(os.path.join(ROOT, "scripts", "configs", "synthetic_mapnet.ini"))
     s["training"].update(n_epochs="1", batch_size="1", snapshot="1", do_val="no", num_workers="0")
     s["hyperparameters"]["skip"] = "1"
     cfg = os.path.join(out_dir, "mapnet_rank%d.ini" % rank)

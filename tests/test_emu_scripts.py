@@ -44,11 +44,11 @@ def _train_args(tmp_path, model, cfg, extra=(), length=2, val_length=1):
 
 
 def test_train_eval_resume_mapnet(lib, tmp_path):
-    cfg = _config(tmp_path, "mapnet.ini", n_epochs=1, batch_size=2, snapshot=1, val_freq=1, skip=1, do_val="no")
+    cfg = _config(tmp_path, "synthetic_mapnet.ini", n_epochs=1, batch_size=2, snapshot=1, val_freq=1, skip=1, do_val="no")
     train_script, args = _train_args(tmp_path, "mapnet", cfg, ["--learn_beta", "--learn_gamma"])
     lines = []
     tr = train_script.run(args, _binding=lib, log=lines.append)
-    assert tr.experiment == "Synthetic_synthetic_mapnet_mapnet_learn_beta_learn_gamma"
+    assert tr.experiment == "Synthetic_synthetic_mapnet_synthetic_mapnet_learn_beta_learn_gamma"
     assert sum(l.startswith("Train ") for l in lines) == 1  # one batch of two windows
     for e in (0, 1):
         assert os.path.isfile(os.path.join(tr.logdir, "epoch_%03d.pth.tar" % e))
@@ -60,7 +60,7 @@ def test_train_eval_resume_mapnet(lib, tmp_path):
 
     # eval.py flow on the checkpoint
     import eval as eval_script
-    ecfg = _config(tmp_path, "mapnet.ini", skip=1)
+    ecfg = _config(tmp_path, "synthetic_mapnet.ini", skip=1)
     eargs = eval_script.build_parser().parse_args(
         ["--model", "mapnet", "--config_file", ecfg, "--weights", tr.final_checkpoint, "--dtype", "fp32", "--synthetic_length",
          "1", "--height", str(H), "--width", str(W), "--val", "--output_dir", str(tmp_path / "out")])
@@ -71,7 +71,7 @@ def test_train_eval_resume_mapnet(lib, tmp_path):
 
     # resume: start epoch and optimiser state come from the checkpoint (n_epochs = the checkpoint's epoch: no further
     # step is run here -- the step after a resume is checked in test_emu_network.py's checkpoint test)
-    cfg3 = _config(tmp_path, "mapnet.ini", n_epochs=1, batch_size=2, snapshot=1, val_freq=5, skip=1, do_val="no")
+    cfg3 = _config(tmp_path, "synthetic_mapnet.ini", n_epochs=1, batch_size=2, snapshot=1, val_freq=5, skip=1, do_val="no")
     _, rargs = _train_args(tmp_path, "mapnet", cfg3, ["--learn_beta", "--learn_gamma", "--checkpoint", tr.final_checkpoint,
                                                       "--resume_optim", "--suffix", "_r"])
     tr2 = train_script.run(rargs, _binding=lib, log=lines.append)
@@ -90,7 +90,7 @@ def test_eval_pose_graph_and_posenet_weights_into_mapnet(lib, tmp_path):
     net = G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, _binding=lib)
     wfn = str(tmp_path / "w.pth.tar")
     torch.save({"model_state_dict": net.state_dict()}, wfn)  # PoseNet keys: MapNet adds its prefix (common/train.py:22-53)
-    cfg = _config(tmp_path, "pgo_inference.ini", skip=1, steps=3)
+    cfg = _config(tmp_path, "synthetic_pose_graph.ini", skip=1, steps=3)
     eargs = eval_script.build_parser().parse_args(
         ["--model", "mapnet", "--config_file", cfg, "--weights", wfn, "--dtype", "fp32", "--synthetic_length", "2",
          "--height", str(H), "--width", str(W), "--pose_graph"])
@@ -100,14 +100,14 @@ def test_eval_pose_graph_and_posenet_weights_into_mapnet(lib, tmp_path):
 
 
 def test_train_posenet_with_validation_and_mapnet_online_wiring(lib, tmp_path):
-    cfg = _config(tmp_path, "posenet.ini", n_epochs=1, batch_size=2, snapshot=1, val_freq=1)
+    cfg = _config(tmp_path, "synthetic_posenet.ini", n_epochs=1, batch_size=2, snapshot=1, val_freq=1)
     train_script, args = _train_args(tmp_path, "posenet", cfg, ["--learn_beta"])
     lines = []
     tr = train_script.run(args, _binding=lib, log=lines.append)
     assert any(l.startswith("Val ") and "val_loss" in l for l in lines) and np.isfinite(tr.last_val_loss)
     # MapNet++: construction only (n_epochs = 0; the step itself is covered by test_emu_network.py) -- model with the
     # NaN filter, online criterion, MFOnline batches of 2T frames with T + (T-1) target rows
-    cfg = _config(tmp_path, "mapnet++.ini", n_epochs=0, batch_size=1, snapshot=1, skip=1)
+    cfg = _config(tmp_path, "synthetic_mapnet_online.ini", n_epochs=0, batch_size=1, snapshot=1, skip=1)
     _, args = _train_args(tmp_path, "mapnet++", cfg, ["--learn_beta", "--learn_gamma"], length=3, val_length=3)
     tr = train_script.run(args, _binding=lib, log=lambda *a: None)
     data, target = next(iter(tr.train_loader))
@@ -118,7 +118,7 @@ def test_train_posenet_with_validation_and_mapnet_online_wiring(lib, tmp_path):
 
 
 def test_real_datasets_are_refused(lib, tmp_path):
-    cfg = _config(tmp_path, "mapnet.ini", n_epochs=1)
+    cfg = _config(tmp_path, "synthetic_mapnet.ini", n_epochs=1)
     train_script, args = _train_args(tmp_path, "mapnet", cfg, ["--dataset", "7Scenes", "--scene", "chess"])
     with pytest.raises(NotImplementedError):
         train_script.run(args, _binding=lib, log=lambda *a: None)

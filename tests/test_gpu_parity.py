@@ -306,7 +306,7 @@ def test_train_and_eval_command_lines(tmp_path):
             s.write(f)
         return fn
 
-    cfg = config("mapnet.ini", n_epochs=2, batch_size=8, snapshot=1, val_freq=1, skip=2)
+    cfg = config("synthetic_mapnet.ini", n_epochs=2, batch_size=8, snapshot=1, val_freq=1, skip=2)
     args = train_script.build_parser().parse_args(
         ["--model", "mapnet", "--config_file", cfg, "--learn_beta", "--learn_gamma", "--dtype", "fp16", "--synthetic_length",
          "32", "--synthetic_val_length", "8", "--height", "64", "--width", "85", "--num_workers", "0", "--logdir",
@@ -325,7 +325,7 @@ def test_train_and_eval_command_lines(tmp_path):
          "16", "--height", "64", "--width", "85", "--val"])
     summary, pred, targ = eval_script.run(eargs, log=lines.append)
     assert pred.shape == (16, 7) and np.isfinite(pred).all() and np.isfinite(summary["median_t"])
-    pcfg = config("pgo_inference.ini", skip=1, steps=5)
+    pcfg = config("synthetic_pose_graph.ini", skip=1, steps=5)
     eargs = eval_script.build_parser().parse_args(
         ["--model", "mapnet", "--config_file", pcfg, "--weights", tr.final_checkpoint, "--dtype", "fp32", "--synthetic_length",
          "16", "--height", "64", "--width", "85", "--pose_graph"])

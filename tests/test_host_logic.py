@@ -40,9 +40,11 @@ def test_product_fails_loudly_without_gpu():
 
 def test_product_never_imports_the_oracle_or_the_emulator():
     bad = []
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "geomapnet_amd")):
-        for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cpp")):
+    for top in ("geomapnet_amd", "scripts"):  # the package and the command lines on top of it
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if not f.endswith((".py", ".h", ".hip", ".cpp")):
+                    continue
                 src = open(os.path.join(dirpath, f)).read()
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "libmapnet_emu" in src or "emu_lib" in src:
                     bad.append(f)

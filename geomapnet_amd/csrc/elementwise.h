@@ -476,9 +476,13 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   constexpr int VEC = ElemTraits<T>::VEC;
   const float* sg_gamma = self_gate_beta ? gamma : nullptr;
   if (self_gate_beta) gate = nullptr;
-  // ~4096 workgroups in flight: the reduction is HBM-bound and needs the whole chip
+  // ~4096 workgroups: the reduction is HBM-bound and needs the whole chip.  (At B = 192 that is ONE loop iteration per
+  // workgroup for layers 3-4 -- 16-32 rows -- so the parameter loads, the LDS reduction and the 2 x C atomics of every
+  // workgroup weigh as much as its loads; MN_BN_REDUCE_BLOCKS is the knob to time fatter workgroups with.)
+  static const long target = getenv("MN_BN_REDUCE_BLOCKS") && atol(getenv("MN_BN_REDUCE_BLOCKS")) > 0
+                                 ? atol(getenv("MN_BN_REDUCE_BLOCKS")) : 4096;
   const int rlanes = 256 / (C / VEC);
-  long rows = (M + 4095) / 4096;
+  long rows = (M + target - 1) / target;
   rows = ((rows + rlanes - 1) / rlanes) * rlanes;
   if (rows < 4L * rlanes) rows = 4L * rlanes;
   int rows_per_block = (int)rows;

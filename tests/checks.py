@@ -431,6 +431,39 @@ def check_criterion_golden(lib, dev, golden_dir):
                 assert abs(ds[i].item() - float(d["d_" + n])) <= 1e-4 * max(1.0, abs(float(d["d_" + n]))), (name, n)
 
 
+def check_criterion_vs_oracle(lib, dev, mode_name, N, T, seed=0):
+    """fused criterion kernel (loss, d pred, d s) vs the oracle criterion under fp64 autograd on seeded poses, for
+    window lengths and batch sizes the golden vectors (all T = 3) do not hold"""
+    _fresh()
+    from oracle import criterion as OC
+    gps = mode_name == "gps"
+    om = {"posenet": "posenet", "mapnet": "mapnet", "online": "mapnet++", "gps": "mapnet++"}[mode_name]
+    _, targ = oracle.make_batch(om, N, 1, 1, t=T, seed=100 + seed, gps_mode=gps)
+    gen = torch.Generator().manual_seed(seed)
+    shape = (N, 6) if mode_name == "posenet" else (N, T, 6) if mode_name == "mapnet" else (N, 2 * T, 6)
+    lead = targ if mode_name in ("posenet", "mapnet") else torch.cat((targ[:, :T], oracle.make_batch("mapnet", N, 1, 1, t=T, seed=7 + seed)[1]), 1)
+    pred = (lead + 0.3 * torch.randn(*shape, generator=gen)).contiguous()
+    s4 = [0.3, -2.5, 0.7, -3.5]
+    kw = dict(sax=s4[0], saq=s4[1], learn_beta=True)
+    if mode_name == "posenet":
+        crit, mode = OC.PoseNetCriterion(**kw), 0
+    elif mode_name == "mapnet":
+        crit, mode = OC.MapNetCriterion(srx=s4[2], srq=s4[3], learn_gamma=True, **kw), 1
+    else:
+        crit, mode = OC.MapNetOnlineCriterion(srx=s4[2], srq=s4[3], learn_gamma=True, gps_mode=gps, **kw), (3 if gps else 2)
+    crit = crit.double()
+    p64 = pred.double().requires_grad_(True)
+    want = crit(p64, targ.double())
+    want.backward()
+    loss, dp, ds, _ = run_criterion(lib, dev, mode, pred, targ, s4)
+    assert abs(loss - want.item()) <= 2e-5 * max(1.0, abs(want.item())), (mode_name, N, T)
+    np.testing.assert_allclose(dp.numpy(), p64.grad.float().numpy(), rtol=3e-4, atol=3e-6, err_msg=str((mode_name, N, T)))
+    names = ("sax", "saq") if mode_name == "posenet" else ("sax", "saq", "srx") if gps else ("sax", "saq", "srx", "srq")
+    for i, n in enumerate(names):
+        w = getattr(crit, n).grad.item()
+        assert abs(ds[i].item() - w) <= 2e-4 * max(1.0, abs(w)), (mode_name, N, T, n)
+
+
 def check_calc_vos_golden(lib, dev, golden_dir):
     _fresh()
     z = np.load(os.path.join(golden_dir, "pose_algebra.npz"))

@@ -177,3 +177,9 @@ def test_weight_gradient_with_assembly_transpose_reads():
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MN_WGRAD_TR_ASM="1")
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
+
+
+@pytest.mark.parametrize("mode,N,T", [("mapnet", 1, 2), ("mapnet", 3, 5), ("mapnet", 2, 7), ("online", 1, 2), ("online", 3, 4),
+                                      ("gps", 2, 5), ("posenet", 1, 1), ("mapnet", 70, 4), ("online", 33, 3)])
+def test_criteria_vs_oracle_other_window_lengths(lib, mode, N, T):
+    checks.check_criterion_vs_oracle(lib, DEV, mode, N, T)

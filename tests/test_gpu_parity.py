@@ -261,6 +261,12 @@ def test_full_size_training_is_finite_and_learns(lib):
     assert int(sd["mapnet.feature_extractor.bn1.num_batches_tracked"]) == 6
 
 
+@pytest.mark.parametrize("mode,N,T", [("mapnet", 1, 2), ("mapnet", 3, 5), ("mapnet", 2, 7), ("online", 1, 2), ("online", 3, 4),
+                                      ("gps", 2, 5), ("posenet", 1, 1), ("mapnet", 70, 4), ("online", 33, 3), ("mapnet", 512, 3)])
+def test_criteria_vs_oracle_other_window_lengths(lib, mode, N, T):
+    checks.check_criterion_vs_oracle(lib, DEV, mode, N, T)
+
+
 def test_pose_graph_golden(lib, golden_dir):
     checks.check_pgo_golden(lib, DEV, golden_dir)
 

@@ -515,7 +515,7 @@ struct WgradDma<half> {
     // MN_WGRAD_TR_ASM=1: transpose reads from inline assembly with hand-placed waits (ASMRD above) for the stride-1 3x3
     // layers; off until it has been race-screened and timed on the GPU
     static const bool tr_asm = getenv("MN_WGRAD_TR_ASM") && atoi(getenv("MN_WGRAD_TR_ASM")) != 0;
-    if constexpr (BKM == 32) {
+    {
       if (fast && tr_asm) {
         if (bmo == 64 && bno == 64)
           hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);

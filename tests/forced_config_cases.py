@@ -17,7 +17,7 @@ def main(backend):
     else:
         from geomapnet_amd import _binding
         lib, dev = _binding.hip(), "cuda"
-    if os.environ.get("MN_WGRAD_TR_ASM") == "1":
+    if os.environ.get("MN_WGRAD_TR_ASM") == "1":  # (with MN_WGRAD_VARIANT=0: the 64-row-step kernels)
         # fp16 weight gradients of stride-1 "same" convolutions with the transpose reads issued from inline assembly
         # (wgrad_dma_kernel<..., ASMRD>): all four tile shapes, several splits, ragged last split
         for shape, blocks in (((2, 9, 11, 64, 64, 3, 1, 1), 8), ((3, 7, 9, 128, 128, 3, 1, 1), 40),

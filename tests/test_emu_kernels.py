@@ -175,8 +175,9 @@ def test_weight_gradient_with_assembly_transpose_reads():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MN_WGRAD_TR_ASM="1")
-    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
+    for variant in ("1", "0"):  # 32-row steps (default) and 64-row steps
+        env = dict(os.environ, MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT=variant)
+        subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
 
 
 @pytest.mark.parametrize("mode,N,T", [("mapnet", 1, 2), ("mapnet", 3, 5), ("mapnet", 2, 7), ("online", 1, 2), ("online", 3, 4),

@@ -12,7 +12,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; tail -3
 timeout 300 python tools/conv_bench.py fp16 192 > $O/conv_bench_default.txt 2>&1
 MN_WGRAD_TR_ASM=1 timeout 300 python tools/conv_bench.py fp16 192 > $O/conv_bench_tr_asm.txt 2>&1
 echo "--- default"; cat $O/conv_bench_default.txt; echo "--- MN_WGRAD_TR_ASM=1"; grep wgrad $O/conv_bench_tr_asm.txt
-timeout 600 bash tools/ab.sh "MN_WGRAD_TR_ASM=0" "MN_WGRAD_TR_ASM=1" > $O/ab_tr_asm.txt 2>&1; cat $O/ab_tr_asm.txt
+timeout 900 bash tools/ab.sh "MN_WGRAD_TR_ASM=0" "MN_WGRAD_TR_ASM=1" "MN_WGRAD_TR_ASM=1 MN_WGRAD_VARIANT=0" > $O/ab_tr_asm.txt 2>&1; cat $O/ab_tr_asm.txt
 timeout 900 bash tools/ab.sh "MN_BN_REDUCE_BLOCKS=4096" "MN_BN_REDUCE_BLOCKS=1024" "MN_BN_REDUCE_BLOCKS=512" > $O/ab_bn_blocks.txt 2>&1; cat $O/ab_bn_blocks.txt
 TAG=r2_open timeout 1200 bash tools/gpu_prof.sh
 timeout 120 tools/probes/dma_probe > $O/dma_probe.txt 2>&1; cat $O/dma_probe.txt

@@ -177,9 +177,15 @@ class SyntheticFrames(torch.utils.data.Dataset):
     random trajectory, poses as (translation, log-quaternion); `gt_idx` = identity, as a dataset whose `real`
     poses index the ground truth one-to-one"""
 
-    def __init__(self, length, H=256, W=341, seed=7):
+    # the statistics a `uint8=True` dataset is meant to be normalised with (model.set_input_u8(MEAN, STD))
+    MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+    def __init__(self, length, H=256, W=341, seed=7, uint8=False):
+        """`uint8=True`: frames as decoded images, uint8 [H,W,3] (what `model.set_input_u8` consumes: ToTensor and
+        Normalize then run on the device and a frame crosses PCIe as 3 bytes per pixel instead of 12)"""
         g = torch.Generator().manual_seed(seed)
         self.images = None
+        self.uint8 = uint8
         self.shape, self.seed, self.length = (3, H, W), seed, length
         t = torch.cumsum(0.05 * torch.randn(length, 3, generator=g), dim=0)
         axis = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0)
@@ -192,4 +198,7 @@ class SyntheticFrames(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1000003 + int(i))
+        if self.uint8:
+            _, H, W = self.shape
+            return torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8), self.poses[int(i)]
         return torch.randn(*self.shape, generator=g), self.poses[int(i)]

@@ -37,6 +37,8 @@ def build_parser():
     # additions
     parser.add_argument("--dtype", choices=("fp16", "fp32"), default="fp16")
     parser.add_argument("--synthetic_length", type=int, default=256)
+    parser.add_argument("--u8_input", action="store_true", help="frames as uint8 [H,W,3]; ToTensor + Normalize run on the "
+                        "device (model.set_input_u8)")
     parser.add_argument("--height", type=int, default=256)
     parser.add_argument("--width", type=int, default=341)
     return parser
@@ -82,6 +84,8 @@ def run(args, dataset=None, pose_stats=None, _binding=None, log=print):
     else:
         model = posenet
     model.eval()
+    if args.u8_input:
+        model.set_input_u8(SyntheticFrames.MEAN, SyntheticFrames.STD)
 
     # load weights
     weights_filename = osp.expanduser(args.weights)
@@ -103,7 +107,8 @@ def run(args, dataset=None, pose_stats=None, _binding=None, log=print):
             raise NotImplementedError(
                 "the {:s} image reader is host-side file parsing outside the MI355X hot path: pass the frame dataset "
                 "to run(args, dataset=...), or use --dataset Synthetic".format(args.dataset))
-        dataset = SyntheticFrames(args.synthetic_length, H=args.height, W=args.width, seed=seed + (0 if train else 1))
+        dataset = SyntheticFrames(args.synthetic_length, H=args.height, W=args.width, seed=seed + (0 if train else 1),
+                                  uint8=args.u8_input)
     if windows:
         if args.pose_graph:
             assert real

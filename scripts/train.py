@@ -46,6 +46,8 @@ def build_parser():
     parser.add_argument("--synthetic_length", type=int, default=1024, help="frames in the synthetic sequence")
     parser.add_argument("--synthetic_val_length", type=int, default=None, help="frames in the validation sequence "
                         "(default: a quarter of --synthetic_length)")
+    parser.add_argument("--u8_input", action="store_true", help="frames as uint8 [H,W,3]; ToTensor + Normalize run on the "
+                        "device (model.set_input_u8)")
     parser.add_argument("--height", type=int, default=256)
     parser.add_argument("--width", type=int, default=341)
     parser.add_argument("--epochs", type=int, default=None, help="override [training] n_epochs")
@@ -120,6 +122,9 @@ def run(args, datasets=None, _binding=None, log=print):
     posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=False, filter_nans=(args.model == "mapnet++"), **kw)
     model = posenet if args.model == "posenet" else G.MapNet(mapnet=posenet)
 
+    if args.u8_input:  # the DataLoader ships decoded frames; normalisation happens in the input-conversion kernel
+        model.set_input_u8(SyntheticFrames.MEAN, SyntheticFrames.STD)
+
     # loss function
     if args.model == "posenet":
         train_criterion = G.PoseNetCriterion(sax=sax, saq=saq, learn_beta=args.learn_beta, **kw)
@@ -145,9 +150,9 @@ def run(args, datasets=None, _binding=None, log=print):
     if datasets is not None:
         train_frames, val_frames = datasets
     elif args.dataset == "Synthetic":
-        train_frames = SyntheticFrames(args.synthetic_length, H=args.height, W=args.width, seed=seed)
+        train_frames = SyntheticFrames(args.synthetic_length, H=args.height, W=args.width, seed=seed, uint8=args.u8_input)
         n_val = args.synthetic_val_length if args.synthetic_val_length else max(args.synthetic_length // 4, 8)
-        val_frames = SyntheticFrames(n_val, H=args.height, W=args.width, seed=seed + 1)
+        val_frames = SyntheticFrames(n_val, H=args.height, W=args.width, seed=seed + 1, uint8=args.u8_input)
     else:
         raise NotImplementedError(
             "the {:s} image reader is host-side file parsing outside the MI355X hot path: build the frame datasets "

@@ -101,10 +101,12 @@ def test_eval_pose_graph_and_posenet_weights_into_mapnet(lib, tmp_path):
 
 def test_train_posenet_with_validation_and_mapnet_online_wiring(lib, tmp_path):
     cfg = _config(tmp_path, "synthetic_posenet.ini", n_epochs=1, batch_size=2, snapshot=1, val_freq=1)
-    train_script, args = _train_args(tmp_path, "posenet", cfg, ["--learn_beta"])
+    train_script, args = _train_args(tmp_path, "posenet", cfg, ["--learn_beta", "--u8_input"])  # uint8 frames, device-side Normalize
     lines = []
     tr = train_script.run(args, _binding=lib, log=lines.append)
     assert any(l.startswith("Val ") and "val_loss" in l for l in lines) and np.isfinite(tr.last_val_loss)
+    data, _ = next(iter(tr.train_loader))
+    assert data.dtype == torch.uint8 and tuple(data.shape) == (2, H, W, 3)
     # MapNet++: construction only (n_epochs = 0; the step itself is covered by test_emu_network.py) -- model with the
     # NaN filter, online criterion, MFOnline batches of 2T frames with T + (T-1) target rows
     cfg = _config(tmp_path, "synthetic_mapnet_online.ini", n_epochs=0, batch_size=1, snapshot=1, skip=1)

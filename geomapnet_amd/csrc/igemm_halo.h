@@ -1,0 +1,290 @@
+// EXPERIMENTAL (MN_IGEMM_HALO=1, off by default; emulator-verified, not yet timed): the 12-wave 288x256 implicit-GEMM
+// tile of igemm.h for 3x3 stride-1 "same" convolutions of fp16 tensors, with the A operand staged per 64-channel CHUNK
+// instead of per K-step.
+//
+// igemm.h moves 288 A rows + 256 B rows = 69.6 KB through LDS-DMA per K-step (one tap of one 64-channel chunk); the nine
+// taps of a chunk fetch nine shifted copies of the same pixels.  Here a chunk's A rows are fetched ONCE, with a halo:
+// in the flattened (b, y, x) pixel order a tap (dy, dx) is the row shift dy*W + dx, so the image holds rows
+// [m0 - (W+1), m0 + 288 + (W+1)) and a K-step reads its A fragments at row offset (W+1) + dy*W + dx.  What differs per
+// row is validity (image borders, rows past M): a lane whose (row, tap) is outside the image reads a 16-byte zero slot
+// instead.  DMA per K-step: 32 KB (B slice) + 44 KB / 9 (A image) = 36.9 KB instead of 69.6 KB.
+//
+// LDS (161.8 of 160 KiB = 163 840 B): two A images of kAH = 352 rows (the next chunk's image is fetched, one DMA pass per
+// K-step, while the current one is read), a two-slot B ring of 256 rows, the zero slot, BatchNorm scratch.
+// W <= 31 (352 >= 288 + 2 (W + 1)): layer3 (W = 22) and layer4 (W = 11) at 256x341.
+// Synchronisation is igemm.h's: one `s_waitcnt vmcnt(0)` + raw barrier per K-step; every DMA is issued right after a
+// barrier and waited for at the next one, so image pass p of chunk c+1 (issued in K-step p of chunk c) has landed eight
+// barriers before it is read, and the image it overwrites was last read in chunk c-1.
+#pragma once
+#include "igemm.h"
+
+namespace mn {
+
+constexpr int kAH = 352;  // rows of one A image
+
+static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
+                                                                   const half* __restrict__ Bw, Epilogue ep, int grid_n,
+                                                                   RowDiv rd) {
+  constexpr int VEC = 8, NP = 8, WM = 3, WN = 4, TM = 3, TN = 2, NT = 768;
+  constexpr int BM = 288, BN = 256, WTM = 96, WTN = 64, RPP = NT / NP;  // 96 rows per DMA pass
+  constexpr int A_IMG = kAH * NP, B_SLOT = BN * NP, RING = 2 * A_IMG + 2 * B_SLOT;  // pieces
+  constexpr int A_PASSES = (kAH + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;   // 4, 3
+  __shared__ piece_t smem[RING + 1 + WM * BN / 2];
+  float* red = reinterpret_cast<float*>(&smem[RING + 1]);  // [WM][BN][2]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = tile / grid_n, tile_n = tile - tile_m * grid_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int W = g.Wi, halo = W + 1;
+  const int NCH = g.C / 64, KT = 9 * NCH;
+  if (t == 0) smem[RING] = zero_piece();  // visible after the first barrier of the K loop
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(A, (long)g.M * g.C * 2L);
+  const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(Bw, (long)g.N * g.K * 2L);
+  const int pc = t % NP, lrow = t / NP;
+  const int src_piece = pc ^ lds_swz<NP>(lrow);  // rows of one thread differ by multiples of 96: invisible to the swizzle
+
+  // DMA state: byte offset of this thread's row in every pass (all ones = outside the tensor: the bounds check returns 0)
+  unsigned a_off[A_PASSES], b_off[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int pix = m0 - halo + lrow + i * RPP;
+    a_off[i] = (pix >= 0 && pix < g.M) ? (unsigned)pix * (unsigned)(g.C * 2) + (unsigned)src_piece * 16u : ~0u;
+  }
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int n = n0 + lrow + j * RPP;
+    b_off[j] = n < g.N ? (unsigned)(n * g.K) * 2u + (unsigned)src_piece * 16u : ~0u;
+  }
+  // pass p of the A image of `chunk`; a wave whose rows lie past the image skips the instruction (wave-uniform)
+  auto issue_a = [&](int chunk, int p) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i)
+      if (i == p && wave * (64 / NP) + i * RPP < kAH)
+        dma16(rsrc_a, a_off[i], (unsigned)(chunk * 128), &smem[(chunk & 1) * A_IMG + i * RPP * NP + wave * 64]);
+  };
+  auto issue_b = [&](int kt) {
+    const int chunk = kt / 9, tap = kt - chunk * 9;
+    const unsigned soff = (unsigned)((tap * g.C + chunk * 64) * 2);
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      if (wave * (64 / NP) + j * RPP < BN)
+        dma16(rsrc_b, b_off[j], soff, &smem[2 * A_IMG + (kt & 1) * B_SLOT + j * RPP * NP + wave * 64]);
+  };
+
+  // Fragment rows of this lane: tile-local row, its validity mask (bit tap set = outside the image, 9 bits per row tile)
+  const int l31 = lane & 31, hi = lane >> 5;
+  unsigned inv_mask = 0;  // [i] at bits 9i .. 9i+8
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WTM + i * 32 + l31;
+    unsigned inv = 0x1ffu;
+    if (m < g.M) {
+      const int tmp = fastdiv(m, rd.q), x = m - tmp * g.Q;
+      const int bb = fastdiv(tmp, rd.p), y = tmp - bb * g.P;
+      inv = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int yy = y + g.off_h + g.rsign * r, xx = x + g.off_w + g.ssign * s;
+          const bool ok = (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi;
+          inv |= (ok ? 0u : 1u) << (r * 3 + s);
+        }
+    }
+    inv_mask |= inv << (9 * i);
+  }
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: the whole image of chunk 0 and the first B slice
+#pragma unroll
+  for (int p = 0; p < A_PASSES; ++p) issue_a(0, p);
+  issue_b(0);
+
+  int chunk = 0, tap = 0, tr = 0, ts = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // this step's B slice (and any image pass in flight) landed; last step's reads are done
+    if (kt + 1 < KT) issue_b(kt + 1);
+    if (tap < A_PASSES && chunk + 1 < NCH) issue_a(chunk + 1, tap);
+    const piece_t* img = &smem[(chunk & 1) * A_IMG];
+    const piece_t* tb = &smem[2 * A_IMG + (kt & 1) * B_SLOT];
+    const int shift = halo + (g.off_h + g.rsign * tr) * W + g.off_w + g.ssign * ts;  // scalar
+    // per row tile: LDS row of this lane for this tap, its swizzle, and whether the lane reads the zero slot instead
+    int arow[TM], aswz[TM];
+    bool ainv[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      arow[i] = wm * WTM + i * 32 + l31 + shift;
+      aswz[i] = lds_swz<NP>(arow[i]);
+      ainv[i] = ((inv_mask >> (9 * i + tap)) & 1u) != 0;
+    }
+    const int brow = wn * WTN + l31, bswz = lds_swz<NP>(l31);  // B rows: multiples of 32 plus l31
+    PieceView<half> fa[2][TM], fb[2][TN];
+    auto load_frags = [&](int ks, int slot) {
+      const int piece = ks * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const piece_t* p = ainv[i] ? &smem[RING] : img + arow[i] * NP + (piece ^ aswz[i]);
+        fa[slot][i].p = *p;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[slot][j].p = tb[(brow + j * 32) * NP + (piece ^ bswz)];
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < NP / 2; ++ks) {
+      if (ks + 1 < NP / 2) load_frags(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_piece<half>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++ts == 3) {
+      ts = 0;
+      ++tr;
+    }
+    if (++tap == 9) {
+      tap = tr = ts = 0;
+      ++chunk;
+    }
+  }
+  __syncthreads();  // all fragment reads done before the ring is reused as epilogue staging
+
+  // ---- epilogue: igemm.h's (alpha, bias, ReLU, BatchNorm column sums, residual / gates, 16-byte stores), three wave
+  //      rows staged per round; no output row map, no stream-K -------------------------------------------------------
+  half* out = reinterpret_cast<half*>(ep.out);
+  const half* res = reinterpret_cast<const half*>(ep.res);
+  const half* gate = reinterpret_cast<const half*>(ep.res_gate);
+  const half* ogate = reinterpret_cast<const half*>(ep.out_gate);
+  float* stage = reinterpret_cast<float*>(&smem[0]);  // [96][128] fp32
+  constexpr int SC = 128, CPR = SC / VEC, PASSES = (WM * 32 * CPR + NT - 1) / NT;  // 2
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+    for (int nh = 0; nh < BN / SC; ++nh) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int lc = wn * WTN + j * 32 + l31;
+        if (lc / SC == nh) {
+          const float bias = (ep.bias && n0 + lc < g.N) ? ep.bias[n0 + lc] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r] * ep.alpha + bias;
+            if (ep.relu & 1) v = fmaxf(v, 0.f);
+            s1[j] += v;
+            s2[j] += v * v;
+            const int lr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            stage[lr * SC + (lc - nh * SC)] = v;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int id = t + ps * NT;
+        const int lr = id / CPR, cpc = id % CPR;
+        const int row = m0 + (lr >> 5) * WTM + i * 32 + (lr & 31);
+        const int col = n0 + nh * SC + cpc * VEC;
+        if (lr < WM * 32 && row < g.M && col < g.N) {
+          float v[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; e += 4) {
+            floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * SC + cpc * VEC + e]);
+            v[e] = f[0];
+            v[e + 1] = f[1];
+            v[e + 2] = f[2];
+            v[e + 3] = f[3];
+          }
+          const long idx = (long)row * ep.ldc + col;
+          if (res) {
+            PieceView<half> rv, gv;
+            rv.p = *reinterpret_cast<const piece_t*>(res + idx);
+            if (gate) gv.p = *reinterpret_cast<const piece_t*>(gate + idx);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              float x = (float)rv.e[e];
+              if (gate && !((float)gv.e[e] > 0.f)) x = 0.f;
+              v[e] += x;
+            }
+          }
+          if (ogate) {
+            PieceView<half> ov;
+            ov.p = *reinterpret_cast<const piece_t*>(ogate + idx);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+              if (!((float)ov.e[e] > 0.f)) v[e] = 0.f;
+          }
+          PieceView<half> o;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o.e[e] = (half)v[e];
+          *reinterpret_cast<piece_t*>(out + idx) = o.p;
+        }
+      }
+      __syncthreads();
+    }
+  if (ep.stats || ep.stats_accum) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+      if (lane < 32) {
+        const int lc = wn * WTN + j * 32 + lane;
+        red[(wm * BN + lc) * 2 + 0] = s1[j];
+        red[(wm * BN + lc) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    for (int c = t; c < BN; c += NT)
+      if (n0 + c < g.N) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          a += red[(w * BN + c) * 2 + 0];
+          b += red[(w * BN + c) * 2 + 1];
+        }
+        if (ep.stats_accum) {
+          double* row = ep.stats_accum + (long)(tile_m % ep.stats_rows) * 2 * g.N;
+          atomicAdd(row + n0 + c, (double)a);
+          atomicAdd(row + g.N + n0 + c, (double)b);
+        } else {
+          ep.stats[((long)tile_m * 2 + 0) * g.N + n0 + c] = a;
+          ep.stats[((long)tile_m * 2 + 1) * g.N + n0 + c] = b;
+        }
+      }
+  }
+}
+
+// the launches the kernel covers: 3x3, stride 1, same size, 64-channel chunks, N in 256-column tiles, narrow images
+inline bool igemm_halo_applies(const GatherGeom& g, const Epilogue& ep) {
+  return g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&
+         g.C % 64 == 0 && g.N % 256 == 0 && g.K == 9 * g.C && !g.bt_on && (g.ldb == 0 || g.ldb == g.K) &&
+         (g.rsign == 1 || g.rsign == -1) && g.rsign == g.ssign && 288 + 2 * (g.Wi + 1) <= kAH && g.M == g.B * g.P * g.Q &&
+         (long)g.M * g.C * 2 < 0xfffffff0l && (long)g.N * g.K * 2 < 0xfffffff0l && !ep.om_on;
+}
+
+// returns the number of M-blocks used (rows of a [grid_m][2][N] statistics buffer)
+inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream) {
+  const int gm = cdiv(g.M, 288), gn = g.N / 256;
+  RowDiv rd;
+  rd.q = make_fastdiv(g.Q);
+  rd.p = make_fastdiv(g.P);
+  hipLaunchKernelGGL(igemm_halo_kernel, dim3(gm * gn), dim3(768), 0, stream, g, A, Bw, ep, gn, rd);
+  return gm;
+}
+
+}  // namespace mn

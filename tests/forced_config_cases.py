@@ -32,6 +32,22 @@ def main(backend):
         print("forced-config cases ok")
         return
     assert os.environ.get("MN_IGEMM_CONFIG") == "12"
+    if os.environ.get("MN_IGEMM_HALO") == "1":
+        # igemm_halo.h (A operand staged once per 64-channel chunk): fp16 3x3 stride-1 convolutions, one to four chunks,
+        # ragged last tile, tiles that start inside an image and span several, widths up to the 31-pixel limit
+        for shape in ((4, 9, 11, 64, 256, 3, 1, 1), (3, 16, 22, 256, 256, 3, 1, 1), (7, 8, 11, 128, 512, 3, 1, 1),
+                      (2, 13, 31, 192, 256, 3, 1, 1), (40, 3, 5, 64, 256, 3, 1, 1)):
+            checks.check_conv_fwd(lib, dev, 1, *shape)
+        for mode in ("plain", "out_gate", "res_gate"):
+            checks.check_conv_dgrad_op(lib, dev, 1, 3, 16, 22, 256, 256, 3, 1, 1, parity=1, mode=mode)
+        checks.check_conv_dgrad_op(lib, dev, 1, 5, 8, 11, 256, 128, 3, 1, 1, parity=1, mode="out_gate")
+        if backend != "emu":  # layer3 / layer4 geometries with hundreds of concurrent workgroups, repeated (race screen)
+            for rep in range(3):
+                checks.check_conv_fwd(lib, dev, 1, 96, 16, 22, 256, 256, 3, 1, 1, seed=rep)
+                checks.check_conv_fwd(lib, dev, 1, 96, 8, 11, 512, 512, 3, 1, 1, seed=10 + rep)
+                checks.check_conv_dgrad_op(lib, dev, 1, 96, 16, 22, 256, 256, 3, 1, 1, parity=1, mode="res_gate", seed=20 + rep)
+        print("forced-config cases ok")
+        return
     for dtype in (0, 1):
         # (B, H, W, Cin, Cout, k, stride, pad): 396 / 663 / 198 rows = 1.4 / 2.3 / 0.7 tiles of 288 rows
         checks.check_conv_fwd(lib, dev, dtype, 4, 9, 11, 64, 256, 3, 1, 1)

@@ -184,3 +184,15 @@ def test_weight_gradient_with_assembly_transpose_reads():
                                       ("gps", 2, 5), ("posenet", 1, 1), ("mapnet", 70, 4), ("online", 33, 3)])
 def test_criteria_vs_oracle_other_window_lengths(lib, mode, N, T):
     checks.check_criterion_vs_oracle(lib, DEV, mode, N, T)
+
+
+def test_experimental_chunk_resident_a_kernel():
+    """igemm_halo.h (MN_IGEMM_HALO=1, off by default): the 288x256 tile with the A operand staged once per 64-channel chunk
+    and taps as row shifts into that image, against torch fp64 (forward with BatchNorm sums, data gradient with residual
+    and gates; one to four chunks, ragged tiles, tiles spanning several images)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1")
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)

@@ -349,3 +349,13 @@ def test_weight_gradient_with_assembly_transpose_reads():
     for variant in ("1", "0"):  # 32-row steps (default) and 64-row steps
         env = dict(os.environ, MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT=variant)
         subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "hip"], check=True, env=env, timeout=600)
+
+
+def test_experimental_chunk_resident_a_kernel():
+    """MN_IGEMM_HALO=1 (off by default): igemm_halo.h against torch fp64, plus layer3 / layer4 geometries repeated.
+    Kept last."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1")
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "hip"], check=True, env=env, timeout=600)

@@ -672,18 +672,18 @@ inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const 
   return gm;
 }
 
-// igemm_halo.h (experimental, MN_IGEMM_HALO=1): the 288x256 tile with the A operand staged once per 64-channel chunk
-inline bool igemm_halo_applies(const GatherGeom& g, const Epilogue& ep);
-inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream);
+// igemm_halo.h (experimental, MN_IGEMM_HALO=1|2): 288-row tiles with the A operand staged once per 64-channel chunk
+inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
+                             int level, bool tile288_wanted);
 template <typename T>
-inline int maybe_launch_igemm_halo(const GatherGeom&, const T*, const T*, const Epilogue&, hipStream_t) {
+inline int maybe_launch_igemm_halo(const GatherGeom&, const T*, const T*, const Epilogue&, hipStream_t, bool) {
   return -1;
 }
 template <>
 inline int maybe_launch_igemm_halo<half>(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep,
-                                         hipStream_t stream) {
-  static const bool on = getenv("MN_IGEMM_HALO") && atoi(getenv("MN_IGEMM_HALO")) != 0;
-  return on && igemm_halo_applies(g, ep) ? launch_igemm_halo(g, A, Bw, ep, stream) : -1;
+                                         hipStream_t stream, bool tile288_wanted) {
+  static const int level = getenv("MN_IGEMM_HALO") ? atoi(getenv("MN_IGEMM_HALO")) : 0;
+  return level > 0 ? launch_igemm_halo(g, A, Bw, ep, stream, level, tile288_wanted) : -1;
 }
 
 // returns the number of M-blocks used (= rows of the stats partial buffer that were written)
@@ -733,6 +733,10 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
     if (wide_k && g.N % 256 == 0 && tiles128 > 512 && tiles288 > 192 && tiles288 <= igemm_sk_blocks() / 2 && g.R * g.S <= 10)
       cfg = 12;
   }
+  {
+    const int gm_halo = maybe_launch_igemm_halo<T>(g, A, Bw, ep, stream, cfg == 12 && wide_k && g.N % 256 == 0);
+    if (gm_halo >= 0) return gm_halo;
+  }
   if (g.N <= 64) {
     // (measured and removed for the 64-channel layers: 3-deep ring, 64-byte steps with a 4-deep ring, 256x64 tiles of
     // 64x64 wave tiles, 2-wave workgroups of 64x64 wave tiles: 145 us -> 157..183 us on layer1)
@@ -749,8 +753,7 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   // 288x256, 12 waves of 96x64, 128-byte K-steps, 2 buffers, one workgroup per CU: M = B*P*Q of the 256x341 input at
   // B = 192 is 132 * 2^k, and 288-row tiles put layer3 (67584 rows, N = 256) on 235 of the 256 CUs in ONE round
   if (cfg == 12 && wide_k && g.N % 256 == 0 && g.R * g.S <= 10) {  // (packed tap masks: 10 bits per A pass)
-    const int gm_halo = maybe_launch_igemm_halo<T>(g, A, Bw, ep, stream);
-    if (gm_halo >= 0) return gm_halo;
+
 #ifdef MN_ABLATION_BUILD
     static const int abl = getenv("MN_ABLATE") ? atoi(getenv("MN_ABLATE")) : 0;
     if (abl == 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 1>(g, A, Bw, ep, stream, zero_page);

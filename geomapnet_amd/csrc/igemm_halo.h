@@ -9,9 +9,9 @@
 // row is validity (image borders, rows past M): a lane whose (row, tap) is outside the image reads a 16-byte zero slot
 // instead.  DMA per K-step: 32 KB (B slice) + 44 KB / 9 (A image) = 36.9 KB instead of 69.6 KB.
 //
-// LDS (161.8 of 160 KiB = 163 840 B): two A images of kAH = 352 rows (the next chunk's image is fetched, one DMA pass per
+// LDS (158 of 160 KiB for the 256-column shape): two A images of kAH rows (the next chunk's image is fetched, one DMA pass per
 // K-step, while the current one is read), a two-slot B ring of 256 rows, the zero slot, BatchNorm scratch.
-// W <= 31 (352 >= 288 + 2 (W + 1)): layer3 (W = 22) and layer4 (W = 11) at 256x341.
+// kAH >= 288 + 2 (W + 1) bounds the image width W.
 // Synchronisation is igemm.h's: one `s_waitcnt vmcnt(0)` + raw barrier per K-step; every DMA is issued right after a
 // barrier and waited for at the next one, so image pass p of chunk c+1 (issued in K-step p of chunk c) has landed eight
 // barriers before it is read, and the image it overwrites was last read in chunk c-1.
@@ -20,14 +20,18 @@
 
 namespace mn {
 
-constexpr int kAH = 352;  // rows of one A image
-
+// Two shapes: <256, 352> (N in 256-column tiles, W <= 31: layer3) and <128, 384> (128-column tiles, W <= 47, 131 KB of
+// LDS: layer2 with its 43-pixel rows, and layer4, whose 16 896 rows give 59 x 4 = 236 tiles = one round of the chip).
+template <int BN, int kAH>
 static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
-  constexpr int VEC = 8, NP = 8, WM = 3, WN = 4, TM = 3, TN = 2, NT = 768;
-  constexpr int BM = 288, BN = 256, WTM = 96, WTN = 64, RPP = NT / NP;  // 96 rows per DMA pass
+  constexpr int VEC = 8, NP = 8, WM = 3, WN = 4, TM = 3, TN = BN / 128, NT = 768;
+  constexpr int BM = 288, WTM = 96, WTN = BN / WN, RPP = NT / NP;  // 96 rows per DMA pass
+  static_assert(BN == 128 || BN == 256, "wave tiles of 96 x 32 or 96 x 64");
   constexpr int A_IMG = kAH * NP, B_SLOT = BN * NP, RING = 2 * A_IMG + 2 * B_SLOT;  // pieces
+  static_assert((RING + 1 + WM * BN / 2) * 16 <= 160 * 1024, "LDS");
+  static_assert(RING * 16 >= 96 * 128 * 4, "epilogue staging (the ring is free by then)");
   constexpr int A_PASSES = (kAH + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;   // 4, 3
   __shared__ piece_t smem[RING + 1 + WM * BN / 2];
   float* red = reinterpret_cast<float*>(&smem[RING + 1]);  // [WM][BN][2]
@@ -269,22 +273,32 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
   }
 }
 
-// the launches the kernel covers: 3x3, stride 1, same size, 64-channel chunks, N in 256-column tiles, narrow images
-inline bool igemm_halo_applies(const GatherGeom& g, const Epilogue& ep) {
+// the launches the kernels cover: fp16 3x3, stride 1, same size, 64-channel chunks
+inline bool igemm_halo_applies(const GatherGeom& g, const Epilogue& ep, int bn, int ah) {
   return g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&
-         g.C % 64 == 0 && g.N % 256 == 0 && g.K == 9 * g.C && !g.bt_on && (g.ldb == 0 || g.ldb == g.K) &&
-         (g.rsign == 1 || g.rsign == -1) && g.rsign == g.ssign && 288 + 2 * (g.Wi + 1) <= kAH && g.M == g.B * g.P * g.Q &&
+         g.C % 64 == 0 && g.N % bn == 0 && g.K == 9 * g.C && !g.bt_on && (g.ldb == 0 || g.ldb == g.K) &&
+         (g.rsign == 1 || g.rsign == -1) && g.rsign == g.ssign && 288 + 2 * (g.Wi + 1) <= ah && g.M == g.B * g.P * g.Q &&
          (long)g.M * g.C * 2 < 0xfffffff0l && (long)g.N * g.K * 2 < 0xfffffff0l && !ep.om_on;
 }
 
-// returns the number of M-blocks used (rows of a [grid_m][2][N] statistics buffer)
-inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream) {
-  const int gm = cdiv(g.M, 288), gn = g.N / 256;
+// MN_IGEMM_HALO: 1 = the 256-column shape where igemm.h would pick its own 288x256 tile (layer3 at 192 images, or a
+// forced MN_IGEMM_CONFIG=12); 2 = additionally the 128-column shape for every other launch it covers (layers 2 and 4).
+// Returns the number of M-blocks used (rows of a [grid_m][2][N] statistics buffer), or -1 if the launch is not taken.
+inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
+                             int level, bool tile288_wanted) {
+  const int gm = cdiv(g.M, 288);
   RowDiv rd;
   rd.q = make_fastdiv(g.Q);
   rd.p = make_fastdiv(g.P);
-  hipLaunchKernelGGL(igemm_halo_kernel, dim3(gm * gn), dim3(768), 0, stream, g, A, Bw, ep, gn, rd);
-  return gm;
+  if (level >= 1 && tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) {
+    hipLaunchKernelGGL((igemm_halo_kernel<256, 352>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
+    return gm;
+  }
+  if (level >= 2 && igemm_halo_applies(g, ep, 128, 384)) {
+    hipLaunchKernelGGL((igemm_halo_kernel<128, 384>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
+    return gm;
+  }
+  return -1;
 }
 
 }  // namespace mn

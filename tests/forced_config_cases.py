@@ -31,6 +31,22 @@ def main(backend):
                     checks.check_conv_wgrad(lib, dev, 1, *shape, target_blocks=1024, seed=2 + rep)
         print("forced-config cases ok")
         return
+    if os.environ.get("MN_IGEMM_HALO") == "2" and os.environ.get("MN_IGEMM_CONFIG") is None:
+        # the 128-column shape of igemm_halo.h (no forced tile configuration: it takes every launch it covers):
+        # N = 128 / 384 / 512, rows up to the 47-pixel limit, one to eight chunks
+        for shape in ((3, 9, 11, 64, 128, 3, 1, 1), (2, 12, 43, 128, 128, 3, 1, 1), (2, 7, 47, 64, 384, 3, 1, 1),
+                      (9, 8, 11, 512, 512, 3, 1, 1), (40, 3, 5, 64, 128, 3, 1, 1)):
+            checks.check_conv_fwd(lib, dev, 1, *shape)
+        for mode in ("plain", "out_gate", "res_gate"):
+            checks.check_conv_dgrad_op(lib, dev, 1, 2, 12, 43, 128, 128, 3, 1, 1, parity=1, mode=mode)
+        checks.check_conv_dgrad_op(lib, dev, 1, 9, 8, 11, 512, 512, 3, 1, 1, parity=1, mode="res_gate")
+        if backend != "emu":  # layer2 / layer4 geometries at a size that fills the chip, repeated (race screen)
+            for rep in range(3):
+                checks.check_conv_fwd(lib, dev, 1, 48, 32, 43, 128, 128, 3, 1, 1, seed=rep)
+                checks.check_conv_fwd(lib, dev, 1, 192, 8, 11, 512, 512, 3, 1, 1, seed=10 + rep)
+                checks.check_conv_dgrad_op(lib, dev, 1, 48, 32, 43, 128, 128, 3, 1, 1, parity=1, mode="res_gate", seed=20 + rep)
+        print("forced-config cases ok")
+        return
     assert os.environ.get("MN_IGEMM_CONFIG") == "12"
     if os.environ.get("MN_IGEMM_HALO") == "1":
         # igemm_halo.h (A operand staged once per 64-channel chunk): fp16 3x3 stride-1 convolutions, one to four chunks,

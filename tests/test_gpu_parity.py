@@ -357,5 +357,8 @@ def test_experimental_chunk_resident_a_kernel():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1")
+    env = dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1")  # the 256-column shape (layer3)
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "hip"], check=True, env=env, timeout=600)
+    env = dict(os.environ, MN_IGEMM_HALO="2")                        # the 128-column shape (layers 2 and 4)
+    env.pop("MN_IGEMM_CONFIG", None)
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "hip"], check=True, env=env, timeout=600)

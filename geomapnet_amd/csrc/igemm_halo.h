@@ -44,7 +44,10 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int W = g.Wi, halo = W + 1;
   const int NCH = g.C / 64, KT = 9 * NCH;
-  if (t == 0) smem[RING] = zero_piece();  // visible after the first barrier of the K loop
+  if (t == 0) smem[RING] = zero_piece();
+  // lgkmcnt(0): the store has reached LDS before this wave arrives at the K loop's first barrier (a raw s_barrier does
+  // not wait for outstanding LDS writes), after which every wave may read the slot
+  __builtin_amdgcn_s_waitcnt(0xc07f);
 
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(A, (long)g.M * g.C * 2L);
   const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(Bw, (long)g.N * g.K * 2L);

@@ -59,8 +59,14 @@ class _Criterion(nn.Module):
     def learn_gamma(self):
         return self._has_rel and self.srx.requires_grad
 
-    def _windows_T(self, pred):
+    def _windows_T(self, pred, targ):
         raise NotImplementedError
+
+    def check_batch(self, n, frames, targ):
+        """shape validation of a fused training step's target against the prediction [n, frames, 6] ([n, 6] for
+        PoseNet) the model will produce -- the same checks `forward` applies; raises ValueError"""
+        shape = (n, 6) if self.mode == MODE_POSENET else (n, frames, 6)
+        return self._windows_T(torch.empty(shape, device="meta"), targ)
 
     def forward(self, pred, targ):
         lib = self._lib if self._lib is not None else _binding.hip()

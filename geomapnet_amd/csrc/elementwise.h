@@ -369,7 +369,8 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
                                                             const double* __restrict__ accum, double count,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float grad_unscale, T* __restrict__ gy, long npieces, int C,
-                                                            const float* __restrict__ sg_beta, PoolGradSrc pg, int accum_rows) {
+                                                            const float* __restrict__ sg_beta, PoolGradSrc pg, int accum_rows,
+                                                            int reverse) {
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512], s_sh[512];
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -391,7 +392,10 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
   }
   __syncthreads();
   const int cpr = C / VEC;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
+  // reverse: walk the tensor back to front -- the reduction pass that ran just before read g and y front to back, so
+  // their tails are what the L2s / Infinity Cache still hold
+  for (long i_ = (long)blockIdx.x * blockDim.x + threadIdx.x; i_ < npieces; i_ += (long)gridDim.x * blockDim.x) {
+    const long i = reverse ? npieces - 1 - i_ : i_;
     int c0 = (int)(i % cpr) * VEC;
     PieceView<T> vg, vy, vm, o;
     if (pg.idx) {
@@ -494,8 +498,10 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
     hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(nblk, 64), cdiv(C, 64)), dim3(256), 0, s,
                        (const float*)partial, nblk, C, accum, 64);
   long np = M * C / VEC;
+  static const int reverse = getenv("MN_BN_BWD_REVERSE") ? atoi(getenv("MN_BN_BWD_REVERSE")) : 0;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd, gamma,
-                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C, self_gate_beta, pg, accum_rows);
+                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C, self_gate_beta, pg, accum_rows,
+                     reverse);
 }
 
 // ---- global average pool --------------------------------------------------------------------------

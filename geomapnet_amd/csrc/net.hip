@@ -118,6 +118,7 @@ struct PlanBase {
     // hip::Graph::UpdateStreams (reproduced: two plans trained and freed, a third one captured and launched;
     // leaking either the execs or the stream avoids it).  The leak is a few hundred graph nodes per plan.
     for (hipEvent_t e : fork_events) hipEventDestroy(e);
+    if (overflow_host) hipHostFree(overflow_host);
   }
   static hipStream_t shared_side_stream() {
     static hipStream_t streams[64] = {};
@@ -242,7 +243,35 @@ struct PlanBase {
                            hipStream_t s) = 0;
   virtual int backward_stage(int stage, hipStream_t s) = 0;
   virtual int optim_step(float grad_mul, hipStream_t s) = 0;
+  virtual int debug_tensor(const char* name, void** ptr, int64_t* numel, int32_t* dtype) = 0;
   mn_config cfg;
+  // fp16 loss scaling.  cur_scale multiplies d(pred) and is divided out where gradients enter the fp32 arena.  An
+  // overflowed step is skipped on the device (optim.h, adam_prep_kernel); the count of skipped steps is copied to a
+  // pinned host word after every optimiser step and read -- without waiting -- when the next step is enqueued: each
+  // newly seen skip halves the scale, `scale_growth_interval` clean steps double it (0 = never grow).  The host reacts
+  // one or two steps late; until then the device keeps skipping, so no non-finite value reaches weights or moments.
+  float cur_scale = 1.f;
+  bool overflow_guard = false;
+  long long* overflow_host = nullptr;  // pinned: {last step skipped, skipped steps in total}
+  long long skipped_seen = 0;
+  int clean_steps = 0;
+  int scale_growth_interval = getenv("MN_SCALE_GROWTH") ? atoi(getenv("MN_SCALE_GROWTH")) : 2000;
+  void poll_overflow() {
+    if (!overflow_guard || !overflow_host) return;
+    const long long seen = *(volatile long long*)(overflow_host + 1);
+    if (seen > skipped_seen) {
+      for (long long i = skipped_seen; i < seen && cur_scale > 1.f; ++i) cur_scale *= 0.5f;
+      skipped_seen = seen;
+      clean_steps = 0;
+      hyper_version++;
+    } else if (scale_growth_interval > 0 && ++clean_steps >= scale_growth_interval) {
+      clean_steps = 0;
+      if (cur_scale < 65536.f) {
+        cur_scale *= 2.f;
+        hyper_version++;
+      }
+    }
+  }
   Layout L{2048};
   float lr = 1e-4f, wd = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, max_grad_norm = 0.f;
   int64_t step = 0;
@@ -314,6 +343,7 @@ struct Plan : PlanBase {
   float* sk_ws = nullptr;   // stream-K slabs [igemm_sk_blocks()][2][128*128] and
   int* sk_counters = nullptr;  // arrival counters; zero between launches (igemm.h)
   void* zero_page;          // 256 zero bytes: source of out-of-image taps for the DMA conv pipeline
+  long long* overflow_dev;  // {this step skipped, skipped steps in total} (adam_prep_kernel)
   long long* step_dev;      // device-resident Adam step counter
   float* bc_dev;            // {1 - beta1^t, 1 - beta2^t}, derived on device from step_dev
   const float* cur_targets = nullptr;
@@ -392,6 +422,7 @@ struct Plan : PlanBase {
     sk_counters = (int*)A((size_t)igemm_sk_blocks() * 4);
     step_dev = (long long*)A(256);
     bc_dev = (float*)A(256);
+    overflow_dev = (long long*)A(256);
     return b.cur;
   }
 
@@ -417,6 +448,8 @@ struct Plan : PlanBase {
 
   Plan(const mn_config& c) {
     cfg = c;
+    cur_scale = c.loss_scale;
+    overflow_guard = DT == MN_F16 && !(getenv("MN_OVERFLOW_GUARD") && atoi(getenv("MN_OVERFLOW_GUARD")) == 0);
     L = Layout(c.feat_dim);
     frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
     B = c.windows * frames;
@@ -475,6 +508,14 @@ struct Plan : PlanBase {
     hipMemcpyAsync(stem_colmap, cm.data(), 224 * 4, hipMemcpyHostToDevice, s);
     hipStreamSynchronize(s);  // cm is a host temporary
     stem.colmap = stem_colmap;
+    if (overflow_guard && !overflow_host) {
+      if (hipHostMalloc((void**)&overflow_host, 2 * sizeof(long long)) != hipSuccess) {
+        overflow_host = nullptr;
+        (void)hipGetLastError();
+      } else {
+        overflow_host[0] = overflow_host[1] = 0;
+      }
+    }
     build_repack_table(s);
     update_frozen(s);
     weights_dirty = true;
@@ -648,7 +689,7 @@ struct Plan : PlanBase {
   void run_criterion(const float* pred, const float* targ, float* loss, float* dpred, float* ds, hipStream_t s) {
     CriterionArgs a;
     a.mode = cfg.mode; a.N = cfg.windows; a.T = cfg.T; a.pred = pred; a.targ = targ; a.s = params + L.crit; a.loss = loss;
-    a.dpred = dpred; a.ds = ds; a.vos_out = nullptr; a.grad_scale = cfg.loss_scale;
+    a.dpred = dpred; a.ds = ds; a.vos_out = nullptr; a.grad_scale = cur_scale;
     hipLaunchKernelGGL(criterion_kernel, dim3(1), dim3(256), 0, s, a);
   }
   int loss_only(const float* pred, const float* targ, float* loss_out, hipStream_t s) override {
@@ -666,7 +707,7 @@ struct Plan : PlanBase {
   // self_gate: `gate` is relu(bn_u(y)) itself (a1 of a block, a0 of the stem): recomputed from y, not read
   void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s, bool self_gate = false) {
     launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
-                     grads + u.bp.beta, u.gy, u.accum_b, 1.f / cfg.loss_scale, s, nullptr,
+                     grads + u.bp.beta, u.gy, u.accum_b, 1.f / cur_scale, s, nullptr,
                      (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr, PoolGradSrc(), ACC_ROWS);
   }
   // bit 0: BatchNorm+ReLU+max-pool in one forward pass (-0.15 ms/step); bit 1: max-pool gradient gathered inside the
@@ -682,7 +723,7 @@ struct Plan : PlanBase {
   void conv_wgrad(Unit& u, const T* x, hipStream_t ws) {
     WgradArgs a;
     a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
-    a.alpha = 1.f / cfg.loss_scale; a.rows_per_split = 0;
+    a.alpha = 1.f / cur_scale; a.rows_per_split = 0;
     auto* tp = timer.begin(1, ws);
     // reduction splits (measured, tools/conv_bench.py): one round of 2 workgroups per CU for the wide layers (half
     // the atomic traffic of 1024), more for layer1 and the stem whose pixel dimension is 4-16x longer
@@ -765,7 +806,7 @@ struct Plan : PlanBase {
   }
   void head_backward(hipStream_t s) {
     int F = cfg.feat_dim;
-    float unscale = 1.f / cfg.loss_scale;
+    float unscale = 1.f / cur_scale;
     if (!grads_zeroed) hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, s);  // optim.learner.zero_grad()
     grads_zeroed = false;
     run_criterion(poses, cur_targets, cur_loss, dposes, grads + L.crit, s);
@@ -803,7 +844,7 @@ struct Plan : PlanBase {
       pg.idx = pool_idx; pg.gout = gp0; pg.H = H0; pg.W = W0; pg.Po = H1; pg.Qo = W1;
       launch_bn_bwd<T>((const T*)nullptr, (const T*)nullptr, (const T*)stem.y, stem.M, 64, params + stem.bp.gamma, stem.mean,
                        stem.invstd, grads + stem.bp.gamma, grads + stem.bp.beta, stem.gy, stem.accum_b,
-                       1.f / cfg.loss_scale, s, nullptr, params + stem.bp.beta, pg, ACC_ROWS);
+                       1.f / cur_scale, s, nullptr, params + stem.bp.beta, pg, ACC_ROWS);
     } else {
       hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s,
                          (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
@@ -827,6 +868,52 @@ struct Plan : PlanBase {
     return check_launch("backward_stage");
   }
 
+  // ---- inspection (mn_debug_tensor): activations / gradients of the last step by name ---------------------------
+  int debug_tensor(const char* name, void** ptr, int64_t* numel, int32_t* dtype) override {
+    const std::string n(name);
+    auto give = [&](const void* p, long count, int dt) {
+      *ptr = const_cast<void*>(p);
+      *numel = count;
+      *dtype = dt;
+      return 0;
+    };
+    const long n0 = (long)B * H0 * W0 * 64, n1 = (long)B * H1 * W1 * 64;
+    if (n == "xpad") return give(xpad, (long)B * Hp * Wp * 4, DT);
+    if (n == "stem.y") return give(stem.y, n0, DT);
+    if (n == "stem.gy") return give(stem.gy, n0, DT);
+    if (n == "p0") return give(p0, n1, DT);
+    if (n == "gp0") return give(gp0, n1, DT);
+    if (n == "pooled") return give(pooled, (long)B * 512, MN_F32);
+    if (n == "feat") return give(feat, (long)B * cfg.feat_dim, MN_F32);
+    if (n == "poses") return give(poses, (long)B * 6, MN_F32);
+    if (n == "dposes") return give(dposes, (long)B * 6, MN_F32);
+    if (n == "dz") return give(dz, (long)B * cfg.feat_dim, MN_F32);
+    if (n == "dpooled") return give(dpooled, (long)B * 512, MN_F32);
+    if (n.size() > 2 && n[0] == 'b') {  // "b<block>.<tensor>", blocks numbered 0..15 in network order
+      const size_t dot = n.find('.');
+      if (dot != std::string::npos) {
+        const int bi = atoi(n.substr(1, dot - 1).c_str());
+        const std::string t = n.substr(dot + 1);
+        if (bi >= 0 && bi < (int)blocks.size()) {
+          Block& k = blocks[bi];
+          const long no = k.u2.M * k.u2.cp.cout;
+          if (t == "y1") return give(k.u1.y, no, DT);
+          if (t == "a1") return give(k.a1, no, DT);
+          if (t == "y2") return give(k.u2.y, no, DT);
+          if (t == "out") return give(k.out, no, DT);
+          if (t == "gy1") return give(k.u1.gy, no, DT);
+          if (t == "ga1") return give(k.ga1, no, DT);
+          if (t == "gy2") return give(k.u2.gy, no, DT);
+          if (t == "gout") return give(k.gout, no, DT);
+          if (k.down && t == "yd") return give(k.ud.y, no, DT);
+          if (k.down && t == "zd") return give(k.zd, no, DT);
+          if (k.down && t == "gyd") return give(k.ud.gy, no, DT);
+        }
+      }
+    }
+    return fail("mn_debug_tensor: unknown tensor '" + n + "'");
+  }
+
   // ---- optimiser -----------------------------------------------------------------------------------
   // host-side effects of an optimiser step (also applied when the step was replayed from a graph)
   void after_optim_host() override {
@@ -840,18 +927,23 @@ struct Plan : PlanBase {
     return check_launch("sync_step");
   }
   int optim_step(float grad_mul, hipStream_t s) override {
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, step_dev, beta1, beta2, bc_dev);
-    if (max_grad_norm > 0.f) {
+    // squared gradient norm: for clip_grad_norm, and (fp16) as the overflow detector of this step
+    if (max_grad_norm > 0.f || overflow_guard) {
       hipMemsetAsync(sqnorm, 0, sizeof(double), s);
       hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(ew_grid(L.model_floats)), dim3(256), 0, s, (const float*)grads,
                          (long)L.model_floats, sqnorm);
     }
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, step_dev, beta1, beta2, bc_dev, (const double*)sqnorm,
+                       overflow_guard ? overflow_dev : (long long*)nullptr);
     AdamArgs a;
     a.p = params; a.g = grads; a.m = m1; a.v = m2; a.n = L.param_floats; a.n_clip = L.model_floats; a.lr = lr; a.wd = wd;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.bc1 = 1.f; a.bc2 = 1.f; a.bc_dev = bc_dev;
     a.grad_mul = grad_mul; a.max_norm = max_grad_norm; a.sqnorm = sqnorm; a.frozen = frozen; a.eps_mode = cfg.eps_mode;
+    a.skip = overflow_guard ? overflow_dev : nullptr;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(L.param_floats)), dim3(256), 0, s, a);
+    if (overflow_guard && overflow_host)
+      hipMemcpyAsync(overflow_host, overflow_dev, 2 * sizeof(long long), hipMemcpyDeviceToHost, s);
     return check_launch("optim_step");
   }
 };
@@ -866,7 +958,7 @@ static int validate(const mn_config* c) {
   if (!c) return fail("null config");
   if (c->mode < 0 || c->mode > 3) return fail("config: bad mode");
   if (c->dtype != MN_DTYPE_F32 && c->dtype != MN_DTYPE_F16) return fail("config: bad dtype");
-  if (c->windows < 1 || c->T < 1 || c->T > 4) return fail("config: windows >= 1 and 1 <= T <= 4 required");
+  if (c->windows < 1 || c->T < 1 || c->T > kMaxT) return fail("config: windows >= 1 and 1 <= T <= 8 required");
   if (c->mode == MN_MODE_POSENET && c->T != 1) return fail("config: PoseNet mode requires T = 1");
   if (c->mode >= MN_MODE_MAPNET && c->T < 2) return fail("config: MapNet modes require T >= 2");
   if (c->H < 32 || c->W < 32) return fail("config: image must be at least 32x32");
@@ -968,6 +1060,31 @@ extern "C" int mn_wait_loss(mn_handle* h) {
   }
   return 0;
 }
+extern "C" int mn_debug_tensor(mn_handle* h, const char* name, void** ptr, int64_t* numel, int32_t* dtype) {
+  MN_H(h);
+  if (!name || !ptr || !numel || !dtype) return fail("mn_debug_tensor: null argument");
+  return P.debug_tensor(name, ptr, numel, dtype);
+}
+extern "C" int mn_get_loss_scale(mn_handle* h, float* scale, int64_t* skipped_steps) {
+  MN_H(h);
+  if (scale) *scale = P.cur_scale;
+  if (skipped_steps) *skipped_steps = P.overflow_host ? (int64_t) * (volatile long long*)(P.overflow_host + 1) : 0;
+  return 0;
+}
+extern "C" int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval) {
+  MN_H(h);
+  if (!(scale > 0.f)) return fail("mn_set_loss_scale: scale must be positive");
+  if (P.cfg.dtype != MN_DTYPE_F16 && scale != 1.f) return fail("mn_set_loss_scale: fp32 plans do not scale the loss");
+  if (P.cur_scale != scale) P.hyper_version++;
+  P.cur_scale = scale;
+  P.scale_growth_interval = growth_interval;
+  P.clean_steps = 0;
+  if (P.overflow_host) {  // skips of steps still in flight belong to the old scale: do not halve the new one for them
+    hipDeviceSynchronize();
+    P.skipped_seen = *(volatile long long*)(P.overflow_host + 1);
+  }
+  return 0;
+}
 extern "C" int mn_set_input_u8(mn_handle* h, int enable, const float* mean, const float* std) {
   MN_H(h);
   if (enable && (!mean || !std)) return fail("mn_set_input_u8: mean and std (3 floats each, host memory) are required");
@@ -998,6 +1115,7 @@ extern "C" int mn_train_forward_loss(mn_handle* h, const void* images, const flo
   unsigned long long key = (unsigned long long)(uintptr_t)images * 31 + (unsigned long long)(uintptr_t)targets * 17 +
                            (unsigned long long)(uintptr_t)loss_out * 13 + (unsigned long long)(uintptr_t)poses_out;
   P.weights_dirty = true;  // a training forward always follows an optimiser step or a parameter load
+  P.poll_overflow();
   P.fwd_key = key;
   return P.run_segment(1, key, s, [&] { return P.forward_loss(images, targets, loss_out, poses_out, s); });
 }
@@ -1031,6 +1149,7 @@ extern "C" int mn_train_step(mn_handle* h, const void* images, const float* targ
   unsigned long long key = (unsigned long long)(uintptr_t)images * 31 + (unsigned long long)(uintptr_t)targets * 17 +
                            (unsigned long long)(uintptr_t)loss_out * 13 + (unsigned long long)(uintptr_t)poses_out;
   P.weights_dirty = true;  // a training step always follows an optimiser step or a parameter load
+  P.poll_overflow();
   int rc = P.run_segment(0, key, s, [&]() -> int {
     auto* tp = P.timer.begin(3, s);
     if (int e = P.forward_loss(images, targets, loss_out, poses_out, s)) return e;

@@ -36,12 +36,29 @@ struct AdamArgs {
   const unsigned char* frozen;  // optional per-element freeze mask for the tail [n_clip, n) (criterion scalars)
   int eps_mode;      // 0: torch>=1.0  denom = sqrt(v)/sqrt(bc2)+eps ; 1: torch 0.4.1  denom = sqrt(v)+eps
   const float* bc_dev;  // optional device copy of {bc1, bc2} (written by adam_prep_kernel); overrides bc1/bc2
+  const long long* skip = nullptr;  // optional overflow word (adam_prep_kernel): non-zero = leave everything untouched
 };
 
 // Advances the device-resident step counter and derives the bias corrections from it, so a captured
 // (hipGraph) training step needs no per-step host arguments.
-static __global__ void adam_prep_kernel(long long* step, float beta1, float beta2, float* bc) {
+// Overflow guard (fp16 steps, `overflow` non-null): the squared gradient norm is non-finite exactly when some
+// gradient element is (inf^2 = inf, NaN propagates) -- one fp16 activation gradient that overflowed reaches every
+// weight gradient below it.  Such a step must not touch the fp32 master weights or the Adam moments (the reference
+// trains in fp32 and cannot overflow; with clipping on, inf * coef(=0) would even turn into NaN): overflow[0] = 1 tells
+// adam_kernel to return, the step counter is not advanced, and overflow[1] counts the skipped steps (the host halves
+// the loss scale when it sees the count move, net.hip).
+static __global__ void adam_prep_kernel(long long* step, float beta1, float beta2, float* bc, const double* sqnorm,
+                                        long long* overflow) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (overflow) {
+      const double v = *sqnorm;
+      const bool bad = !(v == v) || v > 1.7e308 || v < -1.7e308;
+      overflow[0] = bad ? 1 : 0;
+      if (bad) {
+        overflow[1] += 1;
+        return;
+      }
+    }
     const long long t = *step + 1;
     *step = t;
     bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
@@ -50,6 +67,7 @@ static __global__ void adam_prep_kernel(long long* step, float beta1, float beta
 }
 
 static __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
+  if (a.skip && *a.skip) return;  // overflowed step: parameters, moments and step counter stay as they are
   float coef = 1.f;
   if (a.max_norm > 0.f) {
     float total = (float)sqrt(*a.sqnorm) * a.grad_mul;

@@ -124,7 +124,7 @@ class Engine:
         self._check_device()
         dtype = self.dtype or _default_dtype
         scale = self.loss_scale if self.loss_scale is not None else (_default_loss_scale if dtype == "fp16" else 1.0)
-        key = (mode, windows, T, H, W, dtype, scale)
+        key = (mode, windows, T, H, W, dtype, scale, self.eps_mode)
         p = self.plans.get(key)
         if p is None:
             self.ensure_opt_state()
@@ -157,6 +157,34 @@ class Engine:
 
     def params_touched(self):
         self.version += 1
+
+    # -- fp16 loss scaling / overflow bookkeeping (mn_get_loss_scale) ------------------------------------------
+    def loss_scale_state(self, sync=True):
+        """-> (scale the next step will use, training steps skipped because their gradients overflowed), summed over
+        this engine's plans; sync=True waits for the device first so the count is exact."""
+        if sync and self.params.is_cuda:
+            torch.cuda.synchronize(self.device)
+        scale, skipped = None, 0
+        for p in self.plans.values():
+            sc, sk = C.c_float(), C.c_int64()
+            self.lib.check(self.lib.get_loss_scale(p["handle"], C.byref(sc), C.byref(sk)))
+            scale = sc.value if scale is None else min(scale, sc.value)
+            skipped += sk.value
+        return scale, skipped
+
+    def effective_step(self):
+        """optimiser steps actually applied (Adam's `step`): attempts minus the steps skipped on overflow"""
+        return self.step_count - self.loss_scale_state()[1] if self.plans else self.step_count
+
+    def debug_tensor(self, plan, name):
+        """a named activation / gradient of the plan's work arena as a tensor VIEW (tests, tools/layer_error.py)"""
+        ptr_, n, dt = C.c_void_p(), C.c_int64(), C.c_int32()
+        self.lib.check(self.lib.debug_tensor(plan["handle"], name.encode(), C.byref(ptr_), C.byref(n), C.byref(dt)))
+        work = plan["work"]
+        off = ptr_.value - work.data_ptr()
+        es = 2 if dt.value == 1 else 4
+        assert 0 <= off and off + n.value * es <= work.numel()
+        return work[off: off + n.value * es].view(torch.float16 if dt.value == 1 else torch.float32)
 
     # -- calls --------------------------------------------------------------------------------------
     def set_input_u8(self, mean=None, std=None):

@@ -57,6 +57,7 @@ class FusedAdam:
         # a state that was loaded but has not reached the device yet (the optimiser meets its engine in the first
         # step_feedfwd) is returned as loaded: save -> load -> save without a step in between keeps the moments
         pend = getattr(self, "_pending", None)
+        step = eng.effective_step() if have else 0  # Adam's own count: fp16 steps skipped on overflow are not steps
         for g in self.param_groups:
             ids = []
             for p in g["params"]:
@@ -67,7 +68,7 @@ class FusedAdam:
                                       "exp_avg_sq": st["exp_avg_sq"].detach().clone().cpu()}
                 elif have:
                     m, v = self._moment_views(p)
-                    state[idx] = {"step": int(eng.step_count), "exp_avg": m.clone().contiguous(),
+                    state[idx] = {"step": int(step), "exp_avg": m.clone().contiguous(),
                                   "exp_avg_sq": v.clone().contiguous()}
                 ids.append(idx)
                 idx += 1

@@ -58,6 +58,8 @@ def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, tra
         n = data.shape[0]
         t = data.shape[1] if mode == 1 else data.shape[1] // 2
     H, W = engine.image_dims(data)
+    # the fused kernel indexes the target as [n][rows of this criterion][6]: a wrong layout must not reach the device
+    criterion.check_batch(n, data.shape[1] if mode != MODE_POSENET else 1, target)
     _bind(engine, criterion, optim)
     plan = engine.plan(mode, n, t, H, W)
     lr, wd, betas, eps = optim.learner.hyper()

@@ -138,6 +138,23 @@ int mn_train_backward_stage(mn_handle* h, int stage, void* stream);
 int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t* count); /* range in the grads arena */
 int mn_optim_step(mn_handle* h, float grad_mul, void* stream);
 
+/* fp16 loss scaling.  The reference trains in fp32 (common/train.py:351-359) and cannot overflow; the fp16 plan scales
+ * d(pred) by `scale` (mn_config.loss_scale initially) and divides it out where gradients enter the fp32 arena.  A step
+ * whose gradients contain inf/NaN is SKIPPED on the device (parameters, Adam moments and the Adam step counter stay
+ * untouched) and counted; the host halves the scale for each skipped step it has seen when the next step is enqueued
+ * (no synchronisation: it reacts one or two steps late, the device keeps skipping meanwhile) and doubles it after
+ * `growth_interval` clean steps (0 = never; default 2000, up to 65536).  mn_get_loss_scale reports the scale the next
+ * step will use and the number of skipped steps that have reached the host (synchronise the stream first for an exact
+ * count). */
+int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval);
+int mn_get_loss_scale(mn_handle* h, float* scale, int64_t* skipped_steps);
+
+/* Inspection for parity tooling (tests/, tools/layer_error.py): device pointer, element count and MN_DTYPE_* of a named
+ * tensor of the work arena as the last step left it.  Names: "xpad", "stem.y", "stem.gy", "p0", "gp0", "pooled", "feat",
+ * "poses", "dposes", "dz", "dpooled", and per residual block i = 0..15 "b<i>.y1 | a1 | y2 | out | gy1 | ga1 | gy2 | gout"
+ * (+ "yd", "zd", "gyd" for blocks with a projection); NHWC.  Read-only for the caller. */
+int mn_debug_tensor(mn_handle* h, const char* name, void** ptr, int64_t* numel, int32_t* dtype);
+
 /* parameters changed behind the library's back (load_state_dict): refresh compute copies */
 int mn_params_changed(mn_handle* h);
 

@@ -883,3 +883,193 @@ def check_pgo_properties(lib, dev, W=4096, N=7, fc=True, seed=3):
 def lib_error():
     from geomapnet_amd._binding import MapNetHipError
     return MapNetHipError
+
+
+# ---- NaN filter (models/posenet.py:28-34,50-51) with a REAL NaN cotangent ---------------------------------------------
+def check_nan_filter(lib, dev, dtype_name="fp32", N=2, H=64, W=85):
+    """MapNet++ step whose criterion emits NaN d(pred): with fc_wpqr = 0 every predicted log-quaternion is exactly zero,
+    consecutive relative rotations are the identity and qlog_t's backward is inf * 0.  With
+    filter_nans the reference zeroes the NaNs leaving fc_wpqr (grad of its input, weight, bias): the trunk then receives
+    the translation path only.  HIP vs the oracle (real autograd + hooks): d(pred) NaN pattern, every parameter gradient,
+    and -- without the filter -- NaN reaching the same parameters."""
+    _fresh()
+    import geomapnet_amd as G
+    G.set_compute_dtype(dtype_name)
+    out = {}
+    for filt in (True, False):
+        torch.manual_seed(7)
+        onet = oracle.MapNet(oracle.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False, filter_nans=filt))
+        with torch.no_grad():
+            onet.mapnet.fc_wpqr.weight.zero_()
+            onet.mapnet.fc_wpqr.bias.zero_()
+        net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, filter_nans=filt, _binding=lib))
+        net.load_state_dict(onet.state_dict())
+        if torch.device(dev).type == "cuda":
+            net.cuda()
+        x, t = oracle.make_batch("mapnet++", N, H, W, seed=7)
+        oc = oracle.MapNetOnlineCriterion(0.0, -3.0, 0.0, -3.0, True, True)
+        c = G.MapNetOnlineCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+        # lr = 0: the step leaves the weights alone, gradients stay inspectable on both sides
+        oopt = oracle.Optimizer([{"params": onet.parameters()}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}], "adam",
+                                base_lr=0.0, weight_decay=0.0)
+        opt = G.Optimizer([{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}], "adam",
+                          base_lr=0.0, weight_decay=0.0)
+        onet.train()
+        net.train()
+        lo, po = oracle.step_feedfwd(x, onet, False, t, oc, oopt, True)
+        l, p = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True)
+        assert float(po.detach()[..., 3:].abs().max()) == 0.0 and float(p[..., 3:].abs().max()) == 0.0
+        assert abs(l - lo) <= 1e-4 * max(1.0, abs(lo))
+        eng = net.mapnet._engine
+        plan = next(iter(eng.plans.values()))
+        dpred = eng.debug_tensor(plan, "dposes").cpu().view(N, -1, 6)
+        T = dpred.shape[1] // 2
+        assert torch.isnan(dpred[:, T:, 3:]).all(), "the criterion's NaN cotangent did not appear"
+        assert torch.isfinite(dpred[:, :T]).all() and torch.isfinite(dpred[:, T:, :3]).all()
+        og = {k: v.grad for k, v in onet.mapnet.named_parameters()}
+        worst, nan_names = 0.0, []
+        for e in eng.entries:
+            if e.is_buffer:
+                continue
+            name = e.name.decode()
+            g = _view(eng.grads(), e).cpu().double()
+            r = og[name].double()
+            if not torch.isfinite(r).all():
+                nan_names.append(name)
+                assert not torch.isfinite(g).all(), (name, "oracle gradient is non-finite, HIP gradient is finite")
+                continue
+            assert torch.isfinite(g).all(), (name, "HIP gradient non-finite where the oracle's is finite", filt)
+            if r.norm() < 1e-12:
+                assert g.norm() < 1e-9, (name, g.norm())
+            else:
+                worst = max(worst, ((g - r).norm() / r.norm()).item())
+        if filt:
+            assert not nan_names, nan_names
+            assert worst <= (2e-2 if dtype_name == "fp32" else 1e-1), worst
+            g_w = _view(eng.grads(), next(e for e in eng.entries if e.name.decode() == "fc_wpqr.weight")).cpu()
+            assert float(g_w.abs().max()) == 0.0  # NaN -> 0, as the hook does for the whole weight gradient
+        else:
+            assert "fc_wpqr.weight" in nan_names and "feature_extractor.conv1.weight" in nan_names, nan_names
+        out[filt] = (worst, len(nan_names))
+    return out
+
+
+# ---- fp16 overflow: the step is skipped on the device, the host lowers the loss scale -----------------------------------
+def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3):
+    """A loss scale far too large makes the fp16 activation gradients overflow: the step must leave parameters, Adam
+    moments and the Adam step counter untouched (no inf/NaN anywhere), be counted, and the scale must come down; with a
+    sane scale the next step is applied."""
+    _fresh()
+    import geomapnet_amd as G
+    G.set_compute_dtype("fp16", loss_scale=2.0 ** 60)
+    try:
+        onet, net = build_pair(lib, dev)
+        c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+        opt = G.Optimizer([{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}], "adam",
+                          base_lr=1e-3, weight_decay=5e-4)
+        net.train()
+        x, t = oracle.make_batch("mapnet", N, H, W, seed=7)
+        x, t = x.to(dev), t.to(dev)
+        eng = net.mapnet._engine
+        G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)
+        dev_sync(dev)
+        p0 = eng.params.clone()
+        scale, skipped = eng.loss_scale_state()
+        assert skipped == 1 and scale == 2.0 ** 60, (scale, skipped)
+        sd = net.state_dict()
+        assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype == torch.float32)
+        assert float(eng.opt_state[eng.n_params:].abs().max()) == 0.0  # moments untouched
+        assert not torch.isfinite(eng.grads()).all()                   # the overflow is in the gradients
+        for _ in range(more):
+            G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)
+        dev_sync(dev)
+        scale2, skipped2 = eng.loss_scale_state()
+        assert skipped2 == 1 + more and scale2 < scale, (scale2, skipped2)   # the host has seen skips and halved
+        assert torch.equal(eng.params[:-4], p0[:-4])
+        assert opt.learner.state_dict()["state"] == {} or int(opt.learner.state_dict()["state"][0]["step"]) == 0
+        plan = next(iter(eng.plans.values()))
+        lib.check(lib.set_loss_scale(plan["handle"], C.c_float(1024.0), 0))
+        G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)
+        dev_sync(dev)
+        assert eng.loss_scale_state() == (1024.0, 1 + more)
+        assert not torch.equal(eng.params[:-4], p0[:-4]) and torch.isfinite(eng.params).all()
+        assert int(opt.learner.state_dict()["state"][0]["step"]) == 1
+    finally:
+        G.set_compute_dtype("fp16", loss_scale=1024.0)
+
+
+# ---- BASELINE full-size parity against the oracle (both dtypes) ---------------------------------------------------------
+def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, lr=1e-4, wd=5e-4, filter_nans=False,
+                           fp32_loss_rtol=1e-4, fp32_pose_atol=1e-3):
+    """One training step of a BASELINE.json configuration at FULL size: oracle (CPU fp32) once, HIP in fp32 (asserted to
+    the north-star bar: 1e-4 on loss relative to max(1,|loss|), 1e-3 on pose) and in fp16 (recorded; asserted only to
+    stay within the documented envelope).  Returns the measurements."""
+    _fresh()
+    import time
+    import geomapnet_amd as G
+    torch.manual_seed(7)
+    onet = oracle.MapNet(oracle.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False, filter_nans=filter_nans))
+    sd0 = {k: v.clone() for k, v in onet.state_dict().items()}
+    x, t = oracle.make_batch(mode, N, H, W, seed=7)
+    if mode == "posenet":
+        omodel = onet.mapnet
+        oc = oracle.PoseNetCriterion(0.0, -3.0, True)
+        og = [{"params": omodel.parameters()}, {"params": [oc.sax, oc.saq]}]
+    else:
+        omodel = onet
+        oc = (oracle.MapNetCriterion(0.0, -3.0, 0.0, -3.0, True, True) if mode == "mapnet"
+              else oracle.MapNetOnlineCriterion(0.0, -3.0, 0.0, -3.0, True, True))
+        og = [{"params": omodel.parameters()}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}]
+    oopt = oracle.Optimizer(og, "adam", base_lr=lr, weight_decay=wd)
+    omodel.train()
+    t0 = time.time()
+    lo, po = oracle.step_feedfwd(x, omodel, False, t, oc, oopt, True, max_grad_norm)
+    oracle_s = time.time() - t0
+    po = po.detach()
+    ograd = {k: v.grad.clone() for k, v in onet.mapnet.named_parameters()}
+    frames = x.shape[1] if x.dim() == 5 else 1
+    rec = {"mode": mode, "windows": N, "images": N * frames, "H": H, "W": W, "oracle_step_s": round(oracle_s, 1),
+           "loss_oracle": lo, "pose_scale": po.abs().max().item()}
+    del omodel, oopt
+    for dtype_name in ("fp32", "fp16"):
+        G.set_compute_dtype(dtype_name)
+        net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, filter_nans=filter_nans, _binding=lib))
+        net.load_state_dict(sd0)
+        if torch.device(dev).type == "cuda":
+            net.cuda()
+        if mode == "posenet":
+            model = net.mapnet
+            c = G.PoseNetCriterion(sax=0.0, saq=-3.0, learn_beta=True, _binding=lib)
+            gg = [{"params": model.parameters()}, {"params": [c.sax, c.saq]}]
+        else:
+            model = net
+            c = (G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+                 if mode == "mapnet" else
+                 G.MapNetOnlineCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib))
+            gg = [{"params": model.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}]
+        opt = G.Optimizer(gg, "adam", base_lr=lr, weight_decay=wd)
+        model.train()
+        l, p = G.step_feedfwd(x.to(dev), model, dev != "cpu", t.to(dev), c, opt, True, max_grad_norm)
+        d = p.cpu() - po
+        eng = net.mapnet._engine
+        num = den = 0.0
+        worst = 0.0
+        for e in eng.entries:
+            if e.is_buffer:
+                continue
+            g = _view(eng.grads(), e).cpu().double()
+            r = ograd[e.name.decode()].double()
+            if max_grad_norm > 0.0:
+                continue  # the oracle's stored gradients are already clipped, the arena's are not
+            num += (g - r).pow(2).sum().item()
+            den += r.pow(2).sum().item()
+            if r.norm() > 1e-8:
+                worst = max(worst, ((g - r).norm() / r.norm()).item())
+        rec[dtype_name] = {"loss": l, "loss_rel": abs(l - lo) / max(1.0, abs(lo)), "pose_abs_max": d.abs().max().item(),
+                           "pose_abs_rms": d.pow(2).mean().sqrt().item(),
+                           "grad_l2_rel_all": (num / den) ** 0.5 if den > 0 else None, "grad_l2_rel_worst_tensor": worst}
+        del net, model, opt, c
+    assert rec["fp32"]["loss_rel"] <= fp32_loss_rtol, rec
+    assert rec["fp32"]["pose_abs_max"] <= fp32_pose_atol * max(1.0, rec["pose_scale"]), rec
+    assert rec["fp16"]["loss_rel"] <= 5e-3 and rec["fp16"]["pose_abs_max"] <= 5e-2 * max(1.0, rec["pose_scale"]), rec
+    return rec

@@ -90,6 +90,14 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
   return hipSuccess;
 }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) {
+  *p = calloc(1, n);
+  return *p ? hipSuccess : hipErrorUnknown;
+}
+inline hipError_t hipHostFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);

@@ -47,3 +47,32 @@ def test_mapnet_train_step_fp16_close(lib):
     # individually checked in test_emu_kernels.py
     checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=40, W=53, steps=1, loss_rtol=1e-2, pose_atol=2e-2,
                             grad_l2_rtol=None)
+
+
+@pytest.mark.slow
+def test_nan_filter_with_a_nan_cotangent(lib):
+    """models/posenet.py:28-34 on the kernel path: the criterion really emits NaN d(pred) (identical consecutive
+    rotations), compared with the oracle's autograd + hooks, with and without the filter"""
+    checks.check_nan_filter(lib, DEV, "fp32", N=1, H=32, W=40)
+
+
+@pytest.mark.slow
+def test_fp16_overflow_skips_the_step_and_lowers_the_scale(lib):
+    checks.check_overflow_skip(lib, DEV, N=1, H=32, W=40, more=2)
+
+
+def test_training_target_layout_is_validated_before_launch(lib):
+    """a target of the wrong layout (MF batch handed to the online criterion, wrong window count) must raise on the host:
+    the fused kernel would index it out of bounds"""
+    import torch
+    import geomapnet_amd as G
+    import oracle
+    G.set_compute_dtype("fp32")
+    net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, _binding=lib))
+    net.train()
+    x, t = oracle.make_batch("mapnet", 1, 32, 40)
+    for crit, targ in ((G.MapNetOnlineCriterion(_binding=lib), t), (G.MapNetCriterion(_binding=lib), torch.cat((t, t), 0)),
+                       (G.MapNetCriterion(_binding=lib), t[:, :2])):
+        opt = G.Optimizer([{"params": net.parameters()}], "adam", base_lr=1e-4, weight_decay=0.0)
+        with pytest.raises(ValueError):
+            G.step_feedfwd(x, net, False, targ, crit, opt, True)

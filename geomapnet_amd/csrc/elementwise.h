@@ -114,18 +114,16 @@ struct BnParams {
   float eps, momentum;
 };
 
-// Statistics -> per-channel (scale, shift) in the prologue of every workgroup (C <= 512 values, from the
-// fp64 accumulators), then out = [relu]( y * scale[c] + shift[c] [+ res] ), one 16-byte piece per lane.
-// Workgroup 0 also publishes mean / invstd (needed by the backward pass) and updates the running stats.
+// Statistics -> per-channel (scale, shift): ONE small launch per BatchNorm (bn_finalize_fwd_kernel) turns the fp64
+// accumulator rows into coef[0][c] = gamma * invstd, coef[1][c] = beta - mean * scale, publishes mean / invstd for the
+// backward pass and updates the running statistics; the streaming kernels below only load those two floats per channel.
+// (Round 1 derived them in the prologue of every workgroup of the apply kernel: 16 fp64 loads per channel in each of
+// up to 4096 workgroups -- for the late layers, whose tensors are 17-34 MB, that prologue was as long as the streaming.)
 // The accumulators are read-only here; the caller zeroes them before the next accumulation.
-template <typename T>
-static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, const double* __restrict__ accum,
-                                                        double count, BnParams p, int training,
-                                                        const T* __restrict__ res, T* __restrict__ out, long npieces,
-                                                        int C, int relu, int accum_rows) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  __shared__ float s_scale[512], s_shift[512];
-  for (int c = threadIdx.x; c < C; c += 256) {
+static __global__ void __launch_bounds__(256) bn_finalize_fwd_kernel(const double* __restrict__ accum, double count, BnParams p,
+                                                                     int training, float* __restrict__ coef, int C,
+                                                                     int accum_rows) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
     float mean, var;
     double unbiased = 0;
     if (training) {
@@ -146,17 +144,28 @@ static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restric
     }
     const float invstd = 1.0f / sqrtf(var + p.eps);
     const float sc = p.gamma[c] * invstd;
-    s_scale[c] = sc;
-    s_shift[c] = p.beta[c] - mean * sc;
-    if (blockIdx.x == 0) {
-      p.mean[c] = mean;
-      p.invstd[c] = invstd;
-      if (training) {
-        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
-        p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
-        if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
-      }
+    coef[c] = sc;
+    coef[C + c] = p.beta[c] - mean * sc;
+    p.mean[c] = mean;
+    p.invstd[c] = invstd;
+    if (training) {
+      p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+      p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+      if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
     }
+  }
+}
+
+// out = [relu]( y * scale[c] + shift[c] [+ res] ), one 16-byte piece per lane
+template <typename T>
+static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ coef,
+                                                        const T* __restrict__ res, T* __restrict__ out, long npieces,
+                                                        int C, int relu) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  __shared__ float s_scale[512], s_shift[512];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    s_scale[c] = coef[c];
+    s_shift[c] = coef[C + c];
   }
   __syncthreads();
   const int cpr = C / VEC;
@@ -180,44 +189,14 @@ static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restric
 // never written.  Values are rounded to T before the comparison so the routing (first maximum) is the one the
 // two-pass form (bn_apply then maxpool_fwd) takes.
 template <typename T>
-static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __restrict__ y, const double* __restrict__ accum,
-                                                               double count, BnParams p, int training, T* __restrict__ out,
-                                                               unsigned char* __restrict__ idx, int B, int H, int W, int C,
-                                                               int Po, int Qo, int accum_rows) {
+static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ coef,
+                                                               T* __restrict__ out, unsigned char* __restrict__ idx, int B,
+                                                               int H, int W, int C, int Po, int Qo) {
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ float s_scale[512], s_shift[512];
   for (int c = threadIdx.x; c < C; c += 256) {
-    float mean, var;
-    double unbiased = 0;
-    if (training) {
-      double sa = 0, sb = 0;  // accum: [accum_rows][2][C]
-      for (int r = 0; r < accum_rows; ++r) {
-        sa += accum[(long)r * 2 * C + c];
-        sb += accum[(long)r * 2 * C + C + c];
-      }
-      double m = sa / count;
-      double v = sb / count - m * m;
-      if (v < 0) v = 0;
-      mean = (float)m;
-      var = (float)v;
-      unbiased = count > 1 ? v * count / (count - 1) : v;
-    } else {
-      mean = p.running_mean[c];
-      var = p.running_var[c];
-    }
-    const float invstd = 1.0f / sqrtf(var + p.eps);
-    const float sc = p.gamma[c] * invstd;
-    s_scale[c] = sc;
-    s_shift[c] = p.beta[c] - mean * sc;
-    if (blockIdx.x == 0) {
-      p.mean[c] = mean;
-      p.invstd[c] = invstd;
-      if (training) {
-        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
-        p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
-        if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
-      }
-    }
+    s_scale[c] = coef[c];
+    s_shift[c] = coef[C + c];
   }
   __syncthreads();
   const int cpr = C / VEC;
@@ -359,36 +338,49 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
   }
 }
 
-// apply: gy = k1 * (gm - mg - xhat * mgx) with k1 = gamma*invstd, mg = sum(gm)/M, mgx = sum(gm*xhat)/M derived
-// from the fp64 accumulators in every workgroup's prologue; workgroup 0 adds dgamma / dbeta (times
-// grad_unscale = 1/loss_scale) into the gradient arena.
-template <typename T>
-static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ gate,
-                                                            const T* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                            const double* __restrict__ accum, double count,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float grad_unscale, T* __restrict__ gy, long npieces, int C,
-                                                            const float* __restrict__ sg_beta, PoolGradSrc pg, int accum_rows,
-                                                            int reverse) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512], s_sh[512];
-  for (int c = threadIdx.x; c < C; c += 256) {
+// finalize (one small launch between reduce and apply): coef[0][c] = k1 = gamma*invstd, coef[1][c] = mg = sum(gm)/M,
+// coef[2][c] = mgx = sum(gm*xhat)/M, coef[3][c] = shift of the self-gate (only with sg_beta), from the fp64 accumulator
+// rows; adds dgamma / dbeta (times grad_unscale = 1/loss_scale) into the gradient arena.
+static __global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const double* __restrict__ accum, double count,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                     float grad_unscale, const float* __restrict__ sg_beta,
+                                                                     float* __restrict__ coef, int C, int accum_rows) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
     double sg = 0, sgx = 0;  // accum: [accum_rows][2][C]
     for (int r = 0; r < accum_rows; ++r) {
       sg += accum[(long)r * 2 * C + c];
       sgx += accum[(long)r * 2 * C + C + c];
     }
-    s_k1[c] = gamma[c] * invstd[c];
-    s_sh[c] = sg_beta ? sg_beta[c] - mean[c] * (gamma[c] * invstd[c]) : 0.f;
-    s_mg[c] = (float)(sg / count);
-    s_mgx[c] = (float)(sgx / count);
+    const float k1 = gamma[c] * invstd[c];
+    coef[c] = k1;
+    coef[C + c] = (float)(sg / count);
+    coef[2 * C + c] = (float)(sgx / count);
+    if (sg_beta) coef[3 * C + c] = sg_beta[c] - mean[c] * k1;
+    dgamma[c] += (float)(sgx * grad_unscale);
+    dbeta[c] += (float)(sg * grad_unscale);
+  }
+}
+
+// apply: gy = k1 * (gm - mg - xhat * mgx)
+template <typename T>
+static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ gate,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                            T* __restrict__ gy, long npieces, int C, int self_gate,
+                                                            PoolGradSrc pg, int reverse) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512], s_sh[512];
+  const bool sg_beta = self_gate != 0;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    s_k1[c] = coef[c];
+    s_mg[c] = coef[C + c];
+    s_mgx[c] = coef[2 * C + c];
+    s_sh[c] = sg_beta ? coef[3 * C + c] : 0.f;
     s_mean[c] = mean[c];
     s_is[c] = invstd[c];
-    if (blockIdx.x == 0) {
-      dgamma[c] += (float)(sgx * grad_unscale);
-      dbeta[c] += (float)(sg * grad_unscale);
-    }
   }
   __syncthreads();
   const int cpr = C / VEC;
@@ -468,40 +460,37 @@ static __global__ void __launch_bounds__(256) bn_fwd_stats_kernel(const T* __res
   }
 }
 
-// BatchNorm backward = reduce -> apply.  accum: [2][C] doubles, zero on entry (left holding the sums).
+// BatchNorm backward = reduce -> finalize -> apply.  accum: [accum_rows][2][C] doubles, zero on entry (left holding the
+// sums); coef: [4][C] floats of scratch ([3][C] without the self gate).
 template <typename T>
 inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, const float* gamma, const float* mean,
-                          const float* invstd, float* dgamma, float* dbeta, T* gy, double* accum, float grad_unscale,
-                          hipStream_t s, float* partial = nullptr, const float* self_gate_beta = nullptr,
+                          const float* invstd, float* dgamma, float* dbeta, T* gy, double* accum, float* coef,
+                          float grad_unscale, hipStream_t s, const float* self_gate_beta = nullptr,
                           PoolGradSrc pg = PoolGradSrc(), int accum_rows = 1) {
-  // accum_rows > 1: the reduction adds straight into accum[accum_rows][2][C] (fp64 atomics) and `partial` is unused
   // self_gate_beta: the gradient g is taken w.r.t. relu(bn(y)) of THIS BatchNorm; the ReLU gate is recomputed
   // from y and `gate` is not read
   constexpr int VEC = ElemTraits<T>::VEC;
   const float* sg_gamma = self_gate_beta ? gamma : nullptr;
   if (self_gate_beta) gate = nullptr;
-  // ~4096 workgroups: the reduction is HBM-bound and needs the whole chip.  (At B = 192 that is ONE loop iteration per
-  // workgroup for layers 3-4 -- 16-32 rows -- so the parameter loads, the LDS reduction and the 2 x C atomics of every
-  // workgroup weigh as much as its loads; MN_BN_REDUCE_BLOCKS is the knob to time fatter workgroups with.)
+  // ~1024 workgroups (4 per CU): the reduction is HBM-bound and needs the whole chip, but every workgroup ends with an LDS
+  // reduction and 2 x C fp64 atomics -- at 4096 workgroups (round 1) layers 3-4 did ONE loop iteration per workgroup and
+  // that epilogue weighed as much as the loads (MN_BN_REDUCE_BLOCKS: 4096 -> 1024 = -1.2 % step time, same-box A/B)
   static const long target = getenv("MN_BN_REDUCE_BLOCKS") && atol(getenv("MN_BN_REDUCE_BLOCKS")) > 0
-                                 ? atol(getenv("MN_BN_REDUCE_BLOCKS")) : 4096;
+                                 ? atol(getenv("MN_BN_REDUCE_BLOCKS")) : 1024;
   const int rlanes = 256 / (C / VEC);
   long rows = (M + target - 1) / target;
   rows = ((rows + rlanes - 1) / rlanes) * rlanes;
   if (rows < 4L * rlanes) rows = 4L * rlanes;
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
-  if (accum_rows > 1) partial = nullptr;
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
-                     rows_per_block, partial, sg_gamma, self_gate_beta, pg, accum_rows);
-  if (partial)
-    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(nblk, 64), cdiv(C, 64)), dim3(256), 0, s,
-                       (const float*)partial, nblk, C, accum, 64);
+                     rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)accum, (double)M, gamma, mean,
+                     invstd, dgamma, dbeta, grad_unscale, self_gate_beta, coef, C, accum_rows);
   long np = M * C / VEC;
   static const int reverse = getenv("MN_BN_BWD_REVERSE") ? atoi(getenv("MN_BN_BWD_REVERSE")) : 0;
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd, gamma,
-                     (const double*)accum, (double)M, dgamma, dbeta, grad_unscale, gy, np, C, self_gate_beta, pg, accum_rows,
-                     reverse);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
+                     (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg, reverse);
 }
 
 // ---- global average pool --------------------------------------------------------------------------

@@ -297,6 +297,7 @@ struct Plan : PlanBase {
     T* y = nullptr;   // raw conv output [M][Cout]
     T* gy = nullptr;  // its gradient
     float *mean, *invstd;
+    float *coef_f, *coef_b;  // per-channel coefficients of the forward apply [2][C] / backward apply [4][C] (finalize kernels)
     double *accum_f, *accum_b;  // fp64 sums of the forward statistics / backward reductions, [ACC_ROWS][2][C] each
     int ldw;           // row pitch of the master weight gradient
     const int* colmap = nullptr;
@@ -365,6 +366,8 @@ struct Plan : PlanBase {
       u.gy = (T*)A((size_t)u.M * C * sizeof(T));
       u.mean = (float*)A(C * 4);
       u.invstd = (float*)A(C * 4);
+      u.coef_f = (float*)A(2 * C * 4);
+      u.coef_b = (float*)A(4 * C * 4);
       u.accum_f = acc_cursor;
       u.accum_b = acc_cursor ? acc_cursor + (size_t)ACC_ROWS * 2 * C : nullptr;
       if (acc_cursor) acc_cursor += (size_t)ACC_ROWS * 4 * C;
@@ -612,10 +615,15 @@ struct Plan : PlanBase {
   // layer1's 64-channel 3x3 convolutions (forward and data gradient) run from an LDS-resident input halo (halo.h)
   bool use_halo = DT == MN_F16 && !(getenv("MN_HALO") && atoi(getenv("MN_HALO")) == 0);
   bool halo_path(const GatherGeom& g) const { return use_halo && conv_halo_applies(g); }
+  void bn_finalize(Unit& u, hipStream_t s) {  // statistics -> (scale, shift), mean / invstd, running statistics
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(u.cp.cout, 256)), dim3(256), 0, s, (const double*)u.accum_f, (double)u.M,
+                       bn_params(u), cur_training, u.coef_f, u.cp.cout, ACC_ROWS);
+  }
   void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s) {
     long np = u.M * u.cp.cout / VEC;
-    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const double*)u.accum_f,
-                       (double)u.M, bn_params(u), cur_training, res, out, np, u.cp.cout, relu, ACC_ROWS);
+    bn_finalize(u, s);
+    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const float*)u.coef_f, res, out,
+                       np, u.cp.cout, relu);
   }
 
   int forward(const void* images, float* poses_out, int training, hipStream_t s) override {
@@ -644,9 +652,9 @@ struct Plan : PlanBase {
     }
     conv_bn_stats(stem, xpad, training, s);
     if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
+      bn_finalize(stem, s);
       hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
-                         (const T*)stem.y, (const double*)stem.accum_f, (double)stem.M, bn_params(stem), cur_training, p0,
-                         pool_idx, B, H0, W0, 64, H1, W1, ACC_ROWS);
+                         (const T*)stem.y, (const float*)stem.coef_f, p0, pool_idx, B, H0, W0, 64, H1, W1);
     } else {
       bn_act(stem, nullptr, 1, a0, s);
       hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
@@ -707,7 +715,7 @@ struct Plan : PlanBase {
   // self_gate: `gate` is relu(bn_u(y)) itself (a1 of a block, a0 of the stem): recomputed from y, not read
   void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s, bool self_gate = false) {
     launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
-                     grads + u.bp.beta, u.gy, u.accum_b, 1.f / cur_scale, s, nullptr,
+                     grads + u.bp.beta, u.gy, u.accum_b, u.coef_b, 1.f / cur_scale, s,
                      (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr, PoolGradSrc(), ACC_ROWS);
   }
   // bit 0: BatchNorm+ReLU+max-pool in one forward pass (-0.15 ms/step); bit 1: max-pool gradient gathered inside the
@@ -843,8 +851,8 @@ struct Plan : PlanBase {
       PoolGradSrc pg;
       pg.idx = pool_idx; pg.gout = gp0; pg.H = H0; pg.W = W0; pg.Po = H1; pg.Qo = W1;
       launch_bn_bwd<T>((const T*)nullptr, (const T*)nullptr, (const T*)stem.y, stem.M, 64, params + stem.bp.gamma, stem.mean,
-                       stem.invstd, grads + stem.bp.gamma, grads + stem.bp.beta, stem.gy, stem.accum_b,
-                       1.f / cur_scale, s, nullptr, params + stem.bp.beta, pg, ACC_ROWS);
+                       stem.invstd, grads + stem.bp.gamma, grads + stem.bp.beta, stem.gy, stem.accum_b, stem.coef_b,
+                       1.f / cur_scale, s, params + stem.bp.beta, pg, ACC_ROWS);
     } else {
       hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s,
                          (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);

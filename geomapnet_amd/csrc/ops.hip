@@ -222,8 +222,10 @@ static int bn_train_fwd_t(const void* y, int64_t M, int C, const float* gamma, c
   p.gamma = gamma; p.beta = beta; p.running_mean = running_mean; p.running_var = running_var;
   p.num_batches_tracked = nullptr; p.mean = mean; p.invstd = invstd; p.eps = eps; p.momentum = momentum;
   long np = M * C / ElemTraits<T>::VEC;
-  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)y, (const double*)accum,
-                     (double)M, p, 1, (const T*)res, (T*)out, np, C, relu, 1);
+  float* coef = reinterpret_cast<float*>(accum + 2 * C);  // [2][C] floats behind the accumulators
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)accum, (double)M, p, 1, coef, C, 1);
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)y, (const float*)coef, (const T*)res,
+                     (T*)out, np, C, relu);
   return check_launch("bn_train_fwd");
 }
 
@@ -242,9 +244,9 @@ template <typename T>
 static int bn_bwd_t(const void* g, const void* gate, const void* y, int64_t M, int C, const float* gamma, const float* mean,
                     const float* invstd, float* dgamma, float* dbeta, void* gy, float* coef, double* accum,
                     float grad_unscale, hipStream_t s) {
-  (void)coef;
+  if (!coef) return fail("bn_bwd: coef_scratch (3*C floats) is required");
   launch_bn_bwd<T>((const T*)g, (const T*)gate, (const T*)y, (long)M, C, gamma, mean, invstd, dgamma, dbeta, (T*)gy, accum,
-                   grad_unscale, s);
+                   coef, grad_unscale, s);
   hipMemsetAsync(accum, 0, 2 * C * sizeof(double), s);  // hand the scratch back zeroed
   return check_launch("bn_bwd");
 }

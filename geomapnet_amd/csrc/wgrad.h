@@ -512,9 +512,9 @@ struct WgradDma<half> {
     const bool fast = allow_fast && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&
                       g.R * g.S <= 16 && g.P * g.Q <= WG_TBL && g.P * g.Q >= BKM && g.C % 8 == 0 &&
                       (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l;
-    // MN_WGRAD_TR_ASM=1: transpose reads from inline assembly with hand-placed waits (ASMRD above) for the stride-1 3x3
-    // layers; off until it has been race-screened and timed on the GPU
-    static const bool tr_asm = getenv("MN_WGRAD_TR_ASM") && atoi(getenv("MN_WGRAD_TR_ASM")) != 0;
+    // transpose reads from inline assembly with hand-placed waits (ASMRD above); measured on MI355X (round 2): layer1
+    // 189 -> 155 us, layer2 140 -> 122, layer3 144 -> 124, layer4 129 -> 117; MN_WGRAD_TR_ASM=0 restores the builtin reads
+    static const bool tr_asm = !(getenv("MN_WGRAD_TR_ASM") && atoi(getenv("MN_WGRAD_TR_ASM")) == 0);
     {
       if (fast && tr_asm) {
         if (bmo == 64 && bno == 64)
@@ -563,9 +563,21 @@ struct WgradDma<half> {
   }
 };
 
+// wgrad_fused.h: 3x3 stride-1 fp16 layers with the nine taps of a channel tile accumulated from one LDS-resident pass
+// over the pixels (MN_WGRAD_FUSED=0 restores the plain GEMM form below for them)
+inline bool wgrad_fused_applies(const WgradArgs& a);
+inline void launch_wgrad_fused(const WgradArgs& a, int target_blocks, hipStream_t stream);
+
 template <typename T>
 inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, const void* zero_page = nullptr) {
   const GatherGeom& g = a.g;
+  if constexpr (ElemTraits<T>::DTYPE == MN_F16) {
+    static const bool fused = !(getenv("MN_WGRAD_FUSED") && atoi(getenv("MN_WGRAD_FUSED")) == 0);
+    if (fused && wgrad_fused_applies(a)) {
+      launch_wgrad_fused(a, target_blocks, stream);
+      return;
+    }
+  }
   const bool narrow_n = g.N <= 64, narrow_k = g.K <= 64 || (g.K % 128 != 0 && g.K < 256);
   int bmo = narrow_n ? 64 : 128, bno = narrow_k ? 64 : 128;
   int tiles = cdiv(g.N, bmo) * cdiv(g.K, bno);
@@ -592,3 +604,5 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
 }
 
 }  // namespace mn
+
+#include "wgrad_fused.h"

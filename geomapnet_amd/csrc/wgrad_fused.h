@@ -1,0 +1,247 @@
+// Tap-fused weight gradient of 3x3 stride-1 "same" convolutions (fp16 operands, fp32 accumulate): what autograd
+// computes for conv2d's weight under loss.backward() (/root/reference/common/train.py:351-355).
+//
+//   dW[n][tap][c] += alpha * sum_m dY[m][n] * X[m + shift(tap)][c] * inside(m, tap)
+//
+// wgrad.h treats this as a plain TN GEMM with K = 9*C columns: a 128 x 128 output tile moves 16 KB through LDS-DMA per
+// 32 pixels, 62 B/clk/CU at full matrix-core rate against the ~15-20 B/clk/CU that path sustains -- the launches sit at
+// 18-23 % of the MFMA peak, DMA-bound.  But the nine "columns blocks" of one channel tile are the SAME pixels, shifted.
+// Here a workgroup owns dW[64 n][9 taps][64 c] -- 36 accumulator tiles of 32 x 32 over 4 waves (144 registers each) --
+// and walks a range of pixels once: per 32 pixels it fetches 32 x 128 B of dY and 32 x 128 B of X (8 KB for 36 864 x 32
+// MACs: 4.5x fewer bytes per MAC), and the nine taps read their B fragments from the same LDS-resident X rows at nine
+// row offsets.
+//
+// Border handling without masks: pixels are enumerated in a PADDED order -- one zero column after every image row, one
+// zero row after every image: j = (b (P+1) + p) (Q+1) + q, real iff p < P and q < Q.  In that order tap (dh, dw) is the
+// pure shift dh (Q+1) + dw, a neighbour outside the image IS a padding position, and padding positions are zero-filled
+// by the buffer bounds check of the DMA (all-ones offset), for X and for dY alike.  Cost: (1 + 1/P)(1 + 1/Q) - 1 extra
+// MACs (2.7 % on layer1, 22 % on layer4's 8 x 11 maps).
+//
+// X lives in a ring of `ring` LDS rows (row = one position, 64 channels = 128 B, 16-byte pieces XOR-swizzled with
+// row & 3 like wgrad.h so the four rows of a transpose read fall in distinct bank groups): step s reads ring rows
+// [32 s + Gpad + shift, + 32) for each tap while the DMA of step s+1 lands 32 new rows right behind the live window
+// (ring = 2*32 + 2*Gpad rows, Gpad = Q + 2 rounded up to 16).  Fragments come from ds_read_b64_tr_b16 issued from inline
+// assembly with counted lgkmcnt waits (hipcc drains vmcnt(0) in front of the builtin while an LDS-DMA is in flight,
+// wgrad.h); the reads of tap t+1 are in flight under the MFMA of tap t.  A tap window that wraps around the end of the
+// ring (one step in ring/32 per tap) takes a slower path that wraps every row address.
+#pragma once
+#include "wgrad.h"  // (included from the end of wgrad.h)
+
+namespace mn {
+
+struct WgradFusedArgs {
+  const half* dY;  // [M][ldy], M = B*P*Q
+  const half* X;   // [B][P][Q][C]
+  float* dW;       // [N][ldw] fp32, column (tap*C + c), accumulated atomically
+  int ldy, ldw;
+  int B, P, Q, C, N;
+  int Qp;       // Q + 1
+  int J;        // B * (P+1) * (Q+1) padded positions
+  int chunk;    // positions per workgroup (multiple of the step)
+  int nchunks;  // workgroups per (n tile, c tile) pair
+  int tiles_n, tiles_c;
+  int Gpad;     // halo rows kept on each side of the live window (>= Q + 2, multiple of 16)
+  int ring;     // LDS rows of the X ring = 2*BKM + 2*Gpad
+  FastDiv dq, dp;  // divisors Q+1 and P+1
+  float alpha;
+};
+
+constexpr int WGF_RING_MAX = 320;  // rows; bounds the image width (Gpad <= 128 -> Q <= 126)
+
+template <int BKM>
+static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedArgs a) {
+  static_assert(BKM == 32, "one DMA pass of 256 threads per operand and step");
+  constexpr int ROWH = 64;                 // halves per LDS row (64 channels / 64 output channels)
+  constexpr int TILE_Y = BKM * ROWH;       // halves
+  // ONE LDS object: [2 dY tiles][X ring]
+  __shared__ half smem[2 * TILE_Y + WGF_RING_MAX * ROWH] __attribute__((aligned(16)));
+  half* ring = &smem[2 * TILE_Y];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wave >> 1, wc = wave & 1;  // 32-row block of the 64 output channels, 32-column block of the 64 inputs
+  // logical id = (chunk, pair): the pairs of one pixel range are adjacent, i.e. on one XCD, and share its L2 lines
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int pairs = a.tiles_n * a.tiles_c;
+  const int ci = logical / pairs, pr = logical - ci * pairs;
+  const int n0 = (pr / a.tiles_c) * 64, c0 = (pr % a.tiles_c) * 64;
+  const int j0 = ci * a.chunk;
+  const int j1 = min(a.J, j0 + a.chunk);
+  const int nsteps = (j1 - j0 + BKM - 1) / BKM;
+  const int Gpad = a.Gpad, RING = a.ring;
+
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dY, (long)a.B * a.P * a.Q * a.ldy * 2L);
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X, (long)a.B * a.P * a.Q * a.C * 2L);
+
+  // DMA role of this thread: row t/8 of a 32-row block, 16-byte slot t%8; LDS slot s of row r holds source piece
+  // s ^ swz(r), and every block starts at a multiple of 32 rows, so the source piece is fixed per thread
+  const int drow = t >> 3, dslot = t & 7;
+  const int dpiece = dslot ^ wg_swz<8>(drow);
+  const unsigned ycol = (unsigned)((n0 + dpiece * 8) * 2), xcol = (unsigned)((c0 + dpiece * 8) * 2);
+  const bool y_ok = n0 + dpiece * 8 < a.N, x_ok = c0 + dpiece * 8 < a.C;
+  // padded position -> pixel index (or -1: padding / outside the tensor)
+  auto pixel_of = [&](int j) -> int {
+    if ((unsigned)j >= (unsigned)a.J) return -1;
+    const int r = fastdiv(j, a.dq), q = j - r * a.Qp;
+    const int b = fastdiv(r, a.dp), p = r - b * (a.P + 1);
+    return (q < a.Q && p < a.P) ? (b * a.P + p) * a.Q + q : -1;
+  };
+  auto issue_y = [&](int step) {  // positions [j0 + 32 step, + 32) of dY -> tile step & 1 (zero past the chunk's end)
+    const int j = j0 + step * BKM + drow;
+    const int m = j < j1 ? pixel_of(j) : -1;
+    const unsigned off = (m >= 0 && y_ok) ? (unsigned)m * (unsigned)(a.ldy * 2) + ycol : ~0u;
+    dma16(rsrc_y, off, 0u, &smem[(step & 1) * TILE_Y + wave * 64 * 8]);
+  };
+  auto issue_x = [&](int u0) {  // ring-relative rows [u0, u0 + 32): positions j0 - Gpad + u0 + ..
+    const int m = pixel_of(j0 - Gpad + u0 + drow);
+    const unsigned off = (m >= 0 && x_ok) ? (unsigned)m * (unsigned)(a.C * 2) + xcol : ~0u;
+    int rr = u0 % RING;  // wave-uniform; blocks never straddle the end (RING and u0 are multiples of 32)
+    dma16(rsrc_x, off, 0u, ring + rr * ROWH + wave * 64 * 8);
+  };
+
+  floatx16 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // transpose-read lane geometry (wgrad.h): 16-lane group gq -> column block (gq & 1) * 16, k half (gq >> 1) * 8; as a
+  // SOURCE lane this lane addresses row lrow = kgrp + (lane & 15) / 4 and the 8-byte chunk (lane & 3) of its column block
+  const int gq = lane >> 4, i16 = lane & 15;
+  const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
+  const int lrow = (gq >> 1) * 8 + src_row;
+  const unsigned lds0 = lds_addr_of(smem);
+  // A operand (dY tile): row lrow, column wn*32 + src_chunk; the swizzle sees row & 3 = src_row
+  const int colA = wn * 32 + src_chunk;
+  const unsigned aA = lds0 + (unsigned)((lrow * ROWH + (((colA >> 3) ^ wg_swz<8>(src_row)) * 8) + (colA & 7)) * 2);
+  // B operand (X ring): per tap the column term depends on (window start + src_row) & 3; window starts are
+  // Gpad + 32 s + shift (mod RING, a multiple of 4), so the key is loop invariant per tap
+  const int colB = wc * 32 + src_chunk;
+  unsigned xcolB[9];
+  int shift[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    shift[tp] = (tp / 3 - 1) * a.Qp + (tp % 3 - 1);
+    const int key = (Gpad + shift[tp] + src_row) & 3;  // Gpad + shift >= 0
+    xcolB[tp] = (unsigned)((((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
+  }
+  const unsigned ringB = lds0 + (unsigned)(2 * TILE_Y * 2);
+
+  // prologue: ring rows [0, 2 Gpad + 32) and the first dY tile
+  for (int u0 = 0; u0 < 2 * Gpad + BKM; u0 += BKM) issue_x(u0);
+  if (nsteps > 0) issue_y(0);
+
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // step s has landed for everyone; everyone is done with step s-1's reads
+    if (s + 1 < nsteps) {
+      issue_y(s + 1);
+      issue_x(2 * Gpad + BKM * (s + 1));
+    }
+    const unsigned tyA = aA + (unsigned)((s & 1) * TILE_Y * 2);
+    const int w0 = (Gpad + BKM * s) % RING;  // ring row of the unshifted window (scalar)
+#pragma unroll
+    for (int ks = 0; ks < BKM / 16; ++ks) {
+      TrFrag fa, fb[2];
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 0) {
+        fa.h[0] = ds_read_tr16_at<0>(smem, tyA);
+        fa.h[1] = ds_read_tr16_at<4 * ROWH * 2>(smem, tyA);
+      } else {
+        fa.h[0] = ds_read_tr16_at<16 * ROWH * 2>(smem, tyA);
+        fa.h[1] = ds_read_tr16_at<20 * ROWH * 2>(smem, tyA);
+      }
+      // B fragment of tap tp, K sub-step ks: rows (w0 + shift + 16 ks + {0, 4} + lrow) mod RING
+      auto read_b = [&](auto TP, TrFrag& f) {
+        constexpr int tp = decltype(TP)::value;
+        int rb = w0 + shift[tp];  // in (-RING, 2 RING)
+        rb = rb < 0 ? rb + RING : (rb >= RING ? rb - RING : rb);
+        if (rb + BKM <= RING) {  // wave-uniform: the 32-row window does not wrap
+          const unsigned ad = ringB + (unsigned)((rb + lrow) * (ROWH * 2)) + xcolB[tp];
+          if (ks == 0) {
+            f.h[0] = ds_read_tr16_at<0>(smem, ad);
+            f.h[1] = ds_read_tr16_at<4 * ROWH * 2>(smem, ad);
+          } else {
+            f.h[0] = ds_read_tr16_at<16 * ROWH * 2>(smem, ad);
+            f.h[1] = ds_read_tr16_at<20 * ROWH * 2>(smem, ad);
+          }
+        } else {
+          int r0 = rb + lrow + ks * 16, r1 = r0 + 4;
+          r0 = r0 >= RING ? r0 - RING : r0;
+          r1 = r1 >= RING ? r1 - RING : r1;
+          f.h[0] = ds_read_tr16_at<0>(smem, ringB + (unsigned)(r0 * (ROWH * 2)) + xcolB[tp]);
+          f.h[1] = ds_read_tr16_at<0>(smem, ringB + (unsigned)(r1 * (ROWH * 2)) + xcolB[tp]);
+        }
+      };
+      read_b(StaticIndex<0>{}, fb[0]);
+      static_for<9>([&](auto TP) {
+        constexpr int tp = decltype(TP)::value;
+        if constexpr (tp + 1 < 9) read_b(StaticIndex<tp + 1>{}, fb[(tp + 1) & 1]);
+        // LDS reads return in order: with at most the next tap's two reads outstanding, fa and this tap's fragment are in
+        wait_lgkmcnt_for<(tp + 1 < 9) ? 2 : 0>(fb[tp & 1]);
+        if constexpr (tp == 0) wait_lgkmcnt_for<2>(fa);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.v, fb[tp & 1].v, acc[tp], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  }
+
+  // atomic accumulation into dW[n][tap*C + c]
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    const int c = c0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n < a.N && c < a.C) unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[tp][r] * a.alpha);
+    }
+  }
+}
+
+// Applies to the weight gradient of a 3x3 stride-1 pad-1 convolution of an NHWC fp16 tensor whose channel counts are
+// multiples of 8 (ResNet-34: 29 of the 37 conv layers, 93 % of the weight-gradient FLOPs).
+inline bool wgrad_fused_applies(const WgradArgs& a) {
+  const GatherGeom& g = a.g;
+  return g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.rsign == 1 && g.ssign == 1 && g.off_h == -1 &&
+         g.off_w == -1 && g.P == g.Hi && g.Q == g.Wi && g.C % 8 == 0 && g.N % 8 == 0 && a.colmap == nullptr && a.ldw >= 9 * g.C &&
+         g.Q + 2 <= 128 && (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l &&
+         (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
+}
+
+inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream) {
+  constexpr int BKM = 32;
+  const GatherGeom& g = w.g;
+  WgradFusedArgs a;
+  a.dY = reinterpret_cast<const half*>(w.dY);
+  a.X = reinterpret_cast<const half*>(w.X);
+  a.dW = w.dW;
+  a.ldy = w.ldy;
+  a.ldw = w.ldw;
+  a.B = g.B; a.P = g.P; a.Q = g.Q; a.C = g.C; a.N = g.N;
+  a.Qp = g.Q + 1;
+  a.J = g.B * (g.P + 1) * (g.Q + 1);
+  a.tiles_n = cdiv(g.N, 64);
+  a.tiles_c = cdiv(g.C, 64);
+  a.Gpad = ((g.Q + 2 + 15) / 16) * 16;
+  a.ring = 2 * BKM + 2 * a.Gpad;
+  a.dq = make_fastdiv(a.Qp);
+  a.dp = make_fastdiv(g.P + 1);
+  a.alpha = w.alpha;
+  // pixel ranges: enough workgroups to fill the chip, but each at least 8 halos long (the ring prologue fetches
+  // 2 Gpad + 32 rows that belong to the neighbouring ranges)
+  const int pairs = a.tiles_n * a.tiles_c;
+  int chunks = cdiv(target_blocks, pairs);
+  const int min_chunk = 16 * a.Gpad;
+  if ((long)chunks * min_chunk > a.J) chunks = (int)(a.J / min_chunk);
+  if (chunks < 1) chunks = 1;
+  a.chunk = cdiv(cdiv(a.J, chunks), BKM) * BKM;
+  a.nchunks = cdiv(a.J, a.chunk);
+  static const bool trace = getenv("MN_TRACE_DISPATCH") != nullptr;
+  if (trace)
+    fprintf(stderr, "wgrad_fused: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows\n", a.B, a.P, a.Q, a.C,
+            a.N, a.chunk, a.nchunks, pairs, a.ring);
+  hipLaunchKernelGGL((wgrad_fused_kernel<BKM>), dim3(a.nchunks * pairs), dim3(256), 0, stream, a);
+}
+
+}  // namespace mn

@@ -229,7 +229,9 @@ int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t 
                float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm, double* sqnorm_scratch,
                int eps_mode, void* stream);
 
-/* elementwise / reduction operators (NHWC, C multiple of 16 bytes) */
+/* elementwise / reduction operators (NHWC, C multiple of 16 bytes).
+ * Scratch: mn_op_bn_train_fwd's accum_scratch = 2*C doubles followed by 2*C floats; mn_op_bn_bwd's accum_scratch = 2*C
+ * doubles (handed back zeroed), coef_scratch = 3*C floats. */
 int mn_op_bn_train_fwd(int dtype, const void* y, int64_t M, int C, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float* mean, float* invstd, const void* res,
                        int relu, void* out, float eps, float momentum, double* accum_scratch, void* stream);

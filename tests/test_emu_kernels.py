@@ -169,14 +169,15 @@ def test_forced_288x256_configuration():
 
 
 def test_weight_gradient_with_assembly_transpose_reads():
-    """wgrad_dma_kernel<..., ASMRD> (MN_WGRAD_TR_ASM=1): same results as the builtin-read kernel; the emulator executes
-    the variant's address arithmetic (lane base + immediate offsets)"""
+    """wgrad_dma_kernel<..., ASMRD> (the plain-GEMM weight gradient with assembly transpose reads; since round 2 the
+    3x3 stride-1 layers go to wgrad_fused.h, so MN_WGRAD_FUSED=0 routes the cases here): the emulator executes the
+    variant's address arithmetic (lane base + immediate offsets).  MN_WGRAD_TR_ASM=0: the builtin-read form."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    for variant in ("1", "0"):  # 32-row steps (default) and 64-row steps
-        env = dict(os.environ, MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT=variant)
+    for variant, asm in (("1", "1"), ("0", "1"), ("1", "0")):  # 32-row steps (default) and 64-row steps; builtin reads
+        env = dict(os.environ, MN_WGRAD_TR_ASM=asm, MN_WGRAD_CASES="1", MN_WGRAD_VARIANT=variant, MN_WGRAD_FUSED="0")
         subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
 
 
@@ -187,7 +188,7 @@ def test_criteria_vs_oracle_other_window_lengths(lib, mode, N, T):
 
 
 def test_experimental_chunk_resident_a_kernel():
-    """igemm_halo.h (MN_IGEMM_HALO=1, off by default): the 288x256 tile with the A operand staged once per 64-channel chunk
+    """igemm_halo.h (MN_IGEMM_HALO=1|2; 2 is the default since round 2): the 288x256 tile with the A operand staged once per 64-channel chunk
     and taps as row shifts into that image, against torch fp64 (forward with BatchNorm sums, data gradient with residual
     and gates; one to four chunks, ragged tiles, tiles spanning several images)"""
     import os

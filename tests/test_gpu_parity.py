@@ -398,14 +398,20 @@ def _run_experimental(env):
 
 
 def test_weight_gradient_with_assembly_transpose_reads():
-    """MN_WGRAD_TR_ASM=1 (off by default): the fp16 weight-gradient kernel with its transpose reads issued from inline
-    assembly and hand-placed waits, against torch fp64 at small and layer-sized shapes, repeated."""
+    """the plain-GEMM fp16 weight-gradient kernel (MN_WGRAD_FUSED=0 routes the 3x3 layers to it) with its transpose reads
+    issued from inline assembly and hand-placed waits, against torch fp64 at small and layer-sized shapes, repeated."""
     for variant in ("1", "0"):  # 32-row steps (default) and 64-row steps
-        _run_experimental(dict(os.environ, MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT=variant))
+        _run_experimental(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT=variant, MN_WGRAD_FUSED="0"))
+
+
+def test_fused_weight_gradient_race_screen():
+    """wgrad_fused.h (default for the 3x3 stride-1 layers) at layer geometries with hundreds of concurrent workgroups,
+    repeated, in a process of its own"""
+    _run_experimental(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_FUSED="1"))
 
 
 def test_experimental_chunk_resident_a_kernel():
-    """MN_IGEMM_HALO=1|2 (off by default): igemm_halo.h against torch fp64, plus layer2-4 geometries repeated."""
+    """MN_IGEMM_HALO=1|2 (2 is the default since round 2): igemm_halo.h against torch fp64, plus layer2-4 geometries repeated."""
     _run_experimental(dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1"))  # the 256-column shape (layer3)
     env = dict(os.environ, MN_IGEMM_HALO="2")                                     # the 128-column shape (layers 2 and 4)
     env.pop("MN_IGEMM_CONFIG", None)

@@ -26,6 +26,9 @@ namespace mn {
 
 constexpr int kHaloTH = 16, kHaloTW = 16;
 
+// ABL (timing experiments only, MN_HALO_ABLATE, results are wrong): bit 0 = no halo DMA, bit 1 = no weight DMA (and no
+// per-tap wait / barrier), bit 2 = no epilogue stores and residual / gate loads, bit 3 = no MFMA.
+template <int ABL = 0>
 static __global__ void __launch_bounds__(256, 2) conv_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                   const half* __restrict__ Bw, Epilogue ep, int tiles_x,
                                                                   int tiles_y, int grid_n) {
@@ -62,6 +65,7 @@ static __global__ void __launch_bounds__(256, 2) conv_halo_kernel(GatherGeom g, 
 #pragma unroll
   for (int i = 0; i < HPASS; ++i) {
     if (i * NT + wave * 64 >= HPIX * NP) continue;  // wave-uniform: the last pass only has work for the first waves
+    if constexpr ((ABL & 1) != 0) continue;
     const int q = t + i * NT;
     const int hp = q >> 3, pc = q & 7;
     const int hy = hp / HW, hx = hp - hy * HW;
@@ -79,6 +83,7 @@ static __global__ void __launch_bounds__(256, 2) conv_halo_kernel(GatherGeom g, 
     b_off[i] = n < g.N ? (unsigned)(n * g.K) * 2u + (unsigned)((pc ^ ((br >> 1) & 7)) * 16) : ~0u;
   }
   auto issue_b = [&](int tap, int buf) {
+    if constexpr ((ABL & 2) != 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) dma16(rsrc_b, b_off[i], (unsigned)(tap * g.C * 2), &smem[HAL + buf * BT + wave * 64 + i * NT]);
   };
@@ -107,7 +112,8 @@ static __global__ void __launch_bounds__(256, 2) conv_halo_kernel(GatherGeom g, 
       wait_vmcnt<2>();
     else
       wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // halo (first step) and this tap's weights visible; slot (tap - 1) % NB is free
+    if ((ABL & 2) == 0 || tap == 0)
+      __builtin_amdgcn_s_barrier();  // halo (first step) and this tap's weights visible; slot (tap - 1) % NB is free
     if (tap + NB - 1 < ntaps) issue_b(tap + NB - 1, (tap + NB - 1) % NB);
     const int r = tap / S, s = tap - r * S;
     const int dy = g.rsign > 0 ? r : R - 1 - r, dx = g.ssign > 0 ? s : S - 1 - s;
@@ -135,7 +141,13 @@ static __global__ void __launch_bounds__(256, 2) conv_halo_kernel(GatherGeom g, 
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma_piece<half>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) {
+          if constexpr ((ABL & 8) == 0) {
+            mma_piece<half>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+          } else {
+            asm volatile("" ::"v"(fa[ks & 1][i].p), "v"(fb[ks & 1][j].p));
+          }
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -163,7 +175,7 @@ static __global__ void __launch_bounds__(256, 2) conv_halo_kernel(GatherGeom g, 
       const int rl = (lr >> 5) * 64 + i * 32 + (lr & 31);
       const int y = y0 + (rl >> 4), x = x0 + (rl & 15);
       const int col = n0 + cpc * VEC;
-      oks[ps] = y < g.P && x < g.Q && col < g.N;
+      oks[ps] = y < g.P && x < g.Q && col < g.N && (ABL & 4) == 0;
       idxs[ps] = (((long)b * g.P + y) * g.Q + x) * ep.ldc + col;
       if (oks[ps]) {
         if (res) rv[ps].p = *reinterpret_cast<const piece_t*>(res + idxs[ps]);
@@ -272,7 +284,22 @@ inline bool conv_halo_applies(const GatherGeom& g) {
 // returns the number of M-blocks used
 inline int launch_conv_halo(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream) {
   const int tx = cdiv(g.Q, kHaloTW), ty = cdiv(g.P, kHaloTH), gn = cdiv(g.N, 64);
-  hipLaunchKernelGGL(conv_halo_kernel, dim3(g.B * tx * ty * gn), dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn);
+#ifdef MN_ABLATION_BUILD
+  static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
+  const dim3 grid(g.B * tx * ty * gn);
+  switch (abl) {
+    case 1: hipLaunchKernelGGL(conv_halo_kernel<1>, grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn); return g.B * tx * ty;
+    case 2: hipLaunchKernelGGL(conv_halo_kernel<2>, grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn); return g.B * tx * ty;
+    case 3: hipLaunchKernelGGL(conv_halo_kernel<3>, grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn); return g.B * tx * ty;
+    case 4: hipLaunchKernelGGL(conv_halo_kernel<4>, grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn); return g.B * tx * ty;
+    case 7: hipLaunchKernelGGL(conv_halo_kernel<7>, grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn); return g.B * tx * ty;
+    case 8: hipLaunchKernelGGL(conv_halo_kernel<8>, grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn); return g.B * tx * ty;
+    case 12: hipLaunchKernelGGL(conv_halo_kernel<12>, grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn); return g.B * tx * ty;
+    case 15: hipLaunchKernelGGL(conv_halo_kernel<15>, grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn); return g.B * tx * ty;
+    default: break;
+  }
+#endif
+  hipLaunchKernelGGL(conv_halo_kernel<0>, dim3(g.B * tx * ty * gn), dim3(256), 0, stream, g, A, Bw, ep, tx, ty, gn);
   return g.B * tx * ty;
 }
 

@@ -19,8 +19,10 @@
 //
 // X lives in a ring of `ring` LDS rows (row = one position, 64 channels = 128 B, 16-byte pieces XOR-swizzled with
 // row & 3 like wgrad.h so the four rows of a transpose read fall in distinct bank groups): step s reads ring rows
-// [32 s + Gpad + shift, + 32) for each tap while the DMA of step s+1 lands 32 new rows right behind the live window
-// (ring = 2*32 + 2*Gpad rows, Gpad = Q + 2 rounded up to 16).  Fragments come from ds_read_b64_tr_b16 issued from inline
+// [32 s + Gpad + shift, + 32) for each tap while the DMAs of steps s+1 .. s+D land 32 new rows each right behind the live
+// window (ring = 32 (D+1) + 2 Gpad rows, Gpad = Q + 2 rounded up to 16; D+1 dY tiles; counted vmcnt waits -- at two
+// workgroups per CU one step of 18 MFMAs per wave is 0.3 us, a third of the DMA latency: with D = 1 the kernel ran at
+// 390 TF, latency-bound, round-2 measurement).  Fragments come from ds_read_b64_tr_b16 issued from inline
 // assembly with counted lgkmcnt waits (hipcc drains vmcnt(0) in front of the builtin while an LDS-DMA is in flight,
 // wgrad.h); the reads of tap t+1 are in flight under the MFMA of tap t.  A tap window that wraps around the end of the
 // ring (one step in ring/32 per tap) takes a slower path that wraps every row address.
@@ -41,21 +43,25 @@ struct WgradFusedArgs {
   int nchunks;  // workgroups per (n tile, c tile) pair
   int tiles_n, tiles_c;
   int Gpad;     // halo rows kept on each side of the live window (>= Q + 2, multiple of 16)
-  int ring;     // LDS rows of the X ring = 2*BKM + 2*Gpad
+  int ring;     // LDS rows of the X ring = (D+1)*BKM + 2*Gpad
   FastDiv dq, dp;  // divisors Q+1 and P+1
   float alpha;
 };
 
-constexpr int WGF_RING_MAX = 320;  // rows; bounds the image width (Gpad <= 128 -> Q <= 126)
+constexpr int WGF_RING_MAX = 320;  // rows: 4 steps + 2 Gpad; bounds the image width (Gpad <= 96 -> Q <= 94, i.e. inputs up to 376 px wide at layer1)
 
-template <int BKM>
+// ABL (timing experiments only, MN_WGF_ABLATE in the ablation build; results are wrong): bit 0 = no DMA after the prologue,
+// bit 1 = no B-fragment reads, bit 2 = no MFMA, bit 3 = no atomics.
+template <int BKM, int D, int ABL = 0>
 static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedArgs a) {
   static_assert(BKM == 32, "one DMA pass of 256 threads per operand and step");
+  static_assert(D >= 1 && D <= 3, "steps in flight");
   constexpr int ROWH = 64;                 // halves per LDS row (64 channels / 64 output channels)
   constexpr int TILE_Y = BKM * ROWH;       // halves
-  // ONE LDS object: [2 dY tiles][X ring]
-  __shared__ half smem[2 * TILE_Y + WGF_RING_MAX * ROWH] __attribute__((aligned(16)));
-  half* ring = &smem[2 * TILE_Y];
+  constexpr int NY = D + 1;                // dY tiles
+  // ONE LDS object: [NY dY tiles][X ring]
+  __shared__ half smem[NY * TILE_Y + WGF_RING_MAX * ROWH] __attribute__((aligned(16)));
+  half* ring = &smem[NY * TILE_Y];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -86,11 +92,11 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
     const int b = fastdiv(r, a.dp), p = r - b * (a.P + 1);
     return (q < a.Q && p < a.P) ? (b * a.P + p) * a.Q + q : -1;
   };
-  auto issue_y = [&](int step) {  // positions [j0 + 32 step, + 32) of dY -> tile step & 1 (zero past the chunk's end)
+  auto issue_y = [&](int step) {  // positions [j0 + 32 step, + 32) of dY -> tile step % NY (zero past the chunk's end)
     const int j = j0 + step * BKM + drow;
     const int m = j < j1 ? pixel_of(j) : -1;
     const unsigned off = (m >= 0 && y_ok) ? (unsigned)m * (unsigned)(a.ldy * 2) + ycol : ~0u;
-    dma16(rsrc_y, off, 0u, &smem[(step & 1) * TILE_Y + wave * 64 * 8]);
+    dma16(rsrc_y, off, 0u, &smem[(step % NY) * TILE_Y + wave * 64 * 8]);
   };
   auto issue_x = [&](int u0) {  // ring-relative rows [u0, u0 + 32): positions j0 - Gpad + u0 + ..
     const int m = pixel_of(j0 - Gpad + u0 + drow);
@@ -125,20 +131,33 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
     const int key = (Gpad + shift[tp] + src_row) & 3;  // Gpad + shift >= 0
     xcolB[tp] = (unsigned)((((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
   }
-  const unsigned ringB = lds0 + (unsigned)(2 * TILE_Y * 2);
+  const unsigned ringB = lds0 + (unsigned)(NY * TILE_Y * 2);
 
-  // prologue: ring rows [0, 2 Gpad + 32) and the first dY tile
-  for (int u0 = 0; u0 < 2 * Gpad + BKM; u0 += BKM) issue_x(u0);
-  if (nsteps > 0) issue_y(0);
+  // prologue: the halo rows [0, 2 Gpad), then steps 0 .. D-1 (dY tile + 32 ring rows each), in the order the waits count
+  for (int u0 = 0; u0 < 2 * Gpad; u0 += BKM) issue_x(u0);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nsteps) {
+      issue_y(d);
+      issue_x(2 * Gpad + BKM * d);
+    }
 
   for (int s = 0; s < nsteps; ++s) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // step s has landed for everyone; everyone is done with step s-1's reads
-    if (s + 1 < nsteps) {
-      issue_y(s + 1);
-      issue_x(2 * Gpad + BKM * (s + 1));
+    // steps issued so far: min(nsteps, s + D), two DMA instructions each, retired in order: step s has landed when at
+    // most the later ones are outstanding
+    const int ahead = min(nsteps, s + D) - (s + 1);
+    if (D >= 3 && ahead >= 2)
+      wait_vmcnt<4>();
+    else if (D >= 2 && ahead >= 1)
+      wait_vmcnt<2>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // step s visible to everyone; everyone is done with step s-1's reads
+    if (s + D < nsteps && (ABL & 1) == 0) {  // into dY tile (s - 1) % NY and the 32 ring rows behind the live + in-flight window
+      issue_y(s + D);
+      issue_x(2 * Gpad + BKM * (s + D));
     }
-    const unsigned tyA = aA + (unsigned)((s & 1) * TILE_Y * 2);
+    const unsigned tyA = aA + (unsigned)((s % NY) * TILE_Y * 2);
     const int w0 = (Gpad + BKM * s) % RING;  // ring row of the unshifted window (scalar)
 #pragma unroll
     for (int ks = 0; ks < BKM / 16; ++ks) {
@@ -154,6 +173,11 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
       // B fragment of tap tp, K sub-step ks: rows (w0 + shift + 16 ks + {0, 4} + lrow) mod RING
       auto read_b = [&](auto TP, TrFrag& f) {
         constexpr int tp = decltype(TP)::value;
+        if constexpr ((ABL & 2) != 0) {
+          f.h[0] = fa.h[1];
+          f.h[1] = fa.h[0];
+          return;
+        }
         int rb = w0 + shift[tp];  // in (-RING, 2 RING)
         rb = rb < 0 ? rb + RING : (rb >= RING ? rb - RING : rb);
         if (rb + BKM <= RING) {  // wave-uniform: the 32-row window does not wrap
@@ -181,7 +205,10 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
         wait_lgkmcnt_for<(tp + 1 < 9) ? 2 : 0>(fb[tp & 1]);
         if constexpr (tp == 0) wait_lgkmcnt_for<2>(fa);
         __builtin_amdgcn_sched_barrier(0);
-        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.v, fb[tp & 1].v, acc[tp], 0, 0, 0);
+        if constexpr ((ABL & 4) == 0)
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.v, fb[tp & 1].v, acc[tp], 0, 0, 0);
+        else
+          asm volatile("" ::"v"(fa.v), "v"(fb[tp & 1].v));
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -194,7 +221,7 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (n < a.N && c < a.C) unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[tp][r] * a.alpha);
+      if (n < a.N && c < a.C && (ABL & 8) == 0) unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[tp][r] * a.alpha);
     }
   }
 }
@@ -205,7 +232,7 @@ inline bool wgrad_fused_applies(const WgradArgs& a) {
   const GatherGeom& g = a.g;
   return g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.rsign == 1 && g.ssign == 1 && g.off_h == -1 &&
          g.off_w == -1 && g.P == g.Hi && g.Q == g.Wi && g.C % 8 == 0 && g.N % 8 == 0 && a.colmap == nullptr && a.ldw >= 9 * g.C &&
-         g.Q + 2 <= 128 && (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l &&
+         4 * 32 + 2 * (((g.Q + 2 + 15) / 16) * 16) <= WGF_RING_MAX && (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l &&
          (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
 }
 
@@ -224,7 +251,9 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   a.tiles_n = cdiv(g.N, 64);
   a.tiles_c = cdiv(g.C, 64);
   a.Gpad = ((g.Q + 2 + 15) / 16) * 16;
-  a.ring = 2 * BKM + 2 * a.Gpad;
+  static const int depth = getenv("MN_WGF_DEPTH") ? atoi(getenv("MN_WGF_DEPTH")) : 3;  // DMA steps in flight (1..3)
+  const int D = depth < 1 ? 1 : (depth > 3 ? 3 : depth);
+  a.ring = (D + 1) * BKM + 2 * a.Gpad;
   a.dq = make_fastdiv(a.Qp);
   a.dp = make_fastdiv(g.P + 1);
   a.alpha = w.alpha;
@@ -241,7 +270,26 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   if (trace)
     fprintf(stderr, "wgrad_fused: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows\n", a.B, a.P, a.Q, a.C,
             a.N, a.chunk, a.nchunks, pairs, a.ring);
-  hipLaunchKernelGGL((wgrad_fused_kernel<BKM>), dim3(a.nchunks * pairs), dim3(256), 0, stream, a);
+  const dim3 grid(a.nchunks * pairs);
+#ifdef MN_ABLATION_BUILD
+  static const int abl = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
+  switch (abl) {
+    case 1: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 1>), grid, dim3(256), 0, stream, a); return;
+    case 2: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 2>), grid, dim3(256), 0, stream, a); return;
+    case 3: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 3>), grid, dim3(256), 0, stream, a); return;
+    case 4: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 4>), grid, dim3(256), 0, stream, a); return;
+    case 6: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 6>), grid, dim3(256), 0, stream, a); return;
+    case 8: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 8>), grid, dim3(256), 0, stream, a); return;
+    case 11: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 11>), grid, dim3(256), 0, stream, a); return;
+    default: break;
+  }
+#endif
+  if (D == 1)
+    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 1>), grid, dim3(256), 0, stream, a);
+  else if (D == 2)
+    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 2>), grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3>), grid, dim3(256), 0, stream, a);
 }
 
 }  // namespace mn

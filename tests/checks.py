@@ -919,7 +919,7 @@ def check_nan_filter(lib, dev, dtype_name="fp32", N=2, H=64, W=85):
         lo, po = oracle.step_feedfwd(x, onet, False, t, oc, oopt, True)
         l, p = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True)
         assert float(po.detach()[..., 3:].abs().max()) == 0.0 and float(p[..., 3:].abs().max()) == 0.0
-        assert abs(l - lo) <= 1e-4 * max(1.0, abs(lo))
+        assert abs(l - lo) <= (1e-4 if dtype_name == "fp32" else 1e-2) * max(1.0, abs(lo)), (l, lo)
         eng = net.mapnet._engine
         plan = next(iter(eng.plans.values()))
         dpred = eng.debug_tensor(plan, "dposes").cpu().view(N, -1, 6)

@@ -13,7 +13,8 @@ import checks  # noqa: E402
 from geomapnet_amd import _binding  # noqa: E402
 from geomapnet_amd._binding import ptr  # noqa: E402
 
-lib = _binding.hip()
+# MN_LIB: an alternative build of the library (the ablation build, `make -C geomapnet_amd/csrc ablation`)
+lib = _binding.Binding(C.CDLL(os.environ["MN_LIB"])) if os.environ.get("MN_LIB") else _binding.hip()
 dtype = 1 if (len(sys.argv) < 2 or sys.argv[1] == "fp16") else 0
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 td = checks.TD[dtype]

@@ -341,6 +341,8 @@ struct Plan : PlanBase {
   int repack_njobs = 0, repack_blocks = 0, repack_head_jobs = -1, repack_head_blocks = 0;
   bool grads_zeroed = false;
   unsigned char* pool_idx;  // winning tap of every max-pool window
+  float* wgf_ws = nullptr;  // partial tiles of the fused weight gradient (wgrad_fused.h), shared by its launches (one stream)
+  long wgf_ws_floats = 0;
   float* sk_ws = nullptr;   // stream-K slabs [igemm_sk_blocks()][2][128*128] and
   int* sk_counters = nullptr;  // arrival counters; zero between launches (igemm.h)
   void* zero_page;          // 256 zero bytes: source of out-of-image taps for the DMA conv pipeline
@@ -421,6 +423,8 @@ struct Plan : PlanBase {
     stem_colmap = (int*)A(224 * 4);
     repack_jobs = (RepackJob*)A(64 * sizeof(RepackJob));
     zero_page = (void*)A(256);
+    wgf_ws_floats = DT == MN_F16 ? wgrad_fused_ws_floats(WGF_BLOCKS) : 0;
+    wgf_ws = wgf_ws_floats ? (float*)A((size_t)wgf_ws_floats * 4) : nullptr;
     sk_ws = (float*)A((size_t)igemm_sk_blocks() * 2 * 128 * 128 * 4);
     sk_counters = (int*)A((size_t)igemm_sk_blocks() * 4);
     step_dev = (long long*)A(256);
@@ -732,6 +736,7 @@ struct Plan : PlanBase {
     WgradArgs a;
     a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
     a.alpha = 1.f / cur_scale; a.rows_per_split = 0;
+    a.ws = wgf_ws; a.ws_floats = wgf_ws_floats;  // every weight-gradient launch of a step goes to the same stream (`ws`)
     auto* tp = timer.begin(1, ws);
     // reduction splits (measured, tools/conv_bench.py): one round of 2 workgroups per CU for the wide layers (half
     // the atomic traffic of 1024), more for layer1 and the stem whose pixel dimension is 4-16x longer

@@ -108,10 +108,26 @@ extern "C" int mn_op_igemm_streamk(int dtype, const mn_gather_geom* gg, const vo
   return check_launch("igemm_streamk");
 }
 
+static int op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
+                    const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, float* ws, long ws_floats,
+                    void* stream);
 extern "C" int mn_op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
                            const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream) {
+  return op_wgrad(dtype, gg, dY, ldy, X, dW, ldw, colmap, alpha, target_blocks, zero_page, nullptr, 0, stream);
+}
+extern "C" int64_t mn_op_wgrad_ws_floats(void) { return wgrad_fused_ws_floats(WGF_BLOCKS); }
+extern "C" int mn_op_wgrad_ws(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
+                              float alpha, float* ws, int64_t ws_floats, const void* zero_page, void* stream) {
+  if (!ws || ws_floats <= 0) return fail("wgrad_ws: workspace required (mn_op_wgrad_ws_floats() floats)");
+  return op_wgrad(dtype, gg, dY, ldy, X, dW, ldw, nullptr, alpha, 512, zero_page, ws, (long)ws_floats, stream);
+}
+static int op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
+                    const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, float* ws, long ws_floats,
+                    void* stream) {
   begin_call();
   WgradArgs a;
+  a.ws = ws;
+  a.ws_floats = ws_floats;
   a.g = to_geom(gg);
   int vec = dtype == MN_F16 ? 8 : 4;
   if (a.g.C % vec != 0 || a.g.N % vec != 0) return fail("wgrad: channel counts must be multiples of the piece");

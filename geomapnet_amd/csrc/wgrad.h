@@ -28,6 +28,10 @@ struct WgradArgs {
   const int* colmap;  // [K] or null
   float alpha;
   int rows_per_split; // multiple of 32
+  // optional scratch for the partial tiles of wgrad_fused.h (one slab per pixel range instead of fp32 atomics into dW);
+  // launches that share it must be ordered on one stream
+  float* ws = nullptr;
+  long ws_floats = 0;
 };
 
 template <typename T, int BMO, int BNO>

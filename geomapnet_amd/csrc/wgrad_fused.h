@@ -34,7 +34,9 @@ namespace mn {
 struct WgradFusedArgs {
   const half* dY;  // [M][ldy], M = B*P*Q
   const half* X;   // [B][P][Q][C]
-  float* dW;       // [N][ldw] fp32, column (tap*C + c), accumulated atomically
+  float* dW;       // [N][ldw] fp32, column (tap*C + c), accumulated atomically when there is no workspace
+  float* ws;       // optional [nchunks][N][9*C] fp32: every workgroup stores its partial tile there (plain stores) and
+                   // wgrad_fused_reduce_kernel adds the chunks up in order; null = fp32 atomics straight into dW
   int ldy, ldw;
   int B, P, Q, C, N;
   int Qp;       // Q + 1
@@ -52,7 +54,9 @@ constexpr int WGF_RING_MAX = 320;  // rows: 4 steps + 2 Gpad; bounds the image w
 
 // ABL (timing experiments only, MN_WGF_ABLATE in the ablation build; results are wrong): bit 0 = no DMA after the prologue,
 // bit 1 = no B-fragment reads, bit 2 = no MFMA, bit 3 = no atomics.
-template <int BKM, int D, int ABL = 0>
+// PD: B fragments requested ahead of the MFMA that consumes them.  With PD = 1 (round-2 first version) every MFMA waited
+// for an LDS round trip issued one MFMA (32 cycles) earlier: 3000 cycles per step instead of 18 x 32.
+template <int BKM, int D, int ABL = 0, int PD = 4>
 static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedArgs a) {
   static_assert(BKM == 32, "one DMA pass of 256 threads per operand and step");
   static_assert(D >= 1 && D <= 3, "steps in flight");
@@ -159,70 +163,100 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
     }
     const unsigned tyA = aA + (unsigned)((s % NY) * TILE_Y * 2);
     const int w0 = (Gpad + BKM * s) % RING;  // ring row of the unshifted window (scalar)
-#pragma unroll
-    for (int ks = 0; ks < BKM / 16; ++ks) {
-      TrFrag fa, fb[2];
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks == 0) {
-        fa.h[0] = ds_read_tr16_at<0>(smem, tyA);
-        fa.h[1] = ds_read_tr16_at<4 * ROWH * 2>(smem, tyA);
-      } else {
-        fa.h[0] = ds_read_tr16_at<16 * ROWH * 2>(smem, tyA);
-        fa.h[1] = ds_read_tr16_at<20 * ROWH * 2>(smem, tyA);
+    // One step = 18 (K sub-step, tap) items, each one MFMA fed by the step's A fragment of that sub-step and a B fragment
+    // read at the tap's row shift.  B fragments travel through a ring of PD + 1 register buffers: item i + PD is requested
+    // right before the MFMA of item i (its buffer was last used by item i - 1, whose MFMA has been issued).
+    constexpr int NKS = BKM / 16, ITEMS = NKS * 9, NB = PD + 1;
+    static_assert(2 * PD <= 15, "lgkmcnt field");
+    TrFrag fa[NKS], fb[NB];
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NKS>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      fa[ks].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, tyA);
+      fa[ks].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, tyA);
+    });
+    // B fragment of item I = (ks, tp): rows (w0 + shift[tp] + 16 ks + {0, 4} + lrow) mod RING
+    auto read_b = [&](auto I, TrFrag& f) {
+      constexpr int it = decltype(I)::value, ks = it / 9, tp = it % 9;
+      if constexpr ((ABL & 2) != 0) {
+        f.h[0] = fa[ks].h[1];
+        f.h[1] = fa[ks].h[0];
+        return;
       }
-      // B fragment of tap tp, K sub-step ks: rows (w0 + shift + 16 ks + {0, 4} + lrow) mod RING
-      auto read_b = [&](auto TP, TrFrag& f) {
-        constexpr int tp = decltype(TP)::value;
-        if constexpr ((ABL & 2) != 0) {
-          f.h[0] = fa.h[1];
-          f.h[1] = fa.h[0];
-          return;
-        }
-        int rb = w0 + shift[tp];  // in (-RING, 2 RING)
-        rb = rb < 0 ? rb + RING : (rb >= RING ? rb - RING : rb);
-        if (rb + BKM <= RING) {  // wave-uniform: the 32-row window does not wrap
-          const unsigned ad = ringB + (unsigned)((rb + lrow) * (ROWH * 2)) + xcolB[tp];
-          if (ks == 0) {
-            f.h[0] = ds_read_tr16_at<0>(smem, ad);
-            f.h[1] = ds_read_tr16_at<4 * ROWH * 2>(smem, ad);
-          } else {
-            f.h[0] = ds_read_tr16_at<16 * ROWH * 2>(smem, ad);
-            f.h[1] = ds_read_tr16_at<20 * ROWH * 2>(smem, ad);
-          }
-        } else {
-          int r0 = rb + lrow + ks * 16, r1 = r0 + 4;
-          r0 = r0 >= RING ? r0 - RING : r0;
-          r1 = r1 >= RING ? r1 - RING : r1;
-          f.h[0] = ds_read_tr16_at<0>(smem, ringB + (unsigned)(r0 * (ROWH * 2)) + xcolB[tp]);
-          f.h[1] = ds_read_tr16_at<0>(smem, ringB + (unsigned)(r1 * (ROWH * 2)) + xcolB[tp]);
-        }
-      };
-      read_b(StaticIndex<0>{}, fb[0]);
-      static_for<9>([&](auto TP) {
-        constexpr int tp = decltype(TP)::value;
-        if constexpr (tp + 1 < 9) read_b(StaticIndex<tp + 1>{}, fb[(tp + 1) & 1]);
-        // LDS reads return in order: with at most the next tap's two reads outstanding, fa and this tap's fragment are in
-        wait_lgkmcnt_for<(tp + 1 < 9) ? 2 : 0>(fb[tp & 1]);
-        if constexpr (tp == 0) wait_lgkmcnt_for<2>(fa);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr ((ABL & 4) == 0)
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.v, fb[tp & 1].v, acc[tp], 0, 0, 0);
-        else
-          asm volatile("" ::"v"(fa.v), "v"(fb[tp & 1].v));
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    }
+      int rb = w0 + shift[tp];  // in (-RING, 2 RING)
+      rb = rb < 0 ? rb + RING : (rb >= RING ? rb - RING : rb);
+      if (rb + BKM <= RING) {  // wave-uniform: the 32-row window does not wrap
+        const unsigned ad = ringB + (unsigned)((rb + lrow) * (ROWH * 2)) + xcolB[tp];
+        f.h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, ad);
+        f.h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, ad);
+      } else {
+        int r0 = rb + lrow + ks * 16, r1 = r0 + 4;
+        r0 = r0 >= RING ? r0 - RING : r0;
+        r1 = r1 >= RING ? r1 - RING : r1;
+        f.h[0] = ds_read_tr16_at<0>(smem, ringB + (unsigned)(r0 * (ROWH * 2)) + xcolB[tp]);
+        f.h[1] = ds_read_tr16_at<0>(smem, ringB + (unsigned)(r1 * (ROWH * 2)) + xcolB[tp]);
+      }
+    };
+    static_for<(PD < ITEMS ? PD : ITEMS)>([&](auto I) { read_b(I, fb[decltype(I)::value % NB]); });
+    static_for<ITEMS>([&](auto I) {
+      constexpr int it = decltype(I)::value, ks = it / 9, tp = it % 9;
+      if constexpr (it + PD < ITEMS) read_b(StaticIndex<it + PD>{}, fb[(it + PD) % NB]);
+      // LDS reads return in order: once at most the requests issued AFTER item `it` are outstanding (two per item), its
+      // fragment -- and the A fragments, requested before every B fragment -- are in their registers
+      constexpr int later = (ITEMS - 1 - it) < PD ? (ITEMS - 1 - it) : PD;
+      wait_lgkmcnt_for<2 * later>(fb[it % NB]);
+      if constexpr (tp == 0) wait_lgkmcnt_for<2 * later>(fa[ks]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((ABL & 4) == 0)
+        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks].v, fb[it % NB].v, acc[tp], 0, 0, 0);
+      else
+        asm volatile("" ::"v"(fa[ks].v), "v"(fb[it % NB].v));
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
 
-  // atomic accumulation into dW[n][tap*C + c]
+  // partial tile -> workspace slab of this pixel range (plain stores, summed in chunk order by the reduce kernel), or
+  // fp32 atomics straight into dW[n][tap*C + c]
+  const int K9 = 9 * a.C;
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
     const int c = c0 + wc * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (n < a.N && c < a.C && (ABL & 8) == 0) unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[tp][r] * a.alpha);
+      if (n < a.N && c < a.C && (ABL & 8) == 0) {
+        if (a.ws)
+          a.ws[((long)ci * a.N + n) * K9 + tp * a.C + c] = acc[tp][r];
+        else
+          unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[tp][r] * a.alpha);
+      }
     }
+  }
+}
+
+// dW[n][k] += alpha * sum over chunks of ws[chunk][n][k], chunks added in index order.  blockIdx.y splits the chunk
+// range when there are few columns and many chunks (layer1: 36 864 columns x 512 chunks); with more than one group the
+// groups meet in dW through atomics, with one group (layers 3-4) the sum is a plain read-modify-write.
+static __global__ void __launch_bounds__(256) wgrad_fused_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
+                                                                         int N, int K9, int ldw, int chunks,
+                                                                         int chunks_per_group, float alpha) {
+  const long quads = (long)N * K9 / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= quads) return;
+  const int c_begin = blockIdx.y * chunks_per_group;
+  const int c_end = min(chunks, c_begin + chunks_per_group);
+  floatx4 s = {0.f, 0.f, 0.f, 0.f};
+  const floatx4* p = reinterpret_cast<const floatx4*>(ws) + (long)c_begin * quads + i;
+  for (int c = c_begin; c < c_end; ++c, p += quads) s += *p;
+  const long e = i * 4;
+  const int n = (int)(e / K9), k = (int)(e - (long)n * K9);
+  float* d = dW + (long)n * ldw + k;
+  if (gridDim.y == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] += s[j] * alpha;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(d + j, s[j] * alpha);
   }
 }
 
@@ -236,6 +270,24 @@ inline bool wgrad_fused_applies(const WgradArgs& a) {
          (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
 }
 
+inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
+  if (!a.ws) return;
+  const int K9 = 9 * a.C;
+  const long quads = (long)a.N * K9 / 4;
+  // enough threads to pull the slabs at full bandwidth: split the chunk range over blockIdx.y while columns are few
+  int groups = (int)(131072 / quads);
+  if (groups > a.nchunks) groups = a.nchunks;
+  if (groups < 1) groups = 1;
+  const int per = cdiv(a.nchunks, groups);
+  groups = cdiv(a.nchunks, per);
+  hipLaunchKernelGGL(wgrad_fused_reduce_kernel, dim3(cdiv(quads, 256), groups), dim3(256), 0, stream, (const float*)a.ws, a.dW,
+                     a.N, K9, a.ldw, a.nchunks, per, a.alpha);
+}
+
+// floats of workspace a launch with `blocks` workgroups needs (a workgroup's partial tile is 64 x 9 x 64 at most)
+inline long wgrad_fused_ws_floats(int blocks) { return (long)blocks * 64 * 9 * 64; }
+constexpr int WGF_BLOCKS = 512;  // workgroups per launch: two per CU (the register budget), i.e. one round of the chip
+
 inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream) {
   constexpr int BKM = 32;
   const GatherGeom& g = w.g;
@@ -243,6 +295,7 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   a.dY = reinterpret_cast<const half*>(w.dY);
   a.X = reinterpret_cast<const half*>(w.X);
   a.dW = w.dW;
+  a.ws = nullptr;
   a.ldy = w.ldy;
   a.ldw = w.ldw;
   a.B = g.B; a.P = g.P; a.Q = g.Q; a.C = g.C; a.N = g.N;
@@ -260,12 +313,16 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   // pixel ranges: enough workgroups to fill the chip, but each at least 8 halos long (the ring prologue fetches
   // 2 Gpad + 32 rows that belong to the neighbouring ranges)
   const int pairs = a.tiles_n * a.tiles_c;
-  int chunks = cdiv(target_blocks, pairs);
+  static const int env_blocks = getenv("MN_WGF_BLOCKS") ? atoi(getenv("MN_WGF_BLOCKS")) : 0;  // tuning knob
+  (void)target_blocks;  // the plain-GEMM form's split count; this kernel wants exactly one round of resident workgroups
+  int chunks = cdiv(env_blocks > 0 ? env_blocks : WGF_BLOCKS, pairs);
   const int min_chunk = 16 * a.Gpad;
   if ((long)chunks * min_chunk > a.J) chunks = (int)(a.J / min_chunk);
   if (chunks < 1) chunks = 1;
   a.chunk = cdiv(cdiv(a.J, chunks), BKM) * BKM;
   a.nchunks = cdiv(a.J, a.chunk);
+  static const bool use_ws = !(getenv("MN_WGF_WS") && atoi(getenv("MN_WGF_WS")) == 0);
+  if (use_ws && w.ws && (long)a.nchunks * a.N * 9 * a.C <= w.ws_floats) a.ws = w.ws;
   static const bool trace = getenv("MN_TRACE_DISPATCH") != nullptr;
   if (trace)
     fprintf(stderr, "wgrad_fused: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows\n", a.B, a.P, a.Q, a.C,
@@ -274,22 +331,30 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
   switch (abl) {
-    case 1: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 1>), grid, dim3(256), 0, stream, a); return;
+    case 1: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 1>), grid, dim3(256), 0, stream, a); wgrad_fused_reduce(a, stream); return;
     case 2: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 2>), grid, dim3(256), 0, stream, a); return;
     case 3: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 3>), grid, dim3(256), 0, stream, a); return;
-    case 4: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 4>), grid, dim3(256), 0, stream, a); return;
+    case 4: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 4>), grid, dim3(256), 0, stream, a); wgrad_fused_reduce(a, stream); return;
     case 6: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 6>), grid, dim3(256), 0, stream, a); return;
     case 8: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 8>), grid, dim3(256), 0, stream, a); return;
     case 11: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 11>), grid, dim3(256), 0, stream, a); return;
     default: break;
   }
 #endif
+  static const int pd = getenv("MN_WGF_PD") ? atoi(getenv("MN_WGF_PD")) : 4;  // B fragments requested ahead (tuning knob)
   if (D == 1)
     hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 1>), grid, dim3(256), 0, stream, a);
   else if (D == 2)
     hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 2>), grid, dim3(256), 0, stream, a);
+  else if (pd == 1)
+    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 0, 1>), grid, dim3(256), 0, stream, a);
+  else if (pd == 2)
+    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 0, 2>), grid, dim3(256), 0, stream, a);
+  else if (pd >= 6)
+    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 0, 6>), grid, dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3>), grid, dim3(256), 0, stream, a);
+  wgrad_fused_reduce(a, stream);
 }
 
 }  // namespace mn

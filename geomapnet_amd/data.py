@@ -100,10 +100,22 @@ def process_poses(poses_in, mean_t, std_t, align_R, align_t, align_s):
     return poses_out
 
 
+def window_offsets(steps, skips, centre_shift=0):
+    """Frame offsets of one window relative to its index: the running sum of the `steps - 1` gaps, re-centred so the
+    middle frame (steps // 2; the reference's Python-2 integer division, composite.py:66) sits on the index, then shifted
+    by `centre_shift` (no_duplicates: half a window, so that window 0 starts at frame 0)."""
+    off = np.zeros(steps, dtype=np.int64)
+    off[1:] = np.cumsum(np.asarray(skips, dtype=np.int64))
+    return off - off[steps // 2] + centre_shift
+
+
 class MF(torch.utils.data.Dataset):
-    """Returns multiple consecutive frames, and optionally VOs (composite.py:18-102).  `dataset` is any indexable
-    dataset returning (image [3,H,W], pose [6]); with include_vos and real, `gt_dataset` + `dataset.gt_idx` supply
-    the absolute poses as in the reference."""
+    """Windows of `steps` frames `skip` apart around every index, optionally with VO targets: the batch layout contract
+    of dataset_loaders/composite.py:18-102 (same constructor, `get_indices`, item shapes), pinned by golden vectors
+    generated from the reference's own class (tests/golden/batch_construction.npz).  `dataset` is any indexable dataset
+    returning (image [3,H,W], pose [6]); with include_vos and real, `gt_dataset` + `dataset.gt_idx` supply the absolute
+    poses.  With a fixed skip the offsets are one precomputed table; with variable_skip every window draws its gaps from
+    numpy's global generator exactly as the reference does (`np.random.randint(1, skip + 1, steps - 1)`)."""
 
     def __init__(self, dataset, include_vos=False, no_duplicates=False, steps=2, skip=1, variable_skip=False, real=False,
                  train=True, vo_func=calc_vos_simple, gt_dataset=None):
@@ -114,46 +126,39 @@ class MF(torch.utils.data.Dataset):
         self.include_vos, self.train, self.vo_func, self.no_duplicates = include_vos, train, vo_func, no_duplicates
         self.dset, self.gt_dset = dataset, gt_dataset
         self.L = self.steps * self.skip
+        self._shift = (steps // 2) * skip if no_duplicates else 0
+        self._table = None if variable_skip else window_offsets(steps, [skip] * (steps - 1), self._shift)
 
     def get_indices(self, index):
-        if self.variable_skip:
-            skips = np.random.randint(1, high=self.skip + 1, size=self.steps - 1)
-        else:
-            skips = self.skip * np.ones(self.steps - 1)
-        offsets = np.insert(skips, 0, 0).cumsum()
-        offsets -= offsets[len(offsets) // 2]  # Python-2 integer division in the reference (:66)
-        if self.no_duplicates:
-            offsets += self.steps // 2 * self.skip
-        offsets = offsets.astype(int)
-        idx = index + offsets
-        idx = np.minimum(np.maximum(idx, 0), len(self.dset) - 1)
-        assert np.all(idx >= 0), "{:d}".format(index)
-        assert np.all(idx < len(self.dset))
-        return idx
+        off = self._table
+        if off is None:
+            off = window_offsets(self.steps, np.random.randint(1, high=self.skip + 1, size=self.steps - 1), self._shift)
+        return np.clip(index + off, 0, len(self.dset) - 1)  # windows at the sequence ends repeat the boundary frame
+
+    @staticmethod
+    def _frames(dataset, indices):
+        images, poses = zip(*(dataset[int(i)] for i in indices))
+        return torch.stack(images, dim=0), torch.stack(poses, dim=0)
 
     def __getitem__(self, index):
         idx = self.get_indices(index)
-        clip = [self.dset[i] for i in idx]
-        imgs = torch.stack([c[0] for c in clip], dim=0)
-        poses = torch.stack([c[1] for c in clip], dim=0)
-        if self.include_vos:
-            vos = self.vo_func(poses.unsqueeze(0))[0]
-            if self.real:  # absolute poses need to come from the GT dataset
-                clip = [self.gt_dset[self.dset.gt_idx[i]] for i in idx]
-                poses = torch.stack([c[1] for c in clip], dim=0)
-            poses = torch.cat((poses, vos), dim=0)
-        return imgs, poses
+        imgs, poses = self._frames(self.dset, idx)
+        if not self.include_vos:
+            return imgs, poses
+        vos = self.vo_func(poses.unsqueeze(0))[0]  # from THIS dataset's poses (possibly VO / noisy), :88
+        if self.real:  # the absolute half of the target comes from the ground-truth dataset, :90-94
+            _, poses = self._frames(self.gt_dset, [self.dset.gt_idx[i] for i in idx])
+        return imgs, torch.cat((poses, vos), dim=0)
 
     def __len__(self):
-        L = len(self.dset)
-        if self.no_duplicates:
-            L -= (self.steps - 1) * self.skip
-        return L
+        return len(self.dset) - ((self.steps - 1) * self.skip if self.no_duplicates else 0)
 
 
 class MFOnline(torch.utils.data.Dataset):
-    """a labelled window with absolute poses + an unlabelled window with real VOs (composite.py:104-126):
-    images [2*steps,3,H,W], poses [steps + (steps-1), 6] (or [2*steps, 6] in gps_mode)"""
+    """MapNet++ batches (composite.py:104-126): a labelled window with absolute poses followed by an unlabelled window
+    whose targets are real VOs -- images [2*steps,3,H,W], targets [steps + (steps-1), 6]; in gps_mode the second half
+    carries absolute (GPS) poses instead: [2*steps, 6].  Length and indexing follow the unlabelled set; the labelled set
+    is cycled."""
 
     def __init__(self, train_dataset, val_dataset, gps_mode=False, val_gt_dataset=None, **kwargs):
         self.gps_mode = gps_mode
@@ -162,11 +167,11 @@ class MFOnline(torch.utils.data.Dataset):
                           no_duplicates=True, gt_dataset=val_gt_dataset, **kwargs)
 
     def __getitem__(self, idx):
-        train_ims, train_poses = self.train_set[idx % len(self.train_set)]
-        val_ims, val_vos = self.val_set[idx % len(self.val_set)]  # val_vos contains abs poses if gps_mode
-        if not self.gps_mode:
-            val_vos = val_vos[len(val_ims):]
-        return torch.cat((train_ims, val_ims)), torch.cat((train_poses, val_vos))
+        lab_images, lab_poses = self.train_set[idx % len(self.train_set)]
+        unl_images, unl_targets = self.val_set[idx % len(self.val_set)]
+        # unl_targets = [absolute poses | VOs] (or absolute poses only in gps_mode): MapNet++ keeps the VO part
+        tail = unl_targets if self.gps_mode else unl_targets[unl_images.shape[0]:]
+        return torch.cat((lab_images, unl_images)), torch.cat((lab_poses, tail))
 
     def __len__(self):
         return len(self.val_set)

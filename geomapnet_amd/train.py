@@ -73,29 +73,27 @@ def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, tra
 
 
 # ---- checkpoints: /root/reference/common/train.py:22-53 (load_state_dict), :162-178 (resume), :198-204 (save) ----
+def _name_prefix(longer, shorter):
+    """`longer` == prefix + `shorter` -> prefix, else None"""
+    return longer[: len(longer) - len(shorter)] if longer.endswith(shorter) else None
+
+
 def load_state_dict(model, state_dict):
-    """Loads a state dict when the model (or the state dict) has some prefix before the parameter names, e.g. a
-    PoseNet checkpoint into MapNet (`mapnet.` prefix) or the reverse; the prefix is found from the first
-    parameter name (common/train.py:22-53)."""
-    model_names = [n for n, _ in model.named_parameters()]
-    state_names = [n for n in state_dict.keys()]
-    if model_names[0].find(state_names[0]) >= 0:
-        model_prefix = model_names[0].replace(state_names[0], "")
-        state_prefix = None
-    elif state_names[0].find(model_names[0]) >= 0:
-        state_prefix = state_names[0].replace(model_names[0], "")
-        model_prefix = None
+    """model.load_state_dict for checkpoints whose parameter names differ from the model's by a leading module path --
+    a PoseNet checkpoint into MapNet (`mapnet.` prefix) or the reverse (contract of common/train.py:22-53: the relation is
+    read off the FIRST parameter name of each side; names that are not related by a prefix raise KeyError)."""
+    model_first = next(iter(model.named_parameters()))[0]
+    state_first = next(iter(state_dict.keys()))
+    add = _name_prefix(model_first, state_first)       # the model's names carry an extra prefix
+    strip = _name_prefix(state_first, model_first)     # the checkpoint's names do
+    if add is None and strip is None:
+        raise KeyError("Could not find the correct prefixes between %s and %s" % (model_first, state_first))
+    if add is not None:
+        renamed = ((add + k, v) for k, v in state_dict.items())
     else:
-        raise KeyError("Could not find the correct prefixes between %s and %s" % (model_names[0], state_names[0]))
+        renamed = ((k[len(strip):] if k.startswith(strip) else k, v) for k, v in state_dict.items())
     from collections import OrderedDict
-    new_state_dict = OrderedDict()
-    for k, v in state_dict.items():
-        if state_prefix is None:
-            k = model_prefix + k
-        else:
-            k = k.replace(state_prefix, "")
-        new_state_dict[k] = v
-    model.load_state_dict(new_state_dict)
+    model.load_state_dict(OrderedDict(renamed))
 
 
 def save_checkpoint(filename, epoch, model, optimizer, criterion):

@@ -189,6 +189,13 @@ int mn_op_igemm_streamk(int dtype, const mn_gather_geom* g, const void* A, const
 /* dW[n][colmap(k)] += alpha * sum_m dY[m][n] * gather(X)[m][k]  (fp32 atomics into dW) */
 int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw,
                 const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream);
+/* The same operator with scratch for partial results: the 3x3 stride-1 fp16 layers (csrc/wgrad_fused.h) then store one
+ * partial tile per pixel range into `ws` (plain stores) and add the ranges up in index order in a second launch, instead
+ * of fp32 atomics into dW.  ws: device fp32 [ws_floats], ws_floats >= mn_op_wgrad_ws_floats(); launches sharing one
+ * workspace must be ordered on one stream.  Other layer shapes ignore the workspace. */
+int64_t mn_op_wgrad_ws_floats(void);
+int mn_op_wgrad_ws(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw, float alpha,
+                   float* ws, int64_t ws_floats, const void* zero_page, void* stream);
 /* fp16 3x3 stride-1 same-size convolution of 64 input channels (ResNet layer1 forward, and -- with the mirrored
  * geometry rsign = ssign = -1 -- its data gradient) with the 18x18-pixel input halo of a 16x16-pixel output tile staged
  * once in LDS and the taps walked as address offsets (csrc/halo.h); same operands and epilogue as mn_op_igemm plus

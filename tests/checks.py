@@ -249,7 +249,7 @@ def check_conv_halo(lib, dev, B, H, W, Cout=64, dgrad=False, mode="plain", seed=
         assert (sums[1] - (ref * ref).sum(0)).abs().max().item() <= 2e-3 * (ref * ref).sum(0).max().item()
 
 
-def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target_blocks=8, seed=2):
+def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target_blocks=8, seed=2, ws=False):
     _fresh()
     td = TD[dtype]
     gen = torch.Generator().manual_seed(seed)
@@ -260,8 +260,19 @@ def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target
     F.conv2d(x.double(), w, stride=stride, padding=pad).backward(gy.double())
     ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)
     dW = torch.zeros(Cout, k * k * Cin, device=dev)
-    lib.check(lib.op_wgrad(dtype, C.byref(g), K(_nhwc(gy, td, dev)), Cout, K(_nhwc(x, td, dev)), K(dW), k * k * Cin,
-                           None, f32(0.5), target_blocks, K(zero_page(dev)), None))
+    if ws:  # partial tiles through a workspace + ordered reduction (the plan's form), twice: results must be bit-identical
+        wsf = int(lib.op_wgrad_ws_floats())
+        wbuf = torch.full((wsf,), float("nan"), device=dev)
+        dW2 = torch.zeros_like(dW)
+        for out in (dW, dW2):
+            lib.check(lib.op_wgrad_ws(dtype, C.byref(g), K(_nhwc(gy, td, dev)), Cout, K(_nhwc(x, td, dev)), K(out), k * k * Cin,
+                                      f32(0.5), K(wbuf), wsf, K(zero_page(dev)), None))
+        dev_sync(dev)
+        if dtype == 1 and k == 3 and stride == 1 and Cout * 9 * Cin // 4 >= 131072:
+            assert torch.equal(dW, dW2)  # one reduction group: chunks are summed in index order, no atomics anywhere
+    else:
+        lib.check(lib.op_wgrad(dtype, C.byref(g), K(_nhwc(gy, td, dev)), Cout, K(_nhwc(x, td, dev)), K(dW), k * k * Cin,
+                               None, f32(0.5), target_blocks, K(zero_page(dev)), None))
     dev_sync(dev)
     assert (dW.cpu().double() - 0.5 * ref).abs().max().item() <= 2e-5 * ref.abs().max().item() * max(1, (B * Ho * Wo) ** 0.5 / 8)
 

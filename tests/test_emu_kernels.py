@@ -157,6 +157,14 @@ def test_conv_data_gradient_parity_random_geometry(lib, case):
     checks.check_conv_dgrad_op(lib, DEV, 0, B, H, W, 64, 128, 1, 2, 0, parity=1, mode="inplace", seed=H * 100 + W + 1)
 
 
+@pytest.mark.parametrize("shape", [(2, 9, 11, 64, 64, 3, 1, 1), (3, 20, 22, 128, 64, 3, 1, 1), (40, 3, 5, 64, 128, 3, 1, 1),
+                                   (2, 6, 7, 72, 80, 3, 1, 1), (2, 8, 11, 256, 256, 3, 1, 1)])
+def test_fused_weight_gradient_through_workspace(lib, shape):
+    """wgrad_fused.h with partial tiles stored to a (NaN-filled) workspace and added up by the reduce kernel, as the plan
+    runs it; bit-identical between two launches when a single reduction group covers the columns"""
+    checks.check_conv_wgrad(lib, DEV, 1, *shape, ws=True)
+
+
 def test_forced_288x256_configuration():
     """the 12-wave 288x256 tile (packed tap masks, joint A/B DMA passes, odd wave-row count) on small ragged problems,
     in a process of its own because the configuration knob is read once"""

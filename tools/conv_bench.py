@@ -52,6 +52,9 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
     t_d = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_r = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), ptr(gate), one, ptr(checks.zero_page("cuda")), None))
     t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, ptr(checks.zero_page("cuda")), None))
+    if dtype == 1 and k == 3 and stride == 1:  # the plan's form: partial tiles through a workspace + reduce launch
+        t_ws = timeit(lambda: lib.op_wgrad_ws(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, one, ptr(WS), WS.numel(), ptr(checks.zero_page("cuda")), None))
+        print("%-22s wgrad through the workspace %7.1f us %6.0f TF" % (name, t_ws, flops / t_ws / 1e6), flush=True)
     if dtype == 1 and Ci == 64 and k == 3 and stride == 1:
         th_f = timeit(lambda: lib.op_conv_halo(C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, 0, None, None, None, one, None))
         th_d = timeit(lambda: lib.op_conv_halo(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, None, one, None)) if Co == 64 else float("nan")
@@ -63,6 +66,7 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
 
 
 print("dtype", "fp16" if dtype else "fp32", "B", B)
+WS = torch.empty(int(lib.op_wgrad_ws_floats()), device="cuda")
 ONLY_GEMM = os.environ.get("CB_ONLY") == "gemm"
 if ONLY_GEMM:
     def bench(*a):  # noqa: F811

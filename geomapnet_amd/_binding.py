@@ -77,6 +77,7 @@ _PROTOS = {
     "mn_op_conv_halo_grid_m": (c_i, [C.POINTER(GatherGeom)]),
     "mn_op_conv_dgrad": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_i,
                                c_void, c_void]),
+    "mn_op_stem_conv": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),
     "mn_op_oihw_to_ohwi": (c_i, [c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),
     "mn_op_criterion": (c_i, [c_i, c_i, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_f, c_void]),
     "mn_op_calc_vos": (c_i, [c_void, c_i, c_i, c_void, c_void, c_void, c_void]),

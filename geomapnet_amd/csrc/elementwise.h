@@ -472,11 +472,12 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   constexpr int VEC = ElemTraits<T>::VEC;
   const float* sg_gamma = self_gate_beta ? gamma : nullptr;
   if (self_gate_beta) gate = nullptr;
-  // ~1024 workgroups (4 per CU): the reduction is HBM-bound and needs the whole chip, but every workgroup ends with an LDS
+  // ~512 workgroups (2 per CU): the reduction is HBM-bound and needs the whole chip, but every workgroup ends with an LDS
   // reduction and 2 x C fp64 atomics -- at 4096 workgroups (round 1) layers 3-4 did ONE loop iteration per workgroup and
-  // that epilogue weighed as much as the loads (MN_BN_REDUCE_BLOCKS: 4096 -> 1024 = -1.2 % step time, same-box A/B)
+  // that epilogue weighed as much as the loads (MN_BN_REDUCE_BLOCKS, same-box A/Bs of the whole step: 4096 17.77 ms,
+  // 1024 17.60, 512 17.42, 256 17.97)
   static const long target = getenv("MN_BN_REDUCE_BLOCKS") && atol(getenv("MN_BN_REDUCE_BLOCKS")) > 0
-                                 ? atol(getenv("MN_BN_REDUCE_BLOCKS")) : 1024;
+                                 ? atol(getenv("MN_BN_REDUCE_BLOCKS")) : 512;
   const int rlanes = 256 / (C / VEC);
   long rows = (M + target - 1) / target;
   rows = ((rows + rlanes - 1) / rlanes) * rlanes;

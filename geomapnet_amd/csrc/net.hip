@@ -20,6 +20,7 @@
 #include "layout.h"
 #include "optim.h"
 #include "pool.h"
+#include "stem.h"
 #include "util.h"
 #include "wgrad.h"
 
@@ -610,7 +611,9 @@ struct Plan : PlanBase {
     ep.sk_ws = sk_ws;
     ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
-    if (halo_path(u.gf))
+    if (&u == &stem && DT == MN_F16 && use_stem_kernel)  // weights in registers, input pairs read straight from LDS (stem.h)
+      launch_stem_conv((const half*)x, (const half*)u.wf, (half*)u.y, training ? u.accum_f : nullptr, ACC_ROWS, B, H, W, Wp, s);
+    else if (halo_path(u.gf))
       launch_conv_halo(u.gf, (const half*)x, (const half*)u.wf, ep, s);
     else
       launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
@@ -618,6 +621,7 @@ struct Plan : PlanBase {
   }
   // layer1's 64-channel 3x3 convolutions (forward and data gradient) run from an LDS-resident input halo (halo.h)
   bool use_halo = DT == MN_F16 && !(getenv("MN_HALO") && atoi(getenv("MN_HALO")) == 0);
+  bool use_stem_kernel = !(getenv("MN_STEM_KERNEL") && atoi(getenv("MN_STEM_KERNEL")) == 0);
   bool halo_path(const GatherGeom& g) const { return use_halo && conv_halo_applies(g); }
   void bn_finalize(Unit& u, hipStream_t s) {  // statistics -> (scale, shift), mean / invstd, running statistics
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(u.cp.cout, 256)), dim3(256), 0, s, (const double*)u.accum_f, (double)u.M,

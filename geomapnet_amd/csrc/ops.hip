@@ -13,6 +13,7 @@
 #include "optim.h"
 #include "pgo.h"
 #include "pool.h"
+#include "stem.h"
 #include "wgrad.h"
 #include "util.h"
 
@@ -137,6 +138,15 @@ static int op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy
   else
     launch_wgrad<float>(a, target_blocks, (hipStream_t)stream);
   return check_launch("wgrad");
+}
+
+extern "C" int mn_op_stem_conv(const void* xpad, const void* wf, void* y, double* stats_accum, int stats_rows, int B, int H, int W,
+                               int Wp, void* stream) {
+  begin_call();
+  if (Wp % 2 != 0 || Wp < W + 7) return fail("stem_conv: Wp must be even and >= W + 7");
+  if ((long)B * (H + 6) * Wp * 8 >= 0xfffffff0l) return fail("stem_conv: padded input exceeds 4 GiB");
+  launch_stem_conv((const half*)xpad, (const half*)wf, (half*)y, stats_accum, stats_rows, B, H, W, Wp, (hipStream_t)stream);
+  return check_launch("stem_conv");
 }
 
 extern "C" int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream) {

@@ -1,0 +1,154 @@
+// Stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels: torchvision ResNet conv1, call site
+// /root/reference/models/posenet.py:65 through feature_extractor) for fp16 tensors, forward.
+//
+// The implicit-GEMM kernel (igemm.h) treats the stem as a 7x4 convolution over pixel PAIRS of the zero-padded NHWC4 image
+// (K = 7 * 4 * 8 = 224) and stages an im2col tile per workgroup: 128 rows x 448 B of A plus the 28 KB weight matrix per
+// 128 output pixels -- 85 KB of LDS-DMA for 900 matrix-core cycles, i.e. the launch runs at the DMA rate (392 us for 79
+// GFLOP; its HBM floor -- 538 MB of output, 140 MB of input -- is ~130 us).  Here nothing is im2col'd:
+//   * the WEIGHTS (28 KB) live in registers: 14 K-steps x 2 column tiles x 4 VGPRs = 112 per lane, loaded once;
+//   * a workgroup owns an 8 x 32-pixel output tile and DMAs the 21 x 35 pixel pairs it reads (11.8 KB) into LDS once;
+//   * the A fragment of MFMA step (r, kk) for output pixel x is ONE 16-byte pair -- row 2y + r, pair x + 2 kk + (lane >> 5)
+//     of that image -- read straight from LDS (consecutive lanes = consecutive pairs: conflict-free ds_read_b128).
+// One wave computes two output rows of 32 pixels x 64 channels (28 MFMAs each), rounds to fp16 through a private 4 KB
+// LDS staging block (16-byte stores along channels) and keeps the BatchNorm column sums of its pixels; the workgroup
+// adds them into the fp64 accumulator rows like igemm's epilogue.
+#pragma once
+#include "igemm.h"
+
+namespace mn {
+
+struct StemArgs {
+  const half* xpad;  // [B][Hp][Wp][4] zero-padded input (pad 3 top/left): pixel pairs of 16 bytes, Wp even
+  const half* wf;    // [64][224] weights in the pair layout (optim.h, repack mode 2)
+  half* y;           // [B][H0][W0][64] raw conv output
+  double* stats_accum;  // [stats_rows][2][64] fp64 column sums (sum, sum of squares), added to atomically; or null
+  int stats_rows;
+  int B, Hp, Wp2;    // Wp2 = Wp / 2 pairs per padded row
+  int H0, W0;
+  int tiles_x, tiles_y;
+};
+
+constexpr int kStemTH = 8, kStemTW = 32;
+
+static __global__ void __launch_bounds__(256, 2) stem_conv_kernel(StemArgs a) {
+  constexpr int TH = kStemTH, TW = kStemTW;
+  constexpr int IH = 2 * TH + 5, IW = TW + 3, IPIECES = IH * IW;  // 21 rows x 35 pairs
+  constexpr int IPASS = (IPIECES + 255) / 256;
+  // ONE LDS object: [input image][4 staging blocks of 32 pixels x 64 halves][column sums 4 x 64 x 2 floats]
+  __shared__ piece_t smem[IPASS * 256 + 4 * 256 + 128];
+  piece_t* stage_all = &smem[IPASS * 256];
+  float* red = reinterpret_cast<float*>(&smem[IPASS * 256 + 4 * 256]);
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int txi = tile % a.tiles_x;
+  int tmp = tile / a.tiles_x;
+  const int tyi = tmp % a.tiles_y;
+  const int b = tmp / a.tiles_y;
+  const int y0 = tyi * TH, x0 = txi * TW;
+
+  // ---- input image: one DMA sweep (rows 2 y0 .. 2 y0 + 20 of the padded image, pairs x0 .. x0 + 34)
+  const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.xpad, (long)a.B * a.Hp * a.Wp2 * 16L);
+#pragma unroll
+  for (int i = 0; i < IPASS; ++i) {
+    const int q = t + i * 256;
+    const int row = q / IW, col = q - row * IW;
+    const int iy = 2 * y0 + row, ip = x0 + col;
+    const bool ok = q < IPIECES && iy < a.Hp && ip < a.Wp2;
+    const unsigned off = ok ? (unsigned)(((b * a.Hp + iy) * a.Wp2 + ip) * 16) : ~0u;
+    dma16(rsrc, off, 0u, &smem[wave * 64 + i * 256]);
+  }
+
+  // ---- weights -> registers while the image is in flight: B fragment of step s, column tile j = 8 halves of row
+  // n = 32 j + (lane & 31) at k = 16 s + 8 (lane >> 5)
+  PieceView<half> wb[14][2];
+  {
+    const half* wrow = a.wf + (lane & 31) * 224 + (lane >> 5) * 8;
+#pragma unroll
+    for (int s = 0; s < 14; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wb[s][j].p = *reinterpret_cast<const piece_t*>(wrow + j * 32 * 224 + s * 16);
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();  // the image is complete for every wave
+
+  const int l31 = lane & 31, kh = lane >> 5;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  half* stage = reinterpret_cast<half*>(stage_all + wave * 256);  // [32 pixels][64 channels]
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int ty = 2 * wave + rr;  // tile row of this pass
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const piece_t* img = &smem[(2 * ty) * IW + l31 + kh];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+      PieceView<half> fa;
+      fa.p = img[(s >> 1) * IW + 2 * (s & 1)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.v, wb[s][j].v, acc[j], 0, 0, 0);
+    }
+    // epilogue of the row: column sums over the pixels inside the image, fp16 through the wave's staging block
+    const int oy = y0 + ty;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float v = acc[j][r];
+        const bool ok = oy < a.H0 && x0 + px < a.W0;
+        const float vs = ok ? v : 0.f;
+        s1[j] += vs;
+        s2[j] += vs * vs;
+        stage[px * 64 + j * 32 + l31] = (half)v;
+      }
+    // (same wave wrote and reads the block: the compiler's lgkmcnt wait orders the two)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = lane + 64 * i, px = id >> 3, cp = id & 7;
+      const piece_t v = *reinterpret_cast<const piece_t*>(stage + px * 64 + cp * 8);
+      if (oy < a.H0 && x0 + px < a.W0)
+        *reinterpret_cast<piece_t*>(a.y + (((long)b * a.H0 + oy) * a.W0 + x0 + px) * 64 + cp * 8) = v;
+    }
+  }
+  if (a.stats_accum) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+      if (lane < 32) {
+        red[(wave * 64 + j * 32 + lane) * 2 + 0] = s1[j];
+        red[(wave * 64 + j * 32 + lane) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (t < 64) {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        sa += red[(w * 64 + t) * 2 + 0];
+        sb += red[(w * 64 + t) * 2 + 1];
+      }
+      double* row = a.stats_accum + (long)(tile % a.stats_rows) * 2 * 64;
+      atomicAdd(row + t, (double)sa);
+      atomicAdd(row + 64 + t, (double)sb);
+    }
+  }
+}
+
+// xpad: [B][H + 6][Wp][4] with Wp even >= W + 7; y: [B][H0][W0][64], H0 = (H - 1) / 2 + 1, W0 = (W - 1) / 2 + 1
+inline void launch_stem_conv(const half* xpad, const half* wf, half* y, double* stats_accum, int stats_rows, int B, int H, int W,
+                             int Wp, hipStream_t stream) {
+  StemArgs a;
+  a.xpad = xpad; a.wf = wf; a.y = y; a.stats_accum = stats_accum; a.stats_rows = stats_rows > 0 ? stats_rows : 1;
+  a.B = B; a.Hp = H + 6; a.Wp2 = Wp / 2;
+  a.H0 = (H - 1) / 2 + 1; a.W0 = (W - 1) / 2 + 1;
+  a.tiles_x = cdiv(a.W0, kStemTW); a.tiles_y = cdiv(a.H0, kStemTH);
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(B * a.tiles_x * a.tiles_y), dim3(256), 0, stream, a);
+}
+
+}  // namespace mn

@@ -50,26 +50,40 @@ struct WgradFusedArgs {
   float alpha;
 };
 
-constexpr int WGF_RING_MAX = 320;  // rows: 4 steps + 2 Gpad; bounds the image width (Gpad <= 96 -> Q <= 94, i.e. inputs up to 376 px wide at layer1)
+// LDS rows of the X ring: (D+1) steps + 2 Gpad; bounds the image width (Gpad <= 96 -> Q <= 94, i.e. inputs up to 376
+// pixels wide at layer1).  4-wave form: 32-row steps; 8-wave form: 64-row steps.
+constexpr int WGF_RING_MAX4 = 320, WGF_RING_MAX8 = 448;
 
+// NW = 4: 256 threads, 32-pixel steps, two workgroups per CU.
+// NW = 8: 512 threads, 64-pixel steps, one workgroup per CU; waves 0-3 and 4-7 hold the SAME 64 x 9 x 64 output tile and
+//         split every step's pixels between them (rows 0-31 / 32-63) -- split-K inside the workgroup.  At the end the two
+//         halves are added through LDS, so a CU flushes ONE partial tile instead of two: the partial-tile volume of a
+//         launch (what the reduce launch has to read back) is the number of resident accumulator tiles x 147 KB,
+//         75 MB at two workgroups per CU, 38 MB here.
 // ABL (timing experiments only, MN_WGF_ABLATE in the ablation build; results are wrong): bit 0 = no DMA after the prologue,
-// bit 1 = no B-fragment reads, bit 2 = no MFMA, bit 3 = no atomics.
-// PD: B fragments requested ahead of the MFMA that consumes them.  With PD = 1 (round-2 first version) every MFMA waited
-// for an LDS round trip issued one MFMA (32 cycles) earlier: 3000 cycles per step instead of 18 x 32.
-template <int BKM, int D, int ABL = 0, int PD = 4>
-static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedArgs a) {
-  static_assert(BKM == 32, "one DMA pass of 256 threads per operand and step");
+// bit 1 = no B-fragment reads, bit 2 = no MFMA, bit 3 = no stores / atomics.
+// PD: B fragments requested ahead of the MFMA that consumes them.
+// The K loop is issue-bound, not MFMA- or LDS-bound (round-2 ablations: removing the MFMAs changed nothing): one item is
+// ONE vector add (scalar ring base + per-lane tap offset), two transpose reads, one counted wait and one MFMA.  No item
+// ever wraps around the ring: the 32/64 rows behind the ring mirror its first block (the DMA that fills block 0 is issued
+// twice), so a tap window that starts near the end simply runs on into the mirror.
+template <int NW, int D, int ABL = 0, int PD = 4>
+static __global__ void __launch_bounds__(NW * 64, 2) wgrad_fused_kernel(WgradFusedArgs a) {
+  static_assert(NW == 4 || NW == 8, "one or two wave groups");
   static_assert(D >= 1 && D <= 3, "steps in flight");
+  constexpr int BKM = 8 * NW;              // pixels per step = one DMA pass of all threads per operand
   constexpr int ROWH = 64;                 // halves per LDS row (64 channels / 64 output channels)
   constexpr int TILE_Y = BKM * ROWH;       // halves
   constexpr int NY = D + 1;                // dY tiles
-  // ONE LDS object: [NY dY tiles][X ring]
-  __shared__ half smem[NY * TILE_Y + WGF_RING_MAX * ROWH] __attribute__((aligned(16)));
+  constexpr int RING_MAX = NW == 4 ? WGF_RING_MAX4 : WGF_RING_MAX8;
+  // ONE LDS object: [NY dY tiles][X ring (RING rows used)][mirror of ring rows 0 .. BKM-1, right behind row RING-1]
+  __shared__ half smem[NY * TILE_Y + (RING_MAX + BKM) * ROWH] __attribute__((aligned(16)));
   half* ring = &smem[NY * TILE_Y];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = wave >> 1, wc = wave & 1;  // 32-row block of the 64 output channels, 32-column block of the 64 inputs
+  const int grp = wave >> 2, wg = wave & 3;  // pixel half of every step; role inside the group
+  const int wn = wg >> 1, wc = wg & 1;       // 32-row block of the 64 output channels, 32-column block of the 64 inputs
   // logical id = (chunk, pair): the pairs of one pixel range are adjacent, i.e. on one XCD, and share its L2 lines
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int pairs = a.tiles_n * a.tiles_c;
@@ -83,7 +97,7 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
   const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dY, (long)a.B * a.P * a.Q * a.ldy * 2L);
   const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X, (long)a.B * a.P * a.Q * a.C * 2L);
 
-  // DMA role of this thread: row t/8 of a 32-row block, 16-byte slot t%8; LDS slot s of row r holds source piece
+  // DMA role of this thread: row t/8 of a BKM-row block, 16-byte slot t%8; LDS slot s of row r holds source piece
   // s ^ swz(r), and every block starts at a multiple of 32 rows, so the source piece is fixed per thread
   const int drow = t >> 3, dslot = t & 7;
   const int dpiece = dslot ^ wg_swz<8>(drow);
@@ -96,17 +110,20 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
     const int b = fastdiv(r, a.dp), p = r - b * (a.P + 1);
     return (q < a.Q && p < a.P) ? (b * a.P + p) * a.Q + q : -1;
   };
-  auto issue_y = [&](int step) {  // positions [j0 + 32 step, + 32) of dY -> tile step % NY (zero past the chunk's end)
+  auto issue_y = [&](int step) {  // positions [j0 + BKM step, + BKM) of dY -> tile step % NY (zero past the chunk's end)
     const int j = j0 + step * BKM + drow;
     const int m = j < j1 ? pixel_of(j) : -1;
     const unsigned off = (m >= 0 && y_ok) ? (unsigned)m * (unsigned)(a.ldy * 2) + ycol : ~0u;
     dma16(rsrc_y, off, 0u, &smem[(step % NY) * TILE_Y + wave * 64 * 8]);
   };
-  auto issue_x = [&](int u0) {  // ring-relative rows [u0, u0 + 32): positions j0 - Gpad + u0 + ..
+  auto issue_x = [&](int u0) {  // ring-relative rows [u0, u0 + BKM): positions j0 - Gpad + u0 + ..
     const int m = pixel_of(j0 - Gpad + u0 + drow);
     const unsigned off = (m >= 0 && x_ok) ? (unsigned)m * (unsigned)(a.C * 2) + xcol : ~0u;
-    int rr = u0 % RING;  // wave-uniform; blocks never straddle the end (RING and u0 are multiples of 32)
+    const int rr = u0 % RING;  // wave-uniform; blocks never straddle the end (RING and u0 are multiples of BKM)
     dma16(rsrc_x, off, 0u, ring + rr * ROWH + wave * 64 * 8);
+    // block 0 also goes to the mirror.  (One more DMA instruction in the queue on these steps: the counted waits below
+    // then wait for one instruction more than they need to, never for one fewer -- retirement is in order.)
+    if (rr == 0) dma16(rsrc_x, off, 0u, ring + RING * ROWH + wave * 64 * 8);
   };
 
   floatx16 acc[9];
@@ -119,25 +136,27 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
   // SOURCE lane this lane addresses row lrow = kgrp + (lane & 15) / 4 and the 8-byte chunk (lane & 3) of its column block
   const int gq = lane >> 4, i16 = lane & 15;
   const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
-  const int lrow = (gq >> 1) * 8 + src_row;
+  const int lrow = grp * 32 + (gq >> 1) * 8 + src_row;  // + this wave group's half of the step
   const unsigned lds0 = lds_addr_of(smem);
   // A operand (dY tile): row lrow, column wn*32 + src_chunk; the swizzle sees row & 3 = src_row
   const int colA = wn * 32 + src_chunk;
   const unsigned aA = lds0 + (unsigned)((lrow * ROWH + (((colA >> 3) ^ wg_swz<8>(src_row)) * 8) + (colA & 7)) * 2);
-  // B operand (X ring): per tap the column term depends on (window start + src_row) & 3; window starts are
-  // Gpad + 32 s + shift (mod RING, a multiple of 4), so the key is loop invariant per tap
+  // B operand (X ring), tap tp: byte address = ring + rbB[tp] (scalar: first row of the tap's window, advanced per step)
+  // + xoffB[tp] (lane: row lrow, column with the swizzle of (window start + src_row) & 3 -- window starts move in
+  // multiples of 4, so the key is loop invariant per tap) + an immediate for the K sub-step
   const int colB = wc * 32 + src_chunk;
-  unsigned xcolB[9];
-  int shift[9];
+  unsigned xoffB[9];
+  int rbB[9];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
-    shift[tp] = (tp / 3 - 1) * a.Qp + (tp % 3 - 1);
-    const int key = (Gpad + shift[tp] + src_row) & 3;  // Gpad + shift >= 0
-    xcolB[tp] = (unsigned)((((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
+    const int sh = Gpad + (tp / 3 - 1) * a.Qp + (tp % 3 - 1);  // in [0, 2 Gpad] < RING
+    const int key = (sh + src_row) & 3;
+    xoffB[tp] = lds0 + (unsigned)((NY * TILE_Y + lrow * ROWH + ((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
+    rbB[tp] = sh * (ROWH * 2);
   }
-  const unsigned ringB = lds0 + (unsigned)(NY * TILE_Y * 2);
+  const int ring_bytes = RING * ROWH * 2;
 
-  // prologue: the halo rows [0, 2 Gpad), then steps 0 .. D-1 (dY tile + 32 ring rows each), in the order the waits count
+  // prologue: the halo rows [0, 2 Gpad), then steps 0 .. D-1 (dY tile + BKM ring rows each), in the order the waits count
   for (int u0 = 0; u0 < 2 * Gpad; u0 += BKM) issue_x(u0);
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -147,8 +166,8 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
     }
 
   for (int s = 0; s < nsteps; ++s) {
-    // steps issued so far: min(nsteps, s + D), two DMA instructions each, retired in order: step s has landed when at
-    // most the later ones are outstanding
+    // steps issued so far: min(nsteps, s + D), at least two DMA instructions each, retired in order: step s has landed
+    // when at most the later ones are outstanding
     const int ahead = min(nsteps, s + D) - (s + 1);
     if (D >= 3 && ahead >= 2)
       wait_vmcnt<4>();
@@ -157,16 +176,15 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // step s visible to everyone; everyone is done with step s-1's reads
-    if (s + D < nsteps && (ABL & 1) == 0) {  // into dY tile (s - 1) % NY and the 32 ring rows behind the live + in-flight window
+    if (s + D < nsteps && (ABL & 1) == 0) {  // into dY tile (s - 1) % NY and the ring rows behind the live + in-flight window
       issue_y(s + D);
       issue_x(2 * Gpad + BKM * (s + D));
     }
     const unsigned tyA = aA + (unsigned)((s % NY) * TILE_Y * 2);
-    const int w0 = (Gpad + BKM * s) % RING;  // ring row of the unshifted window (scalar)
-    // One step = 18 (K sub-step, tap) items, each one MFMA fed by the step's A fragment of that sub-step and a B fragment
-    // read at the tap's row shift.  B fragments travel through a ring of PD + 1 register buffers: item i + PD is requested
-    // right before the MFMA of item i (its buffer was last used by item i - 1, whose MFMA has been issued).
-    constexpr int NKS = BKM / 16, ITEMS = NKS * 9, NB = PD + 1;
+    // One step = 18 (K sub-step, tap) items per wave, each one MFMA fed by the A fragment of that sub-step and a B
+    // fragment read at the tap's row shift.  B fragments travel through a ring of PD + 1 register buffers: item i + PD is
+    // requested right before the MFMA of item i (its buffer was last used by item i - 1, whose MFMA has been issued).
+    constexpr int NKS = 2, ITEMS = NKS * 9, NB = PD + 1;
     static_assert(2 * PD <= 15, "lgkmcnt field");
     TrFrag fa[NKS], fb[NB];
     __builtin_amdgcn_sched_barrier(0);
@@ -175,7 +193,6 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
       fa[ks].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, tyA);
       fa[ks].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, tyA);
     });
-    // B fragment of item I = (ks, tp): rows (w0 + shift[tp] + 16 ks + {0, 4} + lrow) mod RING
     auto read_b = [&](auto I, TrFrag& f) {
       constexpr int it = decltype(I)::value, ks = it / 9, tp = it % 9;
       if constexpr ((ABL & 2) != 0) {
@@ -183,19 +200,9 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
         f.h[1] = fa[ks].h[0];
         return;
       }
-      int rb = w0 + shift[tp];  // in (-RING, 2 RING)
-      rb = rb < 0 ? rb + RING : (rb >= RING ? rb - RING : rb);
-      if (rb + BKM <= RING) {  // wave-uniform: the 32-row window does not wrap
-        const unsigned ad = ringB + (unsigned)((rb + lrow) * (ROWH * 2)) + xcolB[tp];
-        f.h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, ad);
-        f.h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, ad);
-      } else {
-        int r0 = rb + lrow + ks * 16, r1 = r0 + 4;
-        r0 = r0 >= RING ? r0 - RING : r0;
-        r1 = r1 >= RING ? r1 - RING : r1;
-        f.h[0] = ds_read_tr16_at<0>(smem, ringB + (unsigned)(r0 * (ROWH * 2)) + xcolB[tp]);
-        f.h[1] = ds_read_tr16_at<0>(smem, ringB + (unsigned)(r1 * (ROWH * 2)) + xcolB[tp]);
-      }
+      const unsigned ad = xoffB[tp] + (unsigned)rbB[tp];
+      f.h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, ad);
+      f.h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, ad);
     };
     static_for<(PD < ITEMS ? PD : ITEMS)>([&](auto I) { read_b(I, fb[decltype(I)::value % NB]); });
     static_for<ITEMS>([&](auto I) {
@@ -213,6 +220,50 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
         asm volatile("" ::"v"(fa[ks].v), "v"(fb[it % NB].v));
       __builtin_amdgcn_sched_barrier(0);
     });
+    // the tap windows move on by one step (scalar)
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      rbB[tp] += BKM * ROWH * 2;
+      rbB[tp] -= rbB[tp] >= ring_bytes ? ring_bytes : 0;
+    }
+  }
+
+  int tp_lo = 0, tp_hi = 9;  // taps this wave flushes
+  if constexpr (NW == 8) {
+    // the two wave groups hold partial sums of the same tile: group 1 hands taps 0-4 to group 0, group 0 hands taps 5-8
+    // to group 1 (through LDS, lane-contiguous), then each flushes its share
+    float* xch = reinterpret_cast<float*>(smem);
+    static_assert((NY * TILE_Y + (RING_MAX + BKM) * ROWH) * 2 >= 4 * 5 * 16 * 64 * 4, "exchange buffer");
+    __syncthreads();  // every fragment read of the K loop is done
+    if (grp == 1) {
+#pragma unroll
+      for (int tp = 0; tp < 5; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[((wg * 5 + tp) * 16 + r) * 64 + lane] = acc[tp][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int tp = 0; tp < 5; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] += xch[((wg * 5 + tp) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int tp = 5; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[((wg * 4 + tp - 5) * 16 + r) * 64 + lane] = acc[tp][r];
+    }
+    __syncthreads();
+    if (grp == 1) {
+#pragma unroll
+      for (int tp = 5; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] += xch[((wg * 4 + tp - 5) * 16 + r) * 64 + lane];
+    }
+    tp_lo = grp == 0 ? 0 : 5;
+    tp_hi = grp == 0 ? 5 : 9;
   }
 
   // partial tile -> workspace slab of this pixel range (plain stores, summed in chunk order by the reduce kernel), or
@@ -220,6 +271,7 @@ static __global__ void __launch_bounds__(256, 2) wgrad_fused_kernel(WgradFusedAr
   const int K9 = 9 * a.C;
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
+    if (tp < tp_lo || tp >= tp_hi) continue;  // wave-uniform
     const int c = c0 + wc * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -266,7 +318,7 @@ inline bool wgrad_fused_applies(const WgradArgs& a) {
   const GatherGeom& g = a.g;
   return g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.rsign == 1 && g.ssign == 1 && g.off_h == -1 &&
          g.off_w == -1 && g.P == g.Hi && g.Q == g.Wi && g.C % 8 == 0 && g.N % 8 == 0 && a.colmap == nullptr && a.ldw >= 9 * g.C &&
-         4 * 32 + 2 * (((g.Q + 2 + 15) / 16) * 16) <= WGF_RING_MAX && (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l &&
+         ((g.Q + 2 + 31) / 32) * 32 <= 96 && (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l &&
          (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
 }
 
@@ -288,9 +340,14 @@ inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
 inline long wgrad_fused_ws_floats(int blocks) { return (long)blocks * 64 * 9 * 64; }
 constexpr int WGF_BLOCKS = 512;  // workgroups per launch: two per CU (the register budget), i.e. one round of the chip
 
+inline int wgrad_fused_waves() {  // 8 (default): one 512-thread workgroup per CU with in-workgroup split-K; 4: two 256-thread ones
+  static const int nw = getenv("MN_WGF_WAVES") ? atoi(getenv("MN_WGF_WAVES")) : 8;
+  return nw == 4 ? 4 : 8;
+}
+
 inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream) {
-  constexpr int BKM = 32;
   const GatherGeom& g = w.g;
+  const int NW = wgrad_fused_waves(), BKM = 8 * NW;
   WgradFusedArgs a;
   a.dY = reinterpret_cast<const half*>(w.dY);
   a.X = reinterpret_cast<const half*>(w.X);
@@ -304,18 +361,18 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   a.tiles_n = cdiv(g.N, 64);
   a.tiles_c = cdiv(g.C, 64);
   a.Gpad = ((g.Q + 2 + 15) / 16) * 16;
-  static const int depth = getenv("MN_WGF_DEPTH") ? atoi(getenv("MN_WGF_DEPTH")) : 3;  // DMA steps in flight (1..3)
-  const int D = depth < 1 ? 1 : (depth > 3 ? 3 : depth);
+  if (NW == 8) a.Gpad = ((a.Gpad + 31) / 32) * 32;  // 2 Gpad must be a multiple of the 64-row DMA block
+  constexpr int D = 3;  // DMA steps in flight
   a.ring = (D + 1) * BKM + 2 * a.Gpad;
   a.dq = make_fastdiv(a.Qp);
   a.dp = make_fastdiv(g.P + 1);
   a.alpha = w.alpha;
-  // pixel ranges: enough workgroups to fill the chip, but each at least 8 halos long (the ring prologue fetches
-  // 2 Gpad + 32 rows that belong to the neighbouring ranges)
+  // pixel ranges: one round of resident workgroups (two 4-wave or one 8-wave workgroup per CU), each range at least 8
+  // halos long (the ring prologue fetches 2 Gpad + D steps of rows that belong to the neighbouring ranges)
   const int pairs = a.tiles_n * a.tiles_c;
   static const int env_blocks = getenv("MN_WGF_BLOCKS") ? atoi(getenv("MN_WGF_BLOCKS")) : 0;  // tuning knob
   (void)target_blocks;  // the plain-GEMM form's split count; this kernel wants exactly one round of resident workgroups
-  int chunks = cdiv(env_blocks > 0 ? env_blocks : WGF_BLOCKS, pairs);
+  int chunks = cdiv(env_blocks > 0 ? env_blocks : (NW == 8 ? WGF_BLOCKS / 2 : WGF_BLOCKS), pairs);
   const int min_chunk = 16 * a.Gpad;
   if ((long)chunks * min_chunk > a.J) chunks = (int)(a.J / min_chunk);
   if (chunks < 1) chunks = 1;
@@ -325,35 +382,31 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   if (use_ws && w.ws && (long)a.nchunks * a.N * 9 * a.C <= w.ws_floats) a.ws = w.ws;
   static const bool trace = getenv("MN_TRACE_DISPATCH") != nullptr;
   if (trace)
-    fprintf(stderr, "wgrad_fused: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows\n", a.B, a.P, a.Q, a.C,
-            a.N, a.chunk, a.nchunks, pairs, a.ring);
-  const dim3 grid(a.nchunks * pairs);
+    fprintf(stderr, "wgrad_fused<%d waves>: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows, ws %d\n", NW,
+            a.B, a.P, a.Q, a.C, a.N, a.chunk, a.nchunks, pairs, a.ring, a.ws != nullptr);
+  const dim3 grid(a.nchunks * pairs), block(NW * 64);
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
-  switch (abl) {
-    case 1: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 1>), grid, dim3(256), 0, stream, a); wgrad_fused_reduce(a, stream); return;
-    case 2: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 2>), grid, dim3(256), 0, stream, a); return;
-    case 3: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 3>), grid, dim3(256), 0, stream, a); return;
-    case 4: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 4>), grid, dim3(256), 0, stream, a); wgrad_fused_reduce(a, stream); return;
-    case 6: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 6>), grid, dim3(256), 0, stream, a); return;
-    case 8: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 8>), grid, dim3(256), 0, stream, a); return;
-    case 11: hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 11>), grid, dim3(256), 0, stream, a); return;
-    default: break;
+  if (NW == 8) {
+    switch (abl) {
+      case 1: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 1>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
+      case 2: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 2>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
+      case 4: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 4>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
+      case 8: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 8>), grid, block, 0, stream, a); return;
+      case 9: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 9>), grid, block, 0, stream, a); return;
+      default: break;
+    }
   }
 #endif
   static const int pd = getenv("MN_WGF_PD") ? atoi(getenv("MN_WGF_PD")) : 4;  // B fragments requested ahead (tuning knob)
-  if (D == 1)
-    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 1>), grid, dim3(256), 0, stream, a);
-  else if (D == 2)
-    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 2>), grid, dim3(256), 0, stream, a);
-  else if (pd == 1)
-    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 0, 1>), grid, dim3(256), 0, stream, a);
+  if (NW == 4)
+    hipLaunchKernelGGL((wgrad_fused_kernel<4, D>), grid, block, 0, stream, a);
   else if (pd == 2)
-    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 0, 2>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 0, 2>), grid, block, 0, stream, a);
   else if (pd >= 6)
-    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3, 0, 6>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 0, 6>), grid, block, 0, stream, a);
   else
-    hipLaunchKernelGGL((wgrad_fused_kernel<BKM, 3>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((wgrad_fused_kernel<8, D>), grid, block, 0, stream, a);
   wgrad_fused_reduce(a, stream);
 }
 

@@ -212,6 +212,13 @@ int mn_op_conv_halo_grid_m(const mn_gather_geom* g);
 int mn_op_conv_dgrad(int dtype, int B, int Hin, int Win, int Cin, int Cout, int k, int stride, int pad, const void* gy,
                      const void* wd, void* gx, const void* res, const void* res_gate, const void* out_gate, int parity,
                      const void* zero_page, void* stream);
+/* Stem convolution forward (torchvision ResNet conv1: 7x7 / stride 2 / pad 3, 3 -> 64 channels) for fp16 tensors
+ * (csrc/stem.h).  xpad: [B][H+6][Wp][4] zero-padded NHWC4 input (3 rows / columns of padding at the top / left, channel 3
+ * zero), Wp even and >= W + 7; wf: [64][224] weights in the pixel-pair layout [n][r][s4][2 pixels x 4 channels] (tap
+ * column 7 and channel 3 zero); y: [B][(H-1)/2+1][(W-1)/2+1][64]; stats_accum: optional [stats_rows][2][64] fp64 column
+ * sums (sum, sum of squares), added to atomically. */
+int mn_op_stem_conv(const void* xpad, const void* wf, void* y, double* stats_accum, int stats_rows, int B, int H, int W, int Wp,
+                    void* stream);
 /* conv weight layout helpers: OIHW fp32 <-> OHWI fp32 */
 int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream);
 

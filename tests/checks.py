@@ -306,6 +306,18 @@ def check_stem(lib, dev, dtype, B, H, W, seed=3):
                            None, None, 0, None, None, f32(1), K(zero_page(dev)), None))
     dev_sync(dev)
     assert (out.cpu().double().permute(0, 3, 1, 2) - ref).abs().max().item() <= OUT_TOL[dtype] * ref.abs().max().item()
+    if dtype == 1:  # the dedicated stem kernel (weights in registers, pixel pairs straight from LDS) + its BatchNorm sums
+        out2 = torch.full((B, H0, W0, 64), float("nan"), dtype=td, device=dev)
+        acc = torch.zeros(3, 2, 64, dtype=torch.float64, device=dev)
+        lib.check(lib.op_stem_conv(K(xp.to(td).to(dev)), K(wc.reshape(64, 224).to(td).to(dev)), K(out2), K(acc), 3, B, H, W, Wp, None))
+        dev_sync(dev)
+        o2 = out2.cpu().double().permute(0, 3, 1, 2)
+        assert (o2 - ref).abs().max().item() <= OUT_TOL[dtype] * ref.abs().max().item()
+        n = B * H0 * W0
+        rd = ref.detach()
+        s1, s2 = acc[:, 0].sum(0).cpu(), acc[:, 1].sum(0).cpu()
+        assert (s1 - rd.sum((0, 2, 3))).abs().max().item() <= 1e-4 * rd.abs().max().item() * n ** 0.5 + 1e-4
+        assert ((s2 - (rd ** 2).sum((0, 2, 3))).abs() / (rd ** 2).sum((0, 2, 3))).max().item() <= 1e-4
     gy = torch.randn(B, 64, H0, W0, generator=gen).to(td).float()
     ref.backward(gy.double())
     cm = torch.full((224,), -1, dtype=torch.int32)

@@ -106,7 +106,9 @@ static __global__ void __launch_bounds__(256, 2) stem_conv_kernel(StemArgs a) {
         s2[j] += vs * vs;
         stage[px * 64 + j * 32 + l31] = (half)v;
       }
-    // (same wave wrote and reads the block: the compiler's lgkmcnt wait orders the two)
+    // the same wave wrote and now reads the block: lockstep + in-order LDS on the GPU (the builtin emits no instruction;
+    // the emulator's fibers rendezvous there)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int id = lane + 64 * i, px = id >> 3, cp = id & 7;
@@ -114,6 +116,7 @@ static __global__ void __launch_bounds__(256, 2) stem_conv_kernel(StemArgs a) {
       if (oy < a.H0 && x0 + px < a.W0)
         *reinterpret_cast<piece_t*>(a.y + (((long)b * a.H0 + oy) * a.W0 + x0 + px) * 64 + cp * 8) = v;
     }
+    __builtin_amdgcn_wave_barrier();  // reads done before the next row's values overwrite the block
   }
   if (a.stats_accum) {
 #pragma unroll

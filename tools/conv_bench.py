@@ -86,6 +86,11 @@ wc = (torch.randn(64, 224, device="cuda") * 0.05).to(td)
 y = torch.empty(B, H0, W0, 64, dtype=td, device="cuda")
 st = torch.zeros(lib.op_igemm_grid_m(g.M), 2, 64, device="cuda")
 t_f = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(xp), ptr(wc), ptr(y), 64, ptr(st), None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
+if dtype == 1:
+    t_s = timeit(lambda: lib.op_stem_conv(ptr(xp), ptr(wc), ptr(y), None, 0, B, 256, 341, Wp, None))
+    acc = torch.zeros(8, 2, 64, dtype=torch.float64, device="cuda")
+    t_s2 = timeit(lambda: lib.op_stem_conv(ptr(xp), ptr(wc), ptr(y), ptr(acc), 8, B, 256, 341, Wp, None))
+    print("stem kernel (stem.h): fwd %7.1f us %6.0f TF(real) out %5.2f TB/s | with BatchNorm sums %7.1f us" % (t_s, 2.0 * g.M * 64 * 147 / t_s / 1e6, y.numel() * 2 / t_s / 1e6, t_s2))
 gy = torch.randn_like(y)
 gw = torch.zeros(64, 147, device="cuda")
 cm = torch.arange(224, dtype=torch.int32, device="cuda") % 147

@@ -10,8 +10,10 @@
 //   * the A fragment of MFMA step (r, kk) for output pixel x is ONE 16-byte pair -- row 2y + r, pair x + 2 kk + (lane >> 5)
 //     of that image -- read straight from LDS (consecutive lanes = consecutive pairs: conflict-free ds_read_b128).
 // One wave computes two output rows of 32 pixels x 64 channels (28 MFMAs each), rounds to fp16 through a private 4 KB
-// LDS staging block (16-byte stores along channels) and keeps the BatchNorm column sums of its pixels; the workgroup
-// adds them into the fp64 accumulator rows like igemm's epilogue.
+// LDS staging block (16-byte stores along channels) and keeps the BatchNorm column sums of its pixels.
+// Workgroups are persistent (512 of them walk the 18 432 tiles of a 192-image batch): the weights are loaded once per
+// workgroup instead of once per tile (516 MB of L2 traffic otherwise), the next tile's image is DMA'd while the current
+// one is computed, and the BatchNorm sums leave each workgroup once (128 fp64 atomics instead of 128 per tile).
 #pragma once
 #include "igemm.h"
 
@@ -34,33 +36,38 @@ static __global__ void __launch_bounds__(256, 2) stem_conv_kernel(StemArgs a) {
   constexpr int TH = kStemTH, TW = kStemTW;
   constexpr int IH = 2 * TH + 5, IW = TW + 3, IPIECES = IH * IW;  // 21 rows x 35 pairs
   constexpr int IPASS = (IPIECES + 255) / 256;
-  // ONE LDS object: [input image][4 staging blocks of 32 pixels x 64 halves][column sums 4 x 64 x 2 floats]
-  __shared__ piece_t smem[IPASS * 256 + 4 * 256 + 128];
-  piece_t* stage_all = &smem[IPASS * 256];
-  float* red = reinterpret_cast<float*>(&smem[IPASS * 256 + 4 * 256]);
+  // ONE LDS object: [2 input images][4 staging blocks of 32 pixels x 64 halves][column sums 4 x 64 x 2 floats]
+  __shared__ piece_t smem[2 * IPASS * 256 + 4 * 256 + 128];
+  piece_t* stage_all = &smem[2 * IPASS * 256];
+  float* red = reinterpret_cast<float*>(&smem[2 * IPASS * 256 + 4 * 256]);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int txi = tile % a.tiles_x;
-  int tmp = tile / a.tiles_x;
-  const int tyi = tmp % a.tiles_y;
-  const int b = tmp / a.tiles_y;
-  const int y0 = tyi * TH, x0 = txi * TW;
-
-  // ---- input image: one DMA sweep (rows 2 y0 .. 2 y0 + 20 of the padded image, pairs x0 .. x0 + 34)
+  const int ntiles = a.B * a.tiles_x * a.tiles_y;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.xpad, (long)a.B * a.Hp * a.Wp2 * 16L);
-#pragma unroll
-  for (int i = 0; i < IPASS; ++i) {
-    const int q = t + i * 256;
-    const int row = q / IW, col = q - row * IW;
-    const int iy = 2 * y0 + row, ip = x0 + col;
-    const bool ok = q < IPIECES && iy < a.Hp && ip < a.Wp2;
-    const unsigned off = ok ? (unsigned)(((b * a.Hp + iy) * a.Wp2 + ip) * 16) : ~0u;
-    dma16(rsrc, off, 0u, &smem[wave * 64 + i * 256]);
-  }
 
-  // ---- weights -> registers while the image is in flight: B fragment of step s, column tile j = 8 halves of row
+  // input image of a tile: one DMA sweep (rows 2 y0 .. 2 y0 + 20 of the padded image, pairs x0 .. x0 + 34)
+  auto issue_image = [&](int tile, int buf) {
+    const int txi = tile % a.tiles_x;
+    const int tmp = tile / a.tiles_x;
+    const int tyi = tmp % a.tiles_y, b = tmp / a.tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+#pragma unroll
+    for (int i = 0; i < IPASS; ++i) {
+      const int q = t + i * 256;
+      const int row = q / IW, col = q - row * IW;
+      const int iy = 2 * y0 + row, ip = x0 + col;
+      const bool ok = q < IPIECES && iy < a.Hp && ip < a.Wp2;
+      const unsigned off = ok ? (unsigned)(((b * a.Hp + iy) * a.Wp2 + ip) * 16) : ~0u;
+      dma16(rsrc, off, 0u, &smem[buf * IPASS * 256 + wave * 64 + i * 256]);
+    }
+  };
+  // persistent workgroups: tile = blockIdx.x, + gridDim.x, ...; the weights are loaded ONCE, the next tile's image is in
+  // flight while the current one is computed, the BatchNorm sums leave the workgroup once
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue_image(tile, 0);
+
+  // ---- weights -> registers while the first image is in flight: B fragment of step s, column tile j = 8 halves of row
   // n = 32 j + (lane & 31) at k = 16 s + 8 (lane >> 5)
   PieceView<half> wb[14][2];
   {
@@ -70,53 +77,61 @@ static __global__ void __launch_bounds__(256, 2) stem_conv_kernel(StemArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) wb[s][j].p = *reinterpret_cast<const piece_t*>(wrow + j * 32 * 224 + s * 16);
   }
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();  // the image is complete for every wave
 
   const int l31 = lane & 31, kh = lane >> 5;
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
   half* stage = reinterpret_cast<half*>(stage_all + wave * 256);  // [32 pixels][64 channels]
+  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    wait_vmcnt<0>();               // this tile's image (and the previous tile's stores)
+    __builtin_amdgcn_s_barrier();  // ... for every wave; everyone is done reading the other image
+    if (tile + (int)gridDim.x < ntiles) issue_image(tile + gridDim.x, (it + 1) & 1);
+    const int txi = tile % a.tiles_x;
+    const int tmp = tile / a.tiles_x;
+    const int tyi = tmp % a.tiles_y, b = tmp / a.tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    const piece_t* image = &smem[(it & 1) * IPASS * 256];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int ty = 2 * wave + rr;  // tile row of this pass
-    floatx16 acc[2];
+    for (int rr = 0; rr < 2; ++rr) {
+      const int ty = 2 * wave + rr;  // tile row of this pass
+      floatx16 acc[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const piece_t* img = &smem[(2 * ty) * IW + l31 + kh];
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      const piece_t* img = image + (2 * ty) * IW + l31 + kh;
 #pragma unroll
-    for (int s = 0; s < 14; ++s) {
-      PieceView<half> fa;
-      fa.p = img[(s >> 1) * IW + 2 * (s & 1)];
+      for (int s = 0; s < 14; ++s) {
+        PieceView<half> fa;
+        fa.p = img[(s >> 1) * IW + 2 * (s & 1)];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.v, wb[s][j].v, acc[j], 0, 0, 0);
-    }
-    // epilogue of the row: column sums over the pixels inside the image, fp16 through the wave's staging block
-    const int oy = y0 + ty;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int px = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const float v = acc[j][r];
-        const bool ok = oy < a.H0 && x0 + px < a.W0;
-        const float vs = ok ? v : 0.f;
-        s1[j] += vs;
-        s2[j] += vs * vs;
-        stage[px * 64 + j * 32 + l31] = (half)v;
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.v, wb[s][j].v, acc[j], 0, 0, 0);
       }
-    // the same wave wrote and now reads the block: lockstep + in-order LDS on the GPU (the builtin emits no instruction;
-    // the emulator's fibers rendezvous there)
-    __builtin_amdgcn_wave_barrier();
+      // epilogue of the row: column sums over the pixels inside the image, fp16 through the wave's staging block
+      const int oy = y0 + ty;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = lane + 64 * i, px = id >> 3, cp = id & 7;
-      const piece_t v = *reinterpret_cast<const piece_t*>(stage + px * 64 + cp * 8);
-      if (oy < a.H0 && x0 + px < a.W0)
-        *reinterpret_cast<piece_t*>(a.y + (((long)b * a.H0 + oy) * a.W0 + x0 + px) * 64 + cp * 8) = v;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const float v = acc[j][r];
+          const bool ok = oy < a.H0 && x0 + px < a.W0;
+          const float vs = ok ? v : 0.f;
+          s1[j] += vs;
+          s2[j] += vs * vs;
+          stage[px * 64 + j * 32 + l31] = (half)v;
+        }
+      // the same wave wrote and now reads the block: lockstep + in-order LDS on the GPU (the builtin emits no
+      // instruction; the emulator's fibers rendezvous there)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int id = lane + 64 * i, px = id >> 3, cp = id & 7;
+        const piece_t v = *reinterpret_cast<const piece_t*>(stage + px * 64 + cp * 8);
+        if (oy < a.H0 && x0 + px < a.W0)
+          *reinterpret_cast<piece_t*>(a.y + (((long)b * a.H0 + oy) * a.W0 + x0 + px) * 64 + cp * 8) = v;
+      }
+      __builtin_amdgcn_wave_barrier();  // reads done before the next row's values overwrite the block
     }
-    __builtin_amdgcn_wave_barrier();  // reads done before the next row's values overwrite the block
   }
   if (a.stats_accum) {
 #pragma unroll
@@ -136,7 +151,7 @@ static __global__ void __launch_bounds__(256, 2) stem_conv_kernel(StemArgs a) {
         sa += red[(w * 64 + t) * 2 + 0];
         sb += red[(w * 64 + t) * 2 + 1];
       }
-      double* row = a.stats_accum + (long)(tile % a.stats_rows) * 2 * 64;
+      double* row = a.stats_accum + (long)((int)blockIdx.x % a.stats_rows) * 2 * 64;
       atomicAdd(row + t, (double)sa);
       atomicAdd(row + 64 + t, (double)sb);
     }
@@ -151,7 +166,10 @@ inline void launch_stem_conv(const half* xpad, const half* wf, half* y, double* 
   a.B = B; a.Hp = H + 6; a.Wp2 = Wp / 2;
   a.H0 = (H - 1) / 2 + 1; a.W0 = (W - 1) / 2 + 1;
   a.tiles_x = cdiv(a.W0, kStemTW); a.tiles_y = cdiv(a.H0, kStemTH);
-  hipLaunchKernelGGL(stem_conv_kernel, dim3(B * a.tiles_x * a.tiles_y), dim3(256), 0, stream, a);
+  // persistent: two workgroups per CU (the 220-register kernel's occupancy), each walking tiles blockIdx.x, + grid, ...
+  static const int wgs = getenv("MN_STEM_WGS") ? atoi(getenv("MN_STEM_WGS")) : 512;
+  const int ntiles = B * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(ntiles < wgs ? ntiles : wgs), dim3(256), 0, stream, a);
 }
 
 }  // namespace mn

@@ -15,7 +15,15 @@ inline int ew_grid(long work_items) {
   // grid-stride kernels: at most 16 workgroups per CU (MN_EW_WGS_PER_CU, tuning knob: fewer leave wave slots to the
   // weight-gradient workgroups that run beside the HBM-bound passes)
   static const int per_cu = getenv("MN_EW_WGS_PER_CU") ? atoi(getenv("MN_EW_WGS_PER_CU")) : 16;
+  // small tensors (layers 3-4: 1-2 M pieces): at one piece per thread a workgroup's prologue (coefficient tables into LDS)
+  // and its dispatch cost as much as its loads; MN_EW_MIN_ITERS pieces per thread (while that leaves >= 2 workgroups per CU)
+  static const int min_iters = getenv("MN_EW_MIN_ITERS") ? atoi(getenv("MN_EW_MIN_ITERS")) : 1;
   long b = (work_items + 255) / 256;
+  if (min_iters > 1) {
+    long fat = (work_items + 256L * min_iters - 1) / (256L * min_iters);
+    if (fat < 512) fat = b < 512 ? b : 512;
+    b = fat;
+  }
   if (b > 256L * per_cu) b = 256L * per_cu;
   if (b < 1) b = 1;
   return (int)b;

@@ -766,7 +766,10 @@ struct Plan : PlanBase {
   // 1 = each weight gradient forked as soon as its dY exists (starts beside the data gradient that consumes the
   // same dY); 2 = deferred: a weight gradient is queued and forked right before the NEXT BatchNorm-backward pass of
   // the main stream, so that the MFMA-bound launch starts beside HBM-bound work instead of beside a data gradient.
-  int wgrad_sched = getenv("MN_WGRAD_SCHED") ? atoi(getenv("MN_WGRAD_SCHED")) : (early_fork ? 1 : 0);
+  // Round 2 (fused weight gradient: one 512-thread, 96 KB workgroup per CU -- it does not share a CU with a data-gradient
+  // workgroup, the two time-slice): 1 = 16.44 ms, 0 = 16.05, 2 = 16.01 (same-box A/B); round 1's plain-GEMM weight gradient
+  // preferred 1.
+  int wgrad_sched = getenv("MN_WGRAD_SCHED") ? atoi(getenv("MN_WGRAD_SCHED")) : (early_fork ? 2 : 0);
   struct PendingWgrad {
     Unit* u;
     const T* x;

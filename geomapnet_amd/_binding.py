@@ -78,6 +78,8 @@ _PROTOS = {
     "mn_op_conv_dgrad": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_i,
                                c_void, c_void]),
     "mn_op_stem_conv": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),
+    "mn_op_stem_bwd": (c_i, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_i, c_void, c_void, c_void,
+                             c_void, c_void, c_i, c_i, c_i, c_i, c_f, c_void]),
     "mn_op_oihw_to_ohwi": (c_i, [c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),
     "mn_op_criterion": (c_i, [c_i, c_i, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_f, c_void]),
     "mn_op_calc_vos": (c_i, [c_void, c_i, c_i, c_void, c_void, c_void, c_void]),

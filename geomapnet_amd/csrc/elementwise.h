@@ -474,7 +474,9 @@ template <typename T>
 inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, const float* gamma, const float* mean,
                           const float* invstd, float* dgamma, float* dbeta, T* gy, double* accum, float* coef,
                           float grad_unscale, hipStream_t s, const float* self_gate_beta = nullptr,
-                          PoolGradSrc pg = PoolGradSrc(), int accum_rows = 1) {
+                          PoolGradSrc pg = PoolGradSrc(), int accum_rows = 1, bool apply = true) {
+  // apply = false: reduce + finalize only (sums, d(gamma), d(beta), coef) -- the consumer applies the coefficients itself
+  // (stem_bwd.h computes d(conv output) tile by tile inside the weight-gradient kernel); gy is not written
   // self_gate_beta: the gradient g is taken w.r.t. relu(bn(y)) of THIS BatchNorm; the ReLU gate is recomputed
   // from y and `gate` is not read
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -496,6 +498,7 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
                      rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)accum, (double)M, gamma, mean,
                      invstd, dgamma, dbeta, grad_unscale, self_gate_beta, coef, C, accum_rows);
+  if (!apply) return;
   long np = M * C / VEC;
   static const int reverse = getenv("MN_BN_BWD_REVERSE") ? atoi(getenv("MN_BN_BWD_REVERSE")) : 0;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,

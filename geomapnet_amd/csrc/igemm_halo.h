@@ -22,10 +22,11 @@ namespace mn {
 
 // Two shapes: <256, 352> (N in 256-column tiles, W <= 31: layer3) and <128, 384> (128-column tiles, W <= 47, 131 KB of
 // LDS: layer2 with its 43-pixel rows, and layer4, whose 16 896 rows give 59 x 4 = 236 tiles = one round of the chip).
-// NBS: slots of the B ring.  With 2 slots every K-step waits for the slice it requested one K-step earlier -- for the
-// 128-column shape a K-step is only 1152 matrix-pipe cycles per SIMD, about half the latency of that request: the launch
-// is latency-bound (750 TF on layer2 vs 985 TF for the 256-column shape).  With 3 slots the slice of step kt+2 is
-// requested at step kt and the waits are counted (two slices of DMA instructions stay in flight).
+// NBS: slots of the B ring.  With 2 slots every K-step waits for the slice it requested one K-step earlier; with 3 slots
+// the slice of step kt+2 is requested at step kt and the waits are counted (two slices of DMA instructions stay in
+// flight).  Measured on MI355X for the 128-column shape (round 2): 3 slots are SLOWER -- layer2 109.8 vs 105.1 us, layer4
+// 92.0 vs 85.8 us, whole step 15.36 vs 15.27 ms -- so the request latency is not what bounds these launches; 2 is the default
+// (MN_IGEMM_HALO_NBS=3 selects the deeper ring).
 template <int BN, int kAH, int NBS = 2>
 static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
@@ -331,8 +332,8 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
     return gm;
   }
   if (level >= 2 && igemm_halo_applies(g, ep, 128, 384)) {
-    static const int nbs = getenv("MN_IGEMM_HALO_NBS") ? atoi(getenv("MN_IGEMM_HALO_NBS")) : 3;  // B ring depth (2 | 3)
-    if (nbs == 2)
+    static const int nbs = getenv("MN_IGEMM_HALO_NBS") ? atoi(getenv("MN_IGEMM_HALO_NBS")) : 2;  // B ring depth (2 | 3)
+    if (nbs != 3)
       hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 2>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
     else
       hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 3>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);

@@ -14,6 +14,7 @@
 #include "pgo.h"
 #include "pool.h"
 #include "stem.h"
+#include "stem_bwd.h"
 #include "wgrad.h"
 #include "util.h"
 
@@ -147,6 +148,26 @@ extern "C" int mn_op_stem_conv(const void* xpad, const void* wf, void* y, double
   if ((long)B * (H + 6) * Wp * 8 >= 0xfffffff0l) return fail("stem_conv: padded input exceeds 4 GiB");
   launch_stem_conv((const half*)xpad, (const half*)wf, (half*)y, stats_accum, stats_rows, B, H, W, Wp, (hipStream_t)stream);
   return check_launch("stem_conv");
+}
+
+extern "C" int mn_op_stem_bwd(const void* y, const unsigned char* idx, const void* gp, const float* gamma, const float* beta,
+                              const float* mean, const float* invstd, const void* xpad, float* dW, int ldw, const int32_t* colmap,
+                              float* dgamma, float* dbeta, float* coef_scratch, double* accum_scratch, int B, int H, int W, int Wp,
+                              float alpha, void* stream) {
+  begin_call();
+  if (Wp % 2 != 0 || Wp < W + 7) return fail("stem_bwd: Wp must be even and >= W + 7");
+  hipStream_t s = (hipStream_t)stream;
+  const int H0 = (H - 1) / 2 + 1, W0 = (W - 1) / 2 + 1;
+  PoolGradSrc pg;
+  pg.idx = idx; pg.gout = gp; pg.H = H0; pg.W = W0; pg.Po = (H0 + 2 - 3) / 2 + 1; pg.Qo = (W0 + 2 - 3) / 2 + 1;
+  hipMemsetAsync(accum_scratch, 0, 2 * 64 * sizeof(double), s);
+  launch_bn_bwd<half>((const half*)nullptr, (const half*)nullptr, (const half*)y, (long)B * H0 * W0, 64, gamma, mean, invstd, dgamma,
+                      dbeta, (half*)nullptr, accum_scratch, coef_scratch, alpha, s, beta, pg, 1, false);
+  StemWgradArgs a;
+  a.y = (const half*)y; a.idx = idx; a.gp = (const half*)gp; a.coef = coef_scratch; a.mean = mean; a.invstd = invstd;
+  a.xpad = (const half*)xpad; a.dW = dW; a.colmap = colmap; a.ldw = ldw; a.alpha = alpha;
+  launch_stem_wgrad(a, B, H, W, Wp, s);
+  return check_launch("stem_bwd");
 }
 
 extern "C" int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream) {

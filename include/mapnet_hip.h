@@ -219,6 +219,16 @@ int mn_op_conv_dgrad(int dtype, int B, int Hin, int Win, int Cin, int Cout, int 
  * sums (sum, sum of squares), added to atomically. */
 int mn_op_stem_conv(const void* xpad, const void* wf, void* y, double* stats_accum, int stats_rows, int B, int H, int W, int Wp,
                     void* stream);
+/* Stem backward (fp16) below maxpool(relu(bn1(conv1(x)))) in two launches (csrc/stem_bwd.h): BatchNorm sums with the
+ * max-pool's input gradient gathered on the fly from (idx, gp), then conv1's weight gradient with d(conv output) computed
+ * tile by tile in LDS.  y: raw conv output [B][H0][W0][64]; idx / gp: argmax bytes and gradient of the pooled activation
+ * [B][Po][Qo][64]; xpad / Wp as mn_op_stem_conv; dW: [64][ldw] fp32 (+=, atomics), column k of the 224-column pair layout
+ * goes to colmap[k] (or is dropped where colmap[k] < 0); dgamma / dbeta: += ; coef_scratch: 4*64 floats, accum_scratch:
+ * 2*64 doubles; alpha multiplies every gradient (1 / loss scale). */
+int mn_op_stem_bwd(const void* y, const unsigned char* idx, const void* gp, const float* gamma, const float* beta,
+                   const float* mean, const float* invstd, const void* xpad, float* dW, int ldw, const int32_t* colmap,
+                   float* dgamma, float* dbeta, float* coef_scratch, double* accum_scratch, int B, int H, int W, int Wp,
+                   float alpha, void* stream);
 /* conv weight layout helpers: OIHW fp32 <-> OHWI fp32 */
 int mn_op_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int to_ohwi, void* stream);
 

@@ -1099,3 +1099,65 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
     assert rec["fp32"]["pose_abs_max"] <= fp32_pose_atol * max(1.0, rec["pose_scale"]), rec
     assert rec["fp16"]["loss_rel"] <= 5e-3 and rec["fp16"]["pose_abs_max"] <= 5e-2 * max(1.0, rec["pose_scale"]), rec
     return rec
+
+
+def check_stem_bwd(lib, dev, B, H, W, seed=5):
+    """stem backward in two launches (csrc/stem_bwd.h: BatchNorm sums with the max-pool gradient gathered on the fly, then the
+    weight gradient with d(conv output) computed in LDS) against the four-launch chain of the operators it replaces
+    (maxpool_bwd -> bn_bwd -> wgrad) on identical fp16 tensors: same arithmetic, same roundings"""
+    _fresh()
+    td = torch.float16
+    gen = torch.Generator().manual_seed(seed)
+    g, Hp, Wp, H0, W0 = stem_geom(B, H, W)
+    Po, Qo = (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1
+    x = torch.randn(B, 3, H, W, generator=gen).to(td).float()
+    xp = torch.zeros(B, Hp, Wp, 4)
+    xp[:, 3:3 + H, 3:3 + W, :3] = x.permute(0, 2, 3, 1)
+    xp = xp.to(td).to(dev)
+    y = (torch.randn(B, H0, W0, 64, generator=gen) * 1.5 + 0.3).to(td).to(dev)  # stands for the raw conv output
+    gamma = (1.0 + 0.2 * torch.randn(64, generator=gen)).to(dev)
+    beta = (0.1 * torch.randn(64, generator=gen)).to(dev)
+    M = B * H0 * W0
+    mean, invstd = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    a0 = torch.zeros(B, H0, W0, 64, dtype=td, device=dev)
+    scratch = torch.zeros(2 * 64 * 8 + 2 * 64 * 4, dtype=torch.uint8, device=dev)
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    lib.check(lib.op_bn_train_fwd(1, K(y), M, 64, K(gamma), K(beta), K(rm), K(rv), K(mean), K(invstd), None, 1, K(a0), f32(1e-5),
+                                  f32(0.1), K(scratch), None))
+    p0 = torch.zeros(B, Po, Qo, 64, dtype=td, device=dev)
+    idx = torch.zeros(B, Po, Qo, 64, dtype=torch.uint8, device=dev)
+    lib.check(lib.op_maxpool_fwd(1, K(a0), K(p0), K(idx), B, H0, W0, 64, None))
+    gp = torch.randn(B, Po, Qo, 64, generator=gen).to(td).to(dev)
+    cm = torch.full((224,), -1, dtype=torch.int32)
+    for r in range(7):
+        for s4 in range(4):
+            for e in range(8):
+                sp, ch = 2 * s4 + (e >> 2), e & 3
+                if sp < 7 and ch < 3:
+                    cm[(r * 4 + s4) * 8 + e] = (r * 7 + sp) * 3 + ch
+    cm = cm.to(dev)
+    alpha = 1.0 / 64.0
+    # the chain it replaces
+    ga0 = torch.zeros(B, H0, W0, 64, dtype=td, device=dev)
+    lib.check(lib.op_maxpool_bwd(1, K(idx), K(gp), K(ga0), B, H0, W0, 64, None))
+    dg_ref, db_ref = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    gy = torch.zeros(B, H0, W0, 64, dtype=td, device=dev)
+    coef = torch.zeros(4 * 64, device=dev)
+    acc = torch.zeros(2 * 64, dtype=torch.float64, device=dev)
+    lib.check(lib.op_bn_bwd(1, K(ga0), K(a0), K(y), M, 64, K(gamma), K(mean), K(invstd), K(dg_ref), K(db_ref), K(gy), K(coef), K(acc),
+                            f32(alpha), None))
+    dW_ref = torch.zeros(64, 147, device=dev)
+    lib.check(lib.op_wgrad(1, C.byref(g), K(gy), 64, K(xp), K(dW_ref), 147, K(cm), f32(alpha), 16, K(zero_page(dev)), None))
+    # the two-launch form
+    dg, db = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    dW = torch.zeros(64, 147, device=dev)
+    coef2 = torch.zeros(4 * 64, device=dev)
+    acc2 = torch.zeros(2 * 64, dtype=torch.float64, device=dev)
+    lib.check(lib.op_stem_bwd(K(y), K(idx), K(gp), K(gamma), K(beta), K(mean), K(invstd), K(xp), K(dW), 147, K(cm), K(dg), K(db),
+                              K(coef2), K(acc2), B, H, W, Wp, f32(alpha), None))
+    dev_sync(dev)
+    scale = dW_ref.abs().max().item()
+    assert scale > 0
+    assert (dW - dW_ref).abs().max().item() <= 2e-4 * scale, ((dW - dW_ref).abs().max().item(), scale)
+    np.testing.assert_allclose(dg.cpu().numpy(), dg_ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dg_ref.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(db_ref.abs().max()))

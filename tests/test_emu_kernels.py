@@ -165,6 +165,14 @@ def test_fused_weight_gradient_through_workspace(lib, shape):
     checks.check_conv_wgrad(lib, DEV, 1, *shape, ws=True)
 
 
+@pytest.mark.parametrize("shape", [(1, 20, 27), (2, 33, 70)])
+def test_stem_backward_two_launch_form(lib, shape, monkeypatch):
+    """csrc/stem_bwd.h against the maxpool_bwd -> bn_bwd -> wgrad chain it replaces, identical fp16 tensors; three
+    persistent workgroups so every workgroup walks several tiles"""
+    monkeypatch.setenv("MN_STEM_WGS", "3")
+    checks.check_stem_bwd(lib, DEV, *shape)
+
+
 def test_forced_288x256_configuration():
     """the 12-wave 288x256 tile (packed tap masks, joint A/B DMA passes, odd wave-row count) on small ragged problems,
     in a process of its own because the configuration knob is read once"""

@@ -103,6 +103,12 @@ def test_stem_conv(lib, dtype, hw):
     checks.check_stem(lib, DEV, dtype, 2, *hw)
 
 
+@pytest.mark.parametrize("shape", [(1, 20, 27), (2, 33, 70), (3, 256, 341)])
+def test_stem_backward_two_launch_form(lib, shape):
+    """csrc/stem_bwd.h against the maxpool_bwd -> bn_bwd -> wgrad chain it replaces, identical fp16 tensors"""
+    checks.check_stem_bwd(lib, DEV, *shape)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("M,C,kw", [(300, 64, dict()), (77, 128, dict(with_res=False)), (130, 512, dict(relu=False, with_res=False)),
                                     (2 * 64 * 86, 64, dict())])

@@ -92,6 +92,30 @@ if dtype == 1:
     t_s2 = timeit(lambda: lib.op_stem_conv(ptr(xp), ptr(wc), ptr(y), ptr(acc), 8, B, 256, 341, Wp, None))
     print("stem kernel (stem.h): fwd %7.1f us %6.0f TF(real) out %5.2f TB/s | with BatchNorm sums %7.1f us" % (t_s, 2.0 * g.M * 64 * 147 / t_s / 1e6, y.numel() * 2 / t_s / 1e6, t_s2))
 gy = torch.randn_like(y)
+if dtype == 1:  # stem backward: the two-launch form (stem_bwd.h) vs the four launches it replaces
+    Po, Qo = (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1
+    a0 = torch.relu(y)
+    p0 = torch.empty(B, Po, Qo, 64, dtype=td, device="cuda")
+    idx = torch.empty(B, Po, Qo, 64, dtype=torch.uint8, device="cuda")
+    lib.op_maxpool_fwd(1, ptr(a0), ptr(p0), ptr(idx), B, H0, W0, 64, None)
+    gp = torch.randn_like(p0)
+    gam, bet, mu, isd = (torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda"),
+                         torch.ones(64, device="cuda"))
+    dg, db, coef = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(256, device="cuda")
+    acc2 = torch.zeros(128, dtype=torch.float64, device="cuda")
+    gwf = torch.zeros(64, 147, device="cuda")
+    cmf = torch.arange(224, dtype=torch.int32, device="cuda") % 147
+    t_b = timeit(lambda: lib.op_stem_bwd(ptr(y), ptr(idx), ptr(gp), ptr(gam), ptr(bet), ptr(mu), ptr(isd), ptr(xp), ptr(gwf), 147,
+                                         ptr(cmf), ptr(dg), ptr(db), ptr(coef), ptr(acc2), B, 256, 341, Wp, one, None))
+    ga0 = torch.empty_like(y)
+    gyy = torch.empty_like(y)
+    def chain():
+        lib.op_maxpool_bwd(1, ptr(idx), ptr(gp), ptr(ga0), B, H0, W0, 64, None)
+        lib.op_bn_bwd(1, ptr(ga0), ptr(a0), ptr(y), B * H0 * W0, 64, ptr(gam), ptr(mu), ptr(isd), ptr(dg), ptr(db), ptr(gyy), ptr(coef),
+                      ptr(acc2), one, None)
+        lib.op_wgrad(1, C.byref(g), ptr(gyy), 64, ptr(xp), ptr(gwf), 147, ptr(cmf), one, 1024, ptr(checks.zero_page("cuda")), None)
+    t_c = timeit(chain)
+    print("stem backward: two launches (stem_bwd.h) %7.1f us | maxpool_bwd + bn_bwd + wgrad %7.1f us" % (t_b, t_c))
 gw = torch.zeros(64, 147, device="cuda")
 cm = torch.arange(224, dtype=torch.int32, device="cuda") % 147
 t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), 64, ptr(xp), ptr(gw), 147, ptr(cm), one, 1024, ptr(checks.zero_page("cuda")), None))

@@ -258,7 +258,9 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __
 
 // ---- BatchNorm backward ---------------------------------------------------------------------------
 // reduce: accum[0][c] += sum gm, accum[1][c] += sum gm * xhat,  gm = g * (gate > 0 if gate)
-template <typename T>
+// POOL: the gradient is gathered from (argmax, pooled gradient) -- a separate instantiation so that the common form does
+// not carry the gather's registers
+template <typename T, bool POOL = false>
 static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ gate,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long M, int C,
@@ -295,7 +297,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
       const long rr = r + (long)u * rlanes;
       const bool in = rr < r1;
       const long idx = (in ? rr : r) * cpr + cp;
-      if (pg.idx) {  // the gradient is the max-pool's input gradient, gathered on the fly
+      if constexpr (POOL) {  // the gradient is the max-pool's input gradient, gathered on the fly
         float a[VEC];
         const long rrow = in ? rr : r;
         const int w_ = (int)(rrow % pg.W);
@@ -373,7 +375,7 @@ static __global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const doubl
 }
 
 // apply: gy = k1 * (gm - mg - xhat * mgx)
-template <typename T>
+template <typename T, bool POOL = false>
 static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ gate,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ coef,
@@ -398,7 +400,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
     const long i = reverse ? npieces - 1 - i_ : i_;
     int c0 = (int)(i % cpr) * VEC;
     PieceView<T> vg, vy, vm, o;
-    if (pg.idx) {
+    if constexpr (POOL) {
       float a[VEC];
       const long row = i / cpr;
       const int w_ = (int)(row % pg.W);
@@ -494,15 +496,23 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   if (rows < 4L * rlanes) rows = 4L * rlanes;
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
-                     rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
+  if (pg.idx)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
+                       rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
+                       rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)accum, (double)M, gamma, mean,
                      invstd, dgamma, dbeta, grad_unscale, self_gate_beta, coef, C, accum_rows);
   if (!apply) return;
   long np = M * C / VEC;
   static const int reverse = getenv("MN_BN_BWD_REVERSE") ? atoi(getenv("MN_BN_BWD_REVERSE")) : 0;
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
-                     (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg, reverse);
+  if (pg.idx)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
+                       (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg, reverse);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
+                       (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg, reverse);
 }
 
 // ---- global average pool --------------------------------------------------------------------------

@@ -118,28 +118,38 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemWgradArgs
     const int y0 = tyi * TH, x0 = txi * TW;
     __syncthreads();  // everyone is done with the previous tile's LDS reads (gradient tile, other image)
     if (tile + (int)gridDim.x < ntiles) issue_image(tile + gridDim.x, (it + 1) & 1);
-    // ---- d(conv output) of the tile -> LDS: 8 pieces (pixel, 8 channels) per thread
-#pragma unroll 2
-    for (int i = 0; i < 8; ++i) {
-      const int px = (t >> 3) + 32 * i;  // tile pixel: row px >> 5, column px & 31
-      const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
-      PieceView<half> o;
-      o.p = zero_piece();
-      if (oy < a.H0 && ox < a.W0) {
-        PieceView<half> vy;
-        vy.p = *reinterpret_cast<const piece_t*>(a.y + (((long)b * a.H0 + oy) * a.W0 + ox) * 64 + cp * 8);
-        float g[8];
-        pool_grad_piece<half>(a.idx, a.gp, b, oy, ox, cp, 8, a.Po, a.Qo, g);
+    // ---- d(conv output) of the tile -> LDS: 8 pieces (pixel, 8 channels) per thread, in four groups of two whose loads
+    // (conv output + the four candidate windows of the pool gradient, unconditional at clamped coordinates) are all
+    // requested before the first use
+#pragma unroll
+    for (int grp4 = 0; grp4 < 4; ++grp4) {
+      PieceView<half> vy[2];
+      float g[2][8];
+      bool ok[2];
+      int pxs[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int px = (t >> 3) + 32 * (grp4 * 2 + u);  // tile pixel: row px >> 5, column px & 31
+        const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+        ok[u] = oy < a.H0 && ox < a.W0;
+        pxs[u] = px;
+        const int oyc = oy < a.H0 ? oy : a.H0 - 1, oxc = ox < a.W0 ? ox : a.W0 - 1;
+        vy[u].p = *reinterpret_cast<const piece_t*>(a.y + (((long)b * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
+        pool_grad_piece<half>(a.idx, a.gp, b, oyc, oxc, cp, 8, a.Po, a.Qo, g[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        PieceView<half> o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float yv = (float)vy.e[e];
-          float gv = g[e];
+          const float yv = (float)vy[u].e[e];
+          float gv = g[u][e];
           if (!(yv * k1[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
           const float xh = (yv - mu[e]) * is[e];
-          o.e[e] = (half)(k1[e] * (gv - mg[e] - xh * mgx[e]));
+          o.e[e] = ok[u] ? (half)(k1[e] * (gv - mg[e] - xh * mgx[e])) : (half)0.f;
         }
+        *reinterpret_cast<piece_t*>(gyt + pxs[u] * 64 + ((cp ^ wg_swz<8>(pxs[u])) * 8)) = o.p;
       }
-      *reinterpret_cast<piece_t*>(gyt + px * 64 + ((cp ^ wg_swz<8>(px)) * 8)) = o.p;
     }
     wait_vmcnt<0>();   // this tile's image (requested one tile ago, or in the prologue)
     __syncthreads();   // gradient tile and image complete for every wave

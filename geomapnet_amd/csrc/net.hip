@@ -860,17 +860,18 @@ struct Plan : PlanBase {
   bool use_stem_bwd = DT == MN_F16 && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
   void stem_backward(hipStream_t s) {
     if (use_stem_bwd) {
-      // two launches (stem_bwd.h): BatchNorm sums with the max-pool gradient gathered on the fly, then the weight gradient
-      // with d(conv output) computed tile by tile in LDS -- neither the max-pool's input gradient nor d(conv output) is stored
-      PoolGradSrc pg;
-      pg.idx = pool_idx; pg.gout = gp0; pg.H = H0; pg.W = W0; pg.Po = H1; pg.Qo = W1;
-      launch_bn_bwd<T>((const T*)nullptr, (const T*)nullptr, (const T*)stem.y, stem.M, 64, params + stem.bp.gamma, stem.mean,
-                       stem.invstd, grads + stem.bp.gamma, grads + stem.bp.beta, (T*)nullptr, stem.accum_b, stem.coef_b,
-                       1.f / cur_scale, s, params + stem.bp.beta, pg, ACC_ROWS, /*apply=*/false);
-      StemWgradArgs a;
-      a.y = (const half*)stem.y; a.idx = pool_idx; a.gp = (const half*)gp0; a.coef = stem.coef_b; a.mean = stem.mean;
-      a.invstd = stem.invstd; a.xpad = (const half*)xpad; a.dW = grads + stem.cp.w; a.colmap = stem_colmap; a.ldw = stem.ldw;
+      // two tile-walking launches (stem_bwd.h): BatchNorm sums, then the weight gradient with d(conv output) computed tile
+      // by tile in LDS -- neither the max-pool's input gradient nor d(conv output) is stored
+      StemBwdArgs a;
+      a.y = (const half*)stem.y; a.idx = pool_idx; a.gp = (const half*)gp0; a.gamma = params + stem.bp.gamma;
+      a.beta = params + stem.bp.beta; a.coef = stem.coef_b; a.mean = stem.mean; a.invstd = stem.invstd; a.accum = stem.accum_b;
+      a.accum_rows = ACC_ROWS; a.xpad = (const half*)xpad; a.dW = grads + stem.cp.w; a.colmap = stem_colmap; a.ldw = stem.ldw;
       a.alpha = 1.f / cur_scale;
+      launch_stem_bn_reduce(a, B, H, W, Wp, s);
+      hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(256), 0, s, (const double*)stem.accum_b, (double)stem.M,
+                         (const float*)(params + stem.bp.gamma), (const float*)stem.mean, (const float*)stem.invstd,
+                         grads + stem.bp.gamma, grads + stem.bp.beta, 1.f / cur_scale, (const float*)(params + stem.bp.beta),
+                         stem.coef_b, 64, ACC_ROWS);
       auto* tp = timer.begin(1, s);
       launch_stem_wgrad(a, B, H, W, Wp, s);
       timer.end(tp, s);

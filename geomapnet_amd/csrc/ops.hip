@@ -158,14 +158,14 @@ extern "C" int mn_op_stem_bwd(const void* y, const unsigned char* idx, const voi
   if (Wp % 2 != 0 || Wp < W + 7) return fail("stem_bwd: Wp must be even and >= W + 7");
   hipStream_t s = (hipStream_t)stream;
   const int H0 = (H - 1) / 2 + 1, W0 = (W - 1) / 2 + 1;
-  PoolGradSrc pg;
-  pg.idx = idx; pg.gout = gp; pg.H = H0; pg.W = W0; pg.Po = (H0 + 2 - 3) / 2 + 1; pg.Qo = (W0 + 2 - 3) / 2 + 1;
+  StemBwdArgs a;
+  a.y = (const half*)y; a.idx = idx; a.gp = (const half*)gp; a.gamma = gamma; a.beta = beta; a.coef = coef_scratch; a.mean = mean;
+  a.invstd = invstd; a.accum = accum_scratch; a.accum_rows = 1; a.xpad = (const half*)xpad; a.dW = dW; a.colmap = colmap;
+  a.ldw = ldw; a.alpha = alpha;
   hipMemsetAsync(accum_scratch, 0, 2 * 64 * sizeof(double), s);
-  launch_bn_bwd<half>((const half*)nullptr, (const half*)nullptr, (const half*)y, (long)B * H0 * W0, 64, gamma, mean, invstd, dgamma,
-                      dbeta, (half*)nullptr, accum_scratch, coef_scratch, alpha, s, beta, pg, 1, false);
-  StemWgradArgs a;
-  a.y = (const half*)y; a.idx = idx; a.gp = (const half*)gp; a.coef = coef_scratch; a.mean = mean; a.invstd = invstd;
-  a.xpad = (const half*)xpad; a.dW = dW; a.colmap = colmap; a.ldw = ldw; a.alpha = alpha;
+  launch_stem_bn_reduce(a, B, H, W, Wp, s);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(256), 0, s, (const double*)accum_scratch, (double)((long)B * H0 * W0), gamma,
+                     mean, invstd, dgamma, dbeta, alpha, beta, coef_scratch, 64, 1);
   launch_stem_wgrad(a, B, H, W, Wp, s);
   return check_launch("stem_bwd");
 }

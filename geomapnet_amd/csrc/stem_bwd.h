@@ -1,23 +1,25 @@
-// Stem backward in two launches instead of four (fp16): what autograd computes for conv1.weight below
+// Stem backward in two tile-walking launches (fp16): what autograd computes for conv1.weight, bn1.weight and bn1.bias below
 // maxpool -> relu -> bn1 -> conv1 (torchvision ResNet stem; loss.backward() at /root/reference/common/train.py:355).
 //
 // Round 1 ran: maxpool_bwd (gathers the pooled gradient into a full-size tensor: 0.54 GB written), bn_bwd_reduce and
 // bn_bwd_apply over that tensor and the conv output (2.7 GB of traffic, 0.54 GB written: d(conv output)), and the plain
-// weight-gradient GEMM over d(conv output) and an im2col of the input -- 1.1 ms per step for a gradient of 9 408 numbers.
-// Nothing below the stem consumes d(conv output) (the input needs no gradient), so it never has to exist in memory:
-//   1. bn_bwd_reduce with the max-pool gradient gathered on the fly (elementwise.h, PoolGradSrc) + finalize: the two
-//      BatchNorm sums, d(gamma), d(beta), and the per-channel coefficients of the apply step;
-//   2. stem_wgrad_kernel (here): per 8 x 32-pixel tile, d(conv output) is COMPUTED into LDS -- gather of the pooled
-//      gradient (argmax bytes + pooled gradient, pool.h), ReLU gate recomputed from the conv output, BatchNorm backward
-//      with the coefficients of step 1, rounded to fp16 exactly as the stored tensor was -- and contracted with the input
-//      straight from an LDS-resident image of the zero-padded NHWC4 input (as stem.h's forward: a B fragment of the
-//      weight-gradient GEMM is a transpose read over consecutive pixel PAIRS, no im2col).
-// Traffic: conv output 0.54 GB + argmax 0.07 GB + pooled gradient 0.13 GB (each twice, steps 1 and 2) + input 0.14 GB.
-//
-// Tile = 8 x 32 output pixels; the GEMM is dW[n][k] += sum_m gy[m][n] * X[m][k] with m = pixel, k = (r, s4, e) the 7 x 4
-// pixel pairs x 8 halves of stem.h (224 columns, mapped to the dense 147 by `colmap`).  Wave w owns kernel rows
-// r = 2w, 2w + 1 (the last wave: r = 6 only), both 32-column tiles of the 64 output channels: 4 accumulator tiles.
-// Workgroups are persistent; accumulators leave through fp32 atomics once per workgroup.
+// weight-gradient GEMM over d(conv output) and an im2col of the input -- 1.1 ms per step for 9 536 numbers.
+// Nothing below the stem consumes d(conv output) (the input needs no gradient), so neither it nor the max-pool's input
+// gradient has to exist in memory.  Both kernels here walk 4 x 32-pixel tiles with persistent workgroups and stage,
+// per tile, the 3 x 17 pooled windows the tile's pixels belong to (pooled gradient 128 B + argmax bytes 64 B per window)
+// in LDS by DMA, double-buffered: the gradient of a conv-output pixel is then gathered from LDS (a first version that
+// gathered from global memory issued 4 x 24 B of requests per 16 bytes of conv output and ran at the L2 request rate:
+// 450 + 570 us, no better than the four launches).
+//   1. stem_bn_reduce_kernel: sum(gm), sum(gm * xhat) per channel, gm = gathered gradient gated by the ReLU recomputed
+//      from the conv output; then bn_finalize_bwd_kernel (elementwise.h): d(gamma), d(beta), coefficients of the apply step;
+//   2. stem_wgrad_kernel: per tile, d(conv output) = k1 (gm - mean(gm) - xhat mean(gm xhat)) is computed into LDS, rounded
+//      to fp16 exactly as the stored tensor was, and contracted with the input read from an LDS-resident image of the
+//      zero-padded NHWC4 input (as stem.h's forward: a B fragment of the weight-gradient GEMM is a transpose read over
+//      consecutive pixel PAIRS, no im2col).  The GEMM is dW[n][k] += sum_m gy[m][n] X[m][k], m = pixel, k = (r, s4, e) the
+//      7 x 4 pixel pairs x 8 halves of stem.h (224 columns, mapped to the dense 147 by `colmap`); wave w owns kernel
+//      rows r = 2w, 2w + 1 (the last wave: r = 6) x both 32-column tiles of the 64 output channels.  Accumulators leave
+//      through fp32 atomics once per workgroup.
+// Traffic: conv output 0.54 GB + argmax 0.07 GB + pooled gradient 0.13 GB, each twice, + input 0.14 GB.
 #pragma once
 #include "pool.h"
 #include "stem.h"
@@ -25,39 +27,187 @@
 
 namespace mn {
 
-struct StemWgradArgs {
+struct StemBwdArgs {
   const half* y;             // [B][H0][W0][64] raw conv output
   const unsigned char* idx;  // [B][Po][Qo][64] winning tap of every max-pool window
   const half* gp;            // [B][Po][Qo][64] gradient w.r.t. the pooled activation
-  const float* coef;         // [4][64]: k1 = gamma*invstd, mean of gm, mean of gm*xhat, shift of the self gate (finalize kernel)
+  const float* gamma;        // reduce: [64]
+  const float* beta;         // reduce: [64]
+  const float* coef;         // wgrad: [4][64] k1 = gamma*invstd, mean of gm, mean of gm*xhat, shift of the self gate
   const float* mean;         // [64]
   const float* invstd;       // [64]
-  const half* xpad;          // [B][Hp][Wp][4] zero-padded input
-  float* dW;                 // [64][ldw] fp32, accumulated atomically
-  const int* colmap;         // [224] compute column -> dense column or -1
+  double* accum;             // reduce: [accum_rows][2][64] fp64 sums, added to atomically
+  int accum_rows;
+  const half* xpad;          // wgrad: [B][Hp][Wp][4] zero-padded input
+  float* dW;                 // wgrad: [64][ldw] fp32, accumulated atomically
+  const int* colmap;         // wgrad: [224] compute column -> dense column or -1
   int ldw;
-  float alpha;               // 1 / loss scale
+  float alpha;               // wgrad: 1 / loss scale
   int B, Hp, Wp2, H0, W0, Po, Qo, tiles_x, tiles_y;
 };
 
-static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemWgradArgs a) {
-  constexpr int TH = kStemTH, TW = kStemTW;
-  constexpr int IH = 2 * TH + 5, IW = TW + 3, IPIECES = IH * IW;  // 21 rows x 35 pairs
-  constexpr int IPASS = (IPIECES + 255) / 256;
-  constexpr int GYP = TH * TW * 8;  // pieces of the d(conv output) tile: 256 pixels x 64 halves
-  // ONE LDS object: [2 input images][d(conv output) tile]
-  __shared__ piece_t smem[2 * IPASS * 256 + GYP];
-  half* gyt = reinterpret_cast<half*>(&smem[2 * IPASS * 256]);
+constexpr int kSbTH = 4, kSbTW = 32;                         // tile of conv-output pixels
+constexpr int kSbPR = kSbTH / 2 + 1, kSbPC = kSbTW / 2 + 1;  // 3 x 17 pooled windows touch it
+constexpr int kSbGP = 448;    // pieces reserved for the pooled gradient (3*17*8 = 408, rounded up to whole waves)
+constexpr int kSbPOOL = 768;  // pieces of one pool buffer: gradient, then argmax bytes (3*17*4 = 204)
+
+// DMA of the pooled windows of a tile into `dst` (kSbPOOL pieces): window (pr, pc) = pooled position (y0/2 + pr, x0/2 + pc)
+__device__ __forceinline__ void sb_issue_pool(const StemBwdArgs& a, __amdgpu_buffer_rsrc_t rsrc_g, __amdgpu_buffer_rsrc_t rsrc_i,
+                                              int b, int y0, int x0, piece_t* dst, int t, int wave) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int q = t + i * 256;
+    const bool is_g = (wave * 64 + i * 256) < kSbGP;  // wave-uniform: 448 = 7 waves
+    const int qq = is_g ? q : q - kSbGP;
+    const int win = is_g ? qq >> 3 : qq >> 2, part = is_g ? (qq & 7) : (qq & 3);
+    const int pr = win / kSbPC, pc = win - pr * kSbPC;
+    const int po = (y0 >> 1) + pr, qo = (x0 >> 1) + pc;
+    const bool ok = win < kSbPR * kSbPC && po < a.Po && qo < a.Qo;
+    const unsigned wo = (unsigned)(((b * a.Po + po) * a.Qo + qo) * 64);  // element offset of the window
+    if (is_g)
+      dma16(rsrc_g, ok ? wo * 2u + (unsigned)part * 16u : ~0u, 0u, dst + wave * 64 + i * 256);
+    else
+      dma16(rsrc_i, ok ? wo + (unsigned)part * 16u : ~0u, 0u, dst + wave * 64 + i * 256);
+  }
+}
+
+// gradient of conv-output pixel (h, w) for channel piece cp, gathered from the staged windows: the sum over the (at most
+// four) windows the pixel belongs to of the window's gradient where its recorded argmax is this pixel; rounded to fp16
+// like the stored tensor (pool.h, pool_grad_piece)
+__device__ __forceinline__ void sb_pool_grad(const piece_t* pool, int h, int w, int y0, int x0, int cp, int Po, int Qo,
+                                             float (&acc)[8]) {
+  const int po0 = h >> 1, po1 = (h + 1) >> 1, qo0 = w >> 1, qo1 = (w + 1) >> 1;
+  const bool vp1 = po1 != po0 && po1 < Po, vq1 = qo1 != qo0 && qo1 < Qo;
+  const int pos[2] = {po0, vp1 ? po1 : po0}, qos[2] = {qo0, vq1 ? qo1 : qo0};
+  const bool valid[4] = {true, vq1, vp1, vp1 && vq1};
+  PieceView<half> gv[4];
+  unsigned long long packed[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int win = (pos[k >> 1] - (y0 >> 1)) * kSbPC + (qos[k & 1] - (x0 >> 1));
+    gv[k].p = pool[win * 8 + cp];
+    packed[k] = reinterpret_cast<const unsigned long long*>(pool + kSbGP)[win * 8 + cp];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int po = pos[k >> 1], qo = qos[k & 1];
+    const unsigned mytap = (unsigned)((h - (po * 2 - 1)) * 3 + (w - (qo * 2 - 1)));
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (valid[k] && ((unsigned)(packed[k] >> (8 * e)) & 0xffu) == mytap) acc[e] += (float)gv[k].e[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = (float)(half)acc[e];
+}
+
+__device__ __forceinline__ void sb_tile_coords(const StemBwdArgs& a, int tile, int& b, int& y0, int& x0) {
+  const int txi = tile % a.tiles_x;
+  const int tmp = tile / a.tiles_x;
+  b = tmp / a.tiles_y;
+  y0 = (tmp % a.tiles_y) * kSbTH;
+  x0 = txi * kSbTW;
+}
+
+// ---- 1. BatchNorm backward sums -----------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256, 2) stem_bn_reduce_kernel(StemBwdArgs a) {
+  __shared__ piece_t smem[2 * kSbPOOL];  // ONE LDS object: two pool buffers (reused for the block reduction at the end)
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ntiles = a.B * a.tiles_x * a.tiles_y;
+  const __amdgpu_buffer_rsrc_t rsrc_g = make_rsrc(a.gp, (long)a.B * a.Po * a.Qo * 64 * 2L);
+  const __amdgpu_buffer_rsrc_t rsrc_i = make_rsrc(a.idx, (long)a.B * a.Po * a.Qo * 64L);
+  const int cp = t & 7;
+  float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cp * 8 + e;
+    mu[e] = a.mean[c];
+    is[e] = a.invstd[c];
+    sc[e] = a.gamma[c] * is[e];
+    sh[e] = a.beta[c] - mu[e] * sc[e];
+    s1[e] = s2[e] = 0.f;
+  }
+  int tile = blockIdx.x, b, y0, x0;
+  if (tile < ntiles) {
+    sb_tile_coords(a, tile, b, y0, x0);
+    sb_issue_pool(a, rsrc_g, rsrc_i, b, y0, x0, &smem[0], t, wave);
+  }
+  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    sb_tile_coords(a, tile, b, y0, x0);
+    // conv-output pieces of this thread: pixels (t >> 3) + 32 i, i < 4 (plain loads, requested before the wait)
+    PieceView<half> vy[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
+      ok[i] = oy < a.H0 && ox < a.W0;
+      const int oyc = ok[i] ? oy : a.H0 - 1, oxc = ok[i] ? ox : a.W0 - 1;
+      vy[i].p = *reinterpret_cast<const piece_t*>(a.y + (((long)b * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();  // this tile's windows are staged for everyone; everyone is done with the other buffer
+    if (tile + (int)gridDim.x < ntiles) {
+      int nb, ny0, nx0;
+      sb_tile_coords(a, tile + gridDim.x, nb, ny0, nx0);
+      sb_issue_pool(a, rsrc_g, rsrc_i, nb, ny0, nx0, &smem[((it + 1) & 1) * kSbPOOL], t, wave);
+    }
+    const piece_t* pool = &smem[(it & 1) * kSbPOOL];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: the gathers are LDS reads, nothing to overlap; keeps registers low
+      const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
+      float g[8];
+      sb_pool_grad(pool, ok[i] ? oy : y0, ok[i] ? ox : x0, y0, x0, cp, a.Po, a.Qo, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yv = (float)vy[i].e[e];
+        float gv = ok[i] ? g[e] : 0.f;
+        if (!(yv * sc[e] + sh[e] > 0.f)) gv = 0.f;
+        s1[e] += gv;
+        s2[e] += gv * (yv - mu[e]) * is[e];
+      }
+    }
+  }
+  // block reduction over the 32 threads that share a channel piece (t & 7), then fp64 atomics
+  wait_vmcnt<0>();
+  __syncthreads();
+  float* r1 = reinterpret_cast<float*>(&smem[0]);  // [256 threads][16]: 16 KB of the 24 KB
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    r1[t * 16 + e] = s1[e];
+    r1[t * 16 + 8 + e] = s2[e];
+  }
+  __syncthreads();
+  if (t < 128) {  // t = which * 64 + channel
+    const int which = t >> 6, c = t & 63, ccp = c >> 3, ce = c & 7;
+    double s = 0;
+    for (int l = 0; l < 32; ++l) s += r1[(l * 8 + ccp) * 16 + which * 8 + ce];
+    double* row = a.accum + (long)((int)blockIdx.x % a.accum_rows) * 2 * 64;
+    atomicAdd(row + which * 64 + c, s);
+  }
+}
+
+// ---- 2. weight gradient ---------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemBwdArgs a) {
+  constexpr int TH = kSbTH, TW = kSbTW;
+  constexpr int IH = 2 * TH + 5, IW = TW + 3, IPIECES = IH * IW;  // 13 rows x 35 pairs
+  constexpr int IPASS = (IPIECES + 255) / 256, IMG = IPASS * 256;
+  constexpr int GYP = TH * TW * 8;  // pieces of the d(conv output) tile: 128 pixels x 64 halves
+  // ONE LDS object: [2 input images][2 pool buffers][d(conv output) tile]
+  __shared__ piece_t smem[2 * IMG + 2 * kSbPOOL + GYP];
+  half* gyt = reinterpret_cast<half*>(&smem[2 * IMG + 2 * kSbPOOL]);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ntiles = a.B * a.tiles_x * a.tiles_y;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.xpad, (long)a.B * a.Hp * a.Wp2 * 16L);
-  auto issue_image = [&](int tile, int buf) {
-    const int txi = tile % a.tiles_x;
-    const int tmp = tile / a.tiles_x;
-    const int tyi = tmp % a.tiles_y, b = tmp / a.tiles_y;
-    const int y0 = tyi * TH, x0 = txi * TW;
+  const __amdgpu_buffer_rsrc_t rsrc_g = make_rsrc(a.gp, (long)a.B * a.Po * a.Qo * 64 * 2L);
+  const __amdgpu_buffer_rsrc_t rsrc_i = make_rsrc(a.idx, (long)a.B * a.Po * a.Qo * 64L);
+  auto issue_tile = [&](int tile, int buf) {  // input image + pooled windows of a tile
+    int b, y0, x0;
+    sb_tile_coords(a, tile, b, y0, x0);
 #pragma unroll
     for (int i = 0; i < IPASS; ++i) {
       const int q = t + i * 256;
@@ -65,11 +215,12 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemWgradArgs
       const int iy = 2 * y0 + row, ip = x0 + col;
       const bool ok = q < IPIECES && iy < a.Hp && ip < a.Wp2;
       const unsigned off = ok ? (unsigned)(((b * a.Hp + iy) * a.Wp2 + ip) * 16) : ~0u;
-      dma16(rsrc, off, 0u, &smem[buf * IPASS * 256 + wave * 64 + i * 256]);
+      dma16(rsrc, off, 0u, &smem[buf * IMG + wave * 64 + i * 256]);
     }
+    sb_issue_pool(a, rsrc_g, rsrc_i, b, y0, x0, &smem[2 * IMG + buf * kSbPOOL], t, wave);
   };
   int tile = blockIdx.x;
-  if (tile < ntiles) issue_image(tile, 0);
+  if (tile < ntiles) issue_tile(tile, 0);
 
   // elementwise role: this thread always handles channel piece t & 7 -> its 8 channels' coefficients live in registers
   const int cp = t & 7;
@@ -95,7 +246,7 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemWgradArgs
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = j * 32 + (gq & 1) * 16 + chunk * 4;
-    aA[j] = (unsigned)(2 * IPASS * 256 * 16) +
+    aA[j] = (unsigned)((2 * IMG + 2 * kSbPOOL) * 16) +
             (unsigned)(((kgrp + src_row) * 64 + (((col >> 3) ^ wg_swz<8>(src_row)) * 8) + (col & 7)) * 2);
   }
   // B operand (input image, rows = consecutive pixel pairs of 16 bytes): source lane (row e = src_row, chunk) of column
@@ -112,49 +263,42 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemWgradArgs
       for (int r = 0; r < 16; ++r) acc[j][ri][r] = 0.f;
 
   for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-    const int txi = tile % a.tiles_x;
-    const int tmp = tile / a.tiles_x;
-    const int tyi = tmp % a.tiles_y, b = tmp / a.tiles_y;
-    const int y0 = tyi * TH, x0 = txi * TW;
-    __syncthreads();  // everyone is done with the previous tile's LDS reads (gradient tile, other image)
-    if (tile + (int)gridDim.x < ntiles) issue_image(tile + gridDim.x, (it + 1) & 1);
-    // ---- d(conv output) of the tile -> LDS: 8 pieces (pixel, 8 channels) per thread, in four groups of two whose loads
-    // (conv output + the four candidate windows of the pool gradient, unconditional at clamped coordinates) are all
-    // requested before the first use
+    int b, y0, x0;
+    sb_tile_coords(a, tile, b, y0, x0);
+    // conv-output pieces of this thread: pixels (t >> 3) + 32 i, i < 4 (plain loads, requested before the wait)
+    PieceView<half> vy[4];
+    bool ok[4];
 #pragma unroll
-    for (int grp4 = 0; grp4 < 4; ++grp4) {
-      PieceView<half> vy[2];
-      float g[2][8];
-      bool ok[2];
-      int pxs[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int px = (t >> 3) + 32 * (grp4 * 2 + u);  // tile pixel: row px >> 5, column px & 31
-        const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
-        ok[u] = oy < a.H0 && ox < a.W0;
-        pxs[u] = px;
-        const int oyc = oy < a.H0 ? oy : a.H0 - 1, oxc = ox < a.W0 ? ox : a.W0 - 1;
-        vy[u].p = *reinterpret_cast<const piece_t*>(a.y + (((long)b * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
-        pool_grad_piece<half>(a.idx, a.gp, b, oyc, oxc, cp, 8, a.Po, a.Qo, g[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        PieceView<half> o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float yv = (float)vy[u].e[e];
-          float gv = g[u][e];
-          if (!(yv * k1[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
-          const float xh = (yv - mu[e]) * is[e];
-          o.e[e] = ok[u] ? (half)(k1[e] * (gv - mg[e] - xh * mgx[e])) : (half)0.f;
-        }
-        *reinterpret_cast<piece_t*>(gyt + pxs[u] * 64 + ((cp ^ wg_swz<8>(pxs[u])) * 8)) = o.p;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
+      ok[i] = oy < a.H0 && ox < a.W0;
+      const int oyc = ok[i] ? oy : a.H0 - 1, oxc = ok[i] ? ox : a.W0 - 1;
+      vy[i].p = *reinterpret_cast<const piece_t*>(a.y + (((long)b * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
     }
-    wait_vmcnt<0>();   // this tile's image (requested one tile ago, or in the prologue)
-    __syncthreads();   // gradient tile and image complete for every wave
-    // ---- GEMM: 16 K-steps of 16 pixels (tile row ty, half hx)
-    const unsigned img = (unsigned)((it & 1) * IPASS * 256 * 16);
+    wait_vmcnt<0>();
+    __syncthreads();  // this tile's image and windows are staged; everyone is done with the previous tile's LDS reads
+    if (tile + (int)gridDim.x < ntiles) issue_tile(tile + gridDim.x, (it + 1) & 1);
+    // ---- d(conv output) of the tile -> LDS
+    const piece_t* pool = &smem[2 * IMG + (it & 1) * kSbPOOL];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
+      float g[8];
+      sb_pool_grad(pool, ok[i] ? oy : y0, ok[i] ? ox : x0, y0, x0, cp, a.Po, a.Qo, g);
+      PieceView<half> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yv = (float)vy[i].e[e];
+        float gv = g[e];
+        if (!(yv * k1[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
+        const float xh = (yv - mu[e]) * is[e];
+        o.e[e] = ok[i] ? (half)(k1[e] * (gv - mg[e] - xh * mgx[e])) : (half)0.f;
+      }
+      *reinterpret_cast<piece_t*>(gyt + px * 64 + ((cp ^ wg_swz<8>(px)) * 8)) = o.p;
+    }
+    __syncthreads();  // gradient tile complete
+    // ---- GEMM: 8 K-steps of 16 pixels (tile row ty, half hx)
+    const unsigned img = (unsigned)((it & 1) * IMG * 16);
 #pragma unroll 2
     for (int ks = 0; ks < 2 * TH; ++ks) {
       const int ty = ks >> 1, hx = ks & 1;
@@ -197,14 +341,26 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemWgradArgs
   }
 }
 
-inline void launch_stem_wgrad(StemWgradArgs a, int B, int H, int W, int Wp, hipStream_t stream) {
+inline void stem_bwd_geometry(StemBwdArgs& a, int B, int H, int W, int Wp) {
   a.B = B; a.Hp = H + 6; a.Wp2 = Wp / 2;
   a.H0 = (H - 1) / 2 + 1; a.W0 = (W - 1) / 2 + 1;
   a.Po = (a.H0 + 2 - 3) / 2 + 1; a.Qo = (a.W0 + 2 - 3) / 2 + 1;
-  a.tiles_x = cdiv(a.W0, kStemTW); a.tiles_y = cdiv(a.H0, kStemTH);
-  static const int wgs = getenv("MN_STEM_WGS") ? atoi(getenv("MN_STEM_WGS")) : 512;
-  const int ntiles = B * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(ntiles < wgs ? ntiles : wgs), dim3(256), 0, stream, a);
+  a.tiles_x = cdiv(a.W0, kSbTW); a.tiles_y = cdiv(a.H0, kSbTH);
+}
+inline int stem_bwd_grid(const StemBwdArgs& a, int per_cu) {
+  static const int wgs = getenv("MN_STEM_WGS") ? atoi(getenv("MN_STEM_WGS")) : 0;
+  const int want = wgs > 0 ? wgs : 256 * per_cu;
+  const int ntiles = a.B * a.tiles_x * a.tiles_y;
+  return ntiles < want ? ntiles : want;
+}
+// sums into a.accum (zero on entry); the caller runs bn_finalize_bwd_kernel on them
+inline void launch_stem_bn_reduce(StemBwdArgs a, int B, int H, int W, int Wp, hipStream_t stream) {
+  stem_bwd_geometry(a, B, H, W, Wp);
+  hipLaunchKernelGGL(stem_bn_reduce_kernel, dim3(stem_bwd_grid(a, 2)), dim3(256), 0, stream, a);
+}
+inline void launch_stem_wgrad(StemBwdArgs a, int B, int H, int W, int Wp, hipStream_t stream) {
+  stem_bwd_geometry(a, B, H, W, Wp);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(stem_bwd_grid(a, 2)), dim3(256), 0, stream, a);
 }
 
 }  // namespace mn

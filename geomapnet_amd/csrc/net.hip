@@ -657,7 +657,7 @@ struct Plan : PlanBase {
     if (dirty || zero_grads) {
       hipStream_t side = fork_wgrad(s);
       if (dirty) repack_tail(side);
-      if (zero_grads) hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, side);
+      if (zero_grads) launch_zero_fill(grads, L.param_floats, side);
     }
     conv_bn_stats(stem, xpad, training, s);
     if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
@@ -828,7 +828,7 @@ struct Plan : PlanBase {
   void head_backward(hipStream_t s) {
     int F = cfg.feat_dim;
     float unscale = 1.f / cur_scale;
-    if (!grads_zeroed) hipMemsetAsync(grads, 0, (size_t)L.param_floats * 4, s);  // optim.learner.zero_grad()
+    if (!grads_zeroed) launch_zero_fill(grads, L.param_floats, s);  // optim.learner.zero_grad()
     grads_zeroed = false;
     run_criterion(poses, cur_targets, cur_loss, dposes, grads + L.crit, s);
     post_loss(cur_loss, s);

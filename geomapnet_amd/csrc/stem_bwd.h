@@ -129,45 +129,55 @@ static __global__ void __launch_bounds__(256, 2) stem_bn_reduce_kernel(StemBwdAr
     sh[e] = a.beta[c] - mu[e] * sc[e];
     s1[e] = s2[e] = 0.f;
   }
+  // conv-output pieces of this thread in a tile: pixels (t >> 3) + 32 i, i < 4 -- plain loads, requested ONE TILE AHEAD
+  // (with the tile's windows) so that neither latency is exposed
+  auto load_y = [&](int tl, PieceView<half> (&v)[4]) {
+    int lb, ly0, lx0;
+    sb_tile_coords(a, tl, lb, ly0, lx0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = (t >> 3) + 32 * i, oy = ly0 + (px >> 5), ox = lx0 + (px & 31);
+      const int oyc = oy < a.H0 ? oy : a.H0 - 1, oxc = ox < a.W0 ? ox : a.W0 - 1;
+      v[i].p = *reinterpret_cast<const piece_t*>(a.y + (((long)lb * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
+    }
+  };
   int tile = blockIdx.x, b, y0, x0;
+  PieceView<half> vy[4], vyn[4];
   if (tile < ntiles) {
     sb_tile_coords(a, tile, b, y0, x0);
     sb_issue_pool(a, rsrc_g, rsrc_i, b, y0, x0, &smem[0], t, wave);
+    load_y(tile, vy);
   }
   for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
     sb_tile_coords(a, tile, b, y0, x0);
-    // conv-output pieces of this thread: pixels (t >> 3) + 32 i, i < 4 (plain loads, requested before the wait)
-    PieceView<half> vy[4];
-    bool ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
-      ok[i] = oy < a.H0 && ox < a.W0;
-      const int oyc = ok[i] ? oy : a.H0 - 1, oxc = ok[i] ? ox : a.W0 - 1;
-      vy[i].p = *reinterpret_cast<const piece_t*>(a.y + (((long)b * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
-    }
     wait_vmcnt<0>();
     __syncthreads();  // this tile's windows are staged for everyone; everyone is done with the other buffer
-    if (tile + (int)gridDim.x < ntiles) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    if (more) {
       int nb, ny0, nx0;
       sb_tile_coords(a, tile + gridDim.x, nb, ny0, nx0);
       sb_issue_pool(a, rsrc_g, rsrc_i, nb, ny0, nx0, &smem[((it + 1) & 1) * kSbPOOL], t, wave);
+      load_y(tile + gridDim.x, vyn);
     }
     const piece_t* pool = &smem[(it & 1) * kSbPOOL];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: the gathers are LDS reads, nothing to overlap; keeps registers low
       const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
+      const bool ok = oy < a.H0 && ox < a.W0;
       float g[8];
-      sb_pool_grad(pool, ok[i] ? oy : y0, ok[i] ? ox : x0, y0, x0, cp, a.Po, a.Qo, g);
+      sb_pool_grad(pool, ok ? oy : y0, ok ? ox : x0, y0, x0, cp, a.Po, a.Qo, g);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float yv = (float)vy[i].e[e];
-        float gv = ok[i] ? g[e] : 0.f;
+        float gv = ok ? g[e] : 0.f;
         if (!(yv * sc[e] + sh[e] > 0.f)) gv = 0.f;
         s1[e] += gv;
         s2[e] += gv * (yv - mu[e]) * is[e];
       }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vy[i].p = vyn[i].p;
     }
   }
   // block reduction over the 32 threads that share a channel piece (t & 7), then fp64 atomics
@@ -262,29 +272,37 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemBwdArgs a
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][ri][r] = 0.f;
 
+  // conv-output pieces of this thread in a tile: pixels (t >> 3) + 32 i, i < 4 -- plain loads, requested one tile ahead
+  auto load_y = [&](int tl, PieceView<half> (&v)[4]) {
+    int lb, ly0, lx0;
+    sb_tile_coords(a, tl, lb, ly0, lx0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = (t >> 3) + 32 * i, oy = ly0 + (px >> 5), ox = lx0 + (px & 31);
+      const int oyc = oy < a.H0 ? oy : a.H0 - 1, oxc = ox < a.W0 ? ox : a.W0 - 1;
+      v[i].p = *reinterpret_cast<const piece_t*>(a.y + (((long)lb * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
+    }
+  };
+  PieceView<half> vy[4], vyn[4];
+  if (tile < ntiles) load_y(tile, vy);
   for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
     int b, y0, x0;
     sb_tile_coords(a, tile, b, y0, x0);
-    // conv-output pieces of this thread: pixels (t >> 3) + 32 i, i < 4 (plain loads, requested before the wait)
-    PieceView<half> vy[4];
-    bool ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
-      ok[i] = oy < a.H0 && ox < a.W0;
-      const int oyc = ok[i] ? oy : a.H0 - 1, oxc = ok[i] ? ox : a.W0 - 1;
-      vy[i].p = *reinterpret_cast<const piece_t*>(a.y + (((long)b * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
-    }
     wait_vmcnt<0>();
     __syncthreads();  // this tile's image and windows are staged; everyone is done with the previous tile's LDS reads
-    if (tile + (int)gridDim.x < ntiles) issue_tile(tile + gridDim.x, (it + 1) & 1);
+    const bool more = tile + (int)gridDim.x < ntiles;
+    if (more) {
+      issue_tile(tile + gridDim.x, (it + 1) & 1);
+      load_y(tile + gridDim.x, vyn);
+    }
     // ---- d(conv output) of the tile -> LDS
     const piece_t* pool = &smem[2 * IMG + (it & 1) * kSbPOOL];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
+      const bool ok = oy < a.H0 && ox < a.W0;
       float g[8];
-      sb_pool_grad(pool, ok[i] ? oy : y0, ok[i] ? ox : x0, y0, x0, cp, a.Po, a.Qo, g);
+      sb_pool_grad(pool, ok ? oy : y0, ok ? ox : x0, y0, x0, cp, a.Po, a.Qo, g);
       PieceView<half> o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -292,9 +310,13 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemBwdArgs a
         float gv = g[e];
         if (!(yv * k1[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
         const float xh = (yv - mu[e]) * is[e];
-        o.e[e] = ok[i] ? (half)(k1[e] * (gv - mg[e] - xh * mgx[e])) : (half)0.f;
+        o.e[e] = ok ? (half)(k1[e] * (gv - mg[e] - xh * mgx[e])) : (half)0.f;
       }
       *reinterpret_cast<piece_t*>(gyt + px * 64 + ((cp ^ wg_swz<8>(px)) * 8)) = o.p;
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vy[i].p = vyn[i].p;
     }
     __syncthreads();  // gradient tile complete
     // ---- GEMM: 8 K-steps of 16 pixels (tile row ty, half hx)

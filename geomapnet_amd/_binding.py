@@ -75,6 +75,8 @@ _PROTOS = {
     "mn_op_conv_halo": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_void, c_i, c_void, c_void, c_void, c_f,
                               c_void]),
     "mn_op_conv_halo_grid_m": (c_i, [C.POINTER(GatherGeom)]),
+    "mn_op_conv_halo_pp": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_i, c_i, c_void, c_void, c_void, c_f,
+                                 c_i, c_void]),
     "mn_op_conv_dgrad": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_i,
                                c_void, c_void]),
     "mn_op_stem_conv": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),

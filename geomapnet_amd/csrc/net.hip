@@ -17,6 +17,7 @@
 #include "igemm.h"
 #include "dgrad.h"
 #include "halo.h"
+#include "halo_pp.h"
 #include "layout.h"
 #include "optim.h"
 #include "pool.h"
@@ -614,6 +615,8 @@ struct Plan : PlanBase {
     auto* tp = timer.begin(0, s);
     if (&u == &stem && DT == MN_F16 && use_stem_kernel)  // weights in registers, input pairs read straight from LDS (stem.h)
       launch_stem_conv((const half*)x, (const half*)u.wf, (half*)u.y, training ? u.accum_f : nullptr, ACC_ROWS, B, H, W, Wp, s);
+    else if (halo_path(u.gf) && use_halo_pp && conv_halo_pp_applies(u.gf, ep))
+      launch_conv_halo_pp(u.gf, (const half*)x, (const half*)u.wf, ep, s);
     else if (halo_path(u.gf))
       launch_conv_halo(u.gf, (const half*)x, (const half*)u.wf, ep, s);
     else
@@ -622,6 +625,8 @@ struct Plan : PlanBase {
   }
   // layer1's 64-channel 3x3 convolutions (forward and data gradient) run from an LDS-resident input halo (halo.h)
   bool use_halo = DT == MN_F16 && !(getenv("MN_HALO") && atoi(getenv("MN_HALO")) == 0);
+  // ... in the persistent two-group form (halo_pp.h) when MN_HALO_PP=1
+  bool use_halo_pp = getenv("MN_HALO_PP") && atoi(getenv("MN_HALO_PP")) != 0;
   bool use_stem_kernel = !(getenv("MN_STEM_KERNEL") && atoi(getenv("MN_STEM_KERNEL")) == 0);
   bool halo_path(const GatherGeom& g) const { return use_halo && conv_halo_applies(g); }
   void bn_finalize(Unit& u, hipStream_t s) {  // statistics -> (scale, shift), mean / invstd, running statistics
@@ -757,7 +762,9 @@ struct Plan : PlanBase {
     ep.sk_ws = sk_ws;
     ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
-    if (halo_path(u.dg.full))
+    if (halo_path(u.dg.full) && use_halo_pp && conv_halo_pp_applies(u.dg.full, ep))
+      launch_conv_halo_pp(u.dg.full, (const half*)u.gy, (const half*)u.wd, ep, s);
+    else if (halo_path(u.dg.full))
       launch_conv_halo(u.dg.full, (const half*)u.gy, (const half*)u.wd, ep, s);
     else
       launch_conv_dgrad<T>(u.dg, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page, parity_dgrad);

@@ -10,6 +10,7 @@
 #include "igemm.h"
 #include "dgrad.h"
 #include "halo.h"
+#include "halo_pp.h"
 #include "optim.h"
 #include "pgo.h"
 #include "pool.h"
@@ -90,6 +91,21 @@ extern "C" int mn_op_conv_halo(const mn_gather_geom* gg, const void* A, const vo
   return check_launch("conv_halo");
 }
 extern "C" int mn_op_conv_halo_grid_m(const mn_gather_geom* gg) { return conv_halo_grid_m(to_geom(gg)); }
+
+extern "C" int mn_op_conv_halo_pp(const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc, double* stats_accum,
+                                 int stats_rows, int relu, const void* res, const void* res_gate, const void* out_gate,
+                                 float alpha, int wgs, void* stream) {
+  begin_call();
+  GatherGeom g = to_geom(gg);
+  if (int e = check_geom(g, MN_F16)) return e;
+  Epilogue ep;
+  ep.out = out; ep.ldc = ldc; ep.stats = nullptr; ep.bias = nullptr; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
+  ep.out_gate = out_gate; ep.alpha = alpha; ep.stats_accum = stats_accum; ep.stats_rows = stats_rows;
+  if (!conv_halo_pp_applies(g, ep))
+    return fail("conv_halo_pp: fp16 3x3 stride-1 same-size convolutions of 64 -> 64 channels only (stats_rows > 0 with stats_accum)");
+  launch_conv_halo_pp(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, wgs);
+  return check_launch("conv_halo_pp");
+}
 
 extern "C" int mn_op_igemm_streamk(int dtype, const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc,
                                    float* stats, const float* bias, int relu, const void* res, const void* res_gate,

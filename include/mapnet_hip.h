@@ -204,6 +204,13 @@ int mn_op_conv_halo(const mn_gather_geom* g, const void* A, const void* Bw, void
                     const float* bias, int relu, const void* res, const void* res_gate, const void* out_gate, float alpha,
                     void* stream);
 int mn_op_conv_halo_grid_m(const mn_gather_geom* g);
+/* The same convolution for exactly 64 output channels in the persistent form (csrc/halo_pp.h): one 8-wave workgroup per
+ * CU, two wave groups alternating between the MFMA loop of one tile and the epilogue + next halo fetch of another, all
+ * nine weight slices LDS-resident.  stats_accum: [stats_rows][2][64] fp64 column sums (sum, sum of squares), ADDED to
+ * atomically, or NULL.  wgs: number of persistent workgroups, 0 = one per CU. */
+int mn_op_conv_halo_pp(const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, double* stats_accum,
+                       int stats_rows, int relu, const void* res, const void* res_gate, const void* out_gate, float alpha,
+                       int wgs, void* stream);
 /* Data gradient of a convolution (what autograd computes for conv2d's input, torch 0.4.1 `loss.backward()` under
  * common/train.py:351): gx[B][Hin][Win][Cin] = conv_transpose(gy[B][Hout][Wout][Cout], W) (+ res, res only where
  * res_gate > 0), zeroed where out_gate <= 0.  wd: weights in the data-gradient layout [Cin][k][k][Cout].  stride 1 or 2;

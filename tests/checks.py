@@ -196,10 +196,11 @@ def check_conv_dgrad_op(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, par
     assert err <= OUT_TOL[dtype] * want.abs().max().item() + 1e-6, err
 
 
-def check_conv_halo(lib, dev, B, H, W, Cout=64, dgrad=False, mode="plain", seed=21):
+def check_conv_halo(lib, dev, B, H, W, Cout=64, dgrad=False, mode="plain", seed=21, pp_wgs=None):
     """fp16 3x3 stride-1 convolution of 64 input channels from an LDS-resident halo tile (csrc/halo.h) vs torch fp64:
     forward (with BatchNorm column sums) or data gradient, epilogue variants as check_conv_dgrad_op; ragged tiles
-    (H, W not multiples of 16) exercise the out-of-image masks"""
+    (H, W not multiples of 16) exercise the out-of-image masks.  pp_wgs: the persistent two-group form (csrc/halo_pp.h)
+    with that many workgroups (0 = one per CU); fewer workgroups than tiles walks the phase loop"""
     _fresh()
     td, Cin, k = torch.float16, 64, 3
     gen = torch.Generator().manual_seed(seed)
@@ -237,8 +238,12 @@ def check_conv_halo(lib, dev, B, H, W, Cout=64, dgrad=False, mode="plain", seed=
             ogate = ogate.to(dev)
         res = res.to(dev)
     out = torch.full((B, H, W, N), 7.0, dtype=td, device=dev)
-    st = torch.zeros(lib.op_conv_halo_grid_m(C.byref(g)), 2, N, device=dev) if not dgrad else None
-    lib.check(lib.op_conv_halo(C.byref(g), K(a), K(bw), K(out), N, K(st), None, 0, K(res), K(rgate), K(ogate), f32(1), None))
+    if pp_wgs is not None:
+        st = torch.zeros(5, 2, N, device=dev, dtype=torch.double) if not dgrad else None
+        lib.check(lib.op_conv_halo_pp(C.byref(g), K(a), K(bw), K(out), N, K(st), 5, 0, K(res), K(rgate), K(ogate), f32(1), pp_wgs, None))
+    else:
+        st = torch.zeros(lib.op_conv_halo_grid_m(C.byref(g)), 2, N, device=dev) if not dgrad else None
+        lib.check(lib.op_conv_halo(C.byref(g), K(a), K(bw), K(out), N, K(st), None, 0, K(res), K(rgate), K(ogate), f32(1), None))
     dev_sync(dev)
     err = (out.cpu().double() - want).abs().max().item()
     assert err <= OUT_TOL[1] * want.abs().max().item() + 1e-6, err

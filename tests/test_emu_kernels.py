@@ -133,6 +133,20 @@ def test_conv_halo(lib, case):
     checks.check_conv_halo(lib, DEV, B, H, W, Cout=Cout, dgrad=dgrad, mode=mode)
 
 
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, False, "plain", 0),      # one tile per workgroup: phases 0 and 1 only
+    (1, 20, 22, False, "plain", 1),      # four ragged tiles walked by ONE workgroup (both groups, five phases)
+    (2, 33, 20, False, "plain", 3),      # 12 tiles over 3 workgroups, statistics across tiles
+    (1, 20, 22, True, "res_gate", 1),
+    (2, 17, 35, True, "out_gate", 2),    # 12 tiles over 2 workgroups
+    (1, 9, 11, True, "plain", 0),        # smaller than a tile
+])
+def test_conv_halo_pp(lib, case):
+    """persistent two-group form of the layer1 convolution (csrc/halo_pp.h)"""
+    B, H, W, dgrad, mode, wgs = case
+    checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=dgrad, mode=mode, pp_wgs=wgs)
+
+
 def _random_cases(seed, n):
     import numpy as np
     rng = np.random.default_rng(seed)

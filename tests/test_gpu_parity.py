@@ -55,6 +55,20 @@ def test_conv_halo(lib, case):
     checks.check_conv_halo(lib, DEV, B, H, W, Cout=Cout, dgrad=dgrad, mode=mode)
 
 
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, False, "plain", 0), (1, 20, 22, False, "plain", 1), (2, 33, 20, False, "plain", 3),
+    (1, 20, 22, True, "res_gate", 1), (2, 17, 35, True, "out_gate", 2), (1, 9, 11, True, "plain", 0),
+    (6, 64, 86, False, "plain", 0),      # layer1 geometry at 256x341: 144 tiles
+    (6, 64, 86, False, "plain", 7),      # ... 20-21 tiles per workgroup
+    (6, 64, 86, True, "out_gate", 16),
+    (6, 64, 86, True, "res_gate", 5),
+])
+def test_conv_halo_pp(lib, case):
+    """persistent two-group form of the layer1 convolution (csrc/halo_pp.h)"""
+    B, H, W, dgrad, mode, wgs = case
+    checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=dgrad, mode=mode, pp_wgs=wgs)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape,mode", [
     ((2, 8, 11, 64, 128, 3, 2, 1), "plain"), ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"), ((1, 8, 12, 64, 128, 3, 2, 1), "res_gate"),

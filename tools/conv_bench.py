@@ -60,6 +60,14 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
         th_d = timeit(lambda: lib.op_conv_halo(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, None, one, None)) if Co == 64 else float("nan")
         th_r = timeit(lambda: lib.op_conv_halo(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), None, ptr(gate), one, None)) if Co == 64 else float("nan")
         print("%-22s halo kernel: fwd %7.1f us %6.0f TF | dgrad %7.1f us | +res+out_gate %7.1f us" % (name, th_f, flops / th_f / 1e6, th_d, th_r), flush=True)
+        if Co == 64:  # persistent two-group form (halo_pp.h); CB_PP_WGS = workgroup counts to try
+            acc = torch.zeros(8, 2, 64, dtype=torch.double, device="cuda")
+            for wgs in [int(v) for v in os.environ.get("CB_PP_WGS", "0").split(",")]:
+                tp_f = timeit(lambda: lib.op_conv_halo_pp(C.byref(g), ptr(x), ptr(w), ptr(y), Co, ptr(acc), 8, 0, None, None, None, one, wgs, None))
+                tp_d = timeit(lambda: lib.op_conv_halo_pp(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, 0, 0, None, None, None, one, wgs, None))
+                tp_r = timeit(lambda: lib.op_conv_halo_pp(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, 0, 0, ptr(res), None, ptr(gate), one, wgs, None))
+                print("%-22s halo_pp wgs=%d: fwd+stats %7.1f us %6.0f TF | dgrad %7.1f us | +res+out_gate %7.1f us"
+                      % (name, wgs, tp_f, flops / tp_f / 1e6, tp_d, tp_r), flush=True)
     io = (x.numel() + y.numel()) * x.element_size()
     print("%-22s M=%8d N=%4d K=%5d  fwd %7.1f us %6.0f TF (io %5.2f TB/s) | dgrad %7.1f us %6.0f TF | +res %7.1f us | wgrad %7.1f us %6.0f TF"
           % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, io / t_f / 1e6, t_d, flops / t_d / 1e6, t_r, t_w, flops / t_w / 1e6), flush=True)

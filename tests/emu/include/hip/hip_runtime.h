@@ -355,6 +355,15 @@ inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r,
   if ((unsigned long)(unsigned)voffset + 16 <= r.num_records) memcpy(&v, r.base + (unsigned)voffset + (unsigned)soffset, 16);
   return v;
 }
+typedef unsigned emu_u32x2 __attribute__((ext_vector_type(2)));
+inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u32x2 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+  if ((unsigned long)(unsigned)voffset + 8 <= r.num_records) memcpy(const_cast<char*>(r.base) + (unsigned)voffset + (unsigned)soffset, &v, 8);
+}
+inline emu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+  emu_u32x2 v = {0, 0};
+  if ((unsigned long)(unsigned)voffset + 8 <= r.num_records) memcpy(&v, r.base + (unsigned)voffset + (unsigned)soffset, 8);
+  return v;
+}
 inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width) {
   return (int)((unsigned)v << (32 - off - width)) >> (32 - width);
 }

@@ -37,7 +37,9 @@ union Half4View {
   half e[4];
 };
 
-template <bool STATS>
+// ABL (timing experiments only, ablation build, results are wrong): bit 0 = halo DMA only for each group's first tile,
+// bit 1 = no fragment reads, bit 2 = no stores / residual / gate loads, bit 3 = no MFMA.  PRIO: s_setprio of the MFMA loop.
+template <bool STATS, int ABL = 0, int PRIO = 0>
 static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom g, const half* __restrict__ A,
                                                                      const half* __restrict__ Bw, Epilogue ep, int tiles_x,
                                                                      int tiles_y, int ntiles) {
@@ -142,6 +144,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
     constexpr int PD = 2;  // sub-steps a fragment is read ahead of its MFMAs
     PieceView<half> fa[4][2], fb[4][2];
     auto load_frags = [&](int tap, int ks) __attribute__((always_inline)) {
+      if constexpr ((ABL & 2) != 0) return;
       const int piece = ks * 2 + kh;
       const int hp0 = hpf + sg * ((tap / 3) * HW + tap % 3);
 #pragma unroll
@@ -155,6 +158,13 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
         fb[ks & (2 * PD - 1)][j].p = smem[tap * 512 + row * NP + (piece ^ ((row >> 1) & 7))];
       }
     };
+    if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[k][i].p = fb[k][i].p = zero_piece();
+    }
+    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
 #pragma unroll
     for (int k = 0; k < PD; ++k) load_frags(0, k);
 #pragma unroll 1
@@ -169,11 +179,17 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)  // weights = A operand (rows), pixels = B (columns)
-            mma_piece<half>(fb[ks & (2 * PD - 1)][j], fa[ks & (2 * PD - 1)][i], acc[i][j]);
+          for (int j = 0; j < 2; ++j) {  // weights = A operand (rows), pixels = B (columns)
+            if constexpr ((ABL & 8) == 0) {
+              mma_piece<half>(fb[ks & (2 * PD - 1)][j], fa[ks & (2 * PD - 1)][i], acc[i][j]);
+            } else {
+              asm volatile("" ::"v"(fa[ks & (2 * PD - 1)][i].p), "v"(fb[ks & (2 * PD - 1)][j].p));
+            }
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
   };
 
   // memory-side phase of this group: the residual / gate values of the finished tile are requested first (loads return
@@ -191,7 +207,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
       voff[i] = okp[i] ? (unsigned)((((b * gP + y) * gQ + x) * ldc) * 2 + kh * 8) : kOob;
     }
     Half4View rv[2][2][4], gv[2][2][4];  // residual; THE gate: res_gate or out_gate (never both: conv_halo_pp_applies)
-    if (has_res || has_gate || has_ogate) {
+    if ((ABL & 4) == 0 && (has_res || has_gate || has_ogate)) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -202,7 +218,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
             gv[i][j][q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_g1, (int)voff[i], j * 64 + q * 16, 0);
           }
     }
-    if (next_tile >= 0) issue_halo(next_tile);
+    if ((ABL & 1) == 0 && next_tile >= 0) issue_halo(next_tile);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -229,7 +245,11 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
             if (has_ogate && !((float)og.e[e] > 0.f)) v = 0.f;
             o.e[e] = (half)v;
           }
-          __builtin_amdgcn_raw_buffer_store_b64(o.p, rsrc_out, (int)voff[i], j * 64 + q * 16, 0);
+          if constexpr ((ABL & 4) == 0) {
+            __builtin_amdgcn_raw_buffer_store_b64(o.p, rsrc_out, (int)voff[i], j * 64 + q * 16, 0);
+          } else {
+            asm volatile("" ::"v"(o.p));
+          }
         }
   };
 
@@ -296,6 +316,25 @@ inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* 
   static const int wgs_env = getenv("MN_HALO_PP_WGS") ? atoi(getenv("MN_HALO_PP_WGS")) : 256;  // one per CU
   const int wgs = wgs_arg > 0 ? wgs_arg : wgs_env;
   const dim3 grid(ntiles < wgs ? ntiles : wgs);
+#ifdef MN_ABLATION_BUILD
+  static const int abl = getenv("MN_HALO_PP_ABLATE") ? atoi(getenv("MN_HALO_PP_ABLATE")) : 0;
+#define PP_CASE(S, A_, P_) hipLaunchKernelGGL((conv_halo_pp_kernel<S, A_, P_>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return
+  if (!ep.stats_accum) {
+    switch (abl) {
+      case 1: PP_CASE(false, 1, 0);
+      case 2: PP_CASE(false, 2, 0);
+      case 4: PP_CASE(false, 4, 0);
+      case 5: PP_CASE(false, 5, 0);
+      case 8: PP_CASE(false, 8, 0);
+      case 10: PP_CASE(false, 10, 0);
+      case 13: PP_CASE(false, 13, 0);
+      case 100: PP_CASE(false, 0, 1);  // not an ablation: MFMA loop at raised wave priority
+      case 101: PP_CASE(false, 0, 3);
+      default: break;
+    }
+  }
+#undef PP_CASE
+#endif
   if (ep.stats_accum)
     hipLaunchKernelGGL(conv_halo_pp_kernel<true>, grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
   else

@@ -39,7 +39,9 @@ union Half4View {
 
 // ABL (timing experiments only, ablation build, results are wrong): bit 0 = halo DMA only for each group's first tile,
 // bit 1 = no fragment reads, bit 2 = no stores / residual / gate loads, bit 3 = no MFMA.  PRIO: s_setprio of the MFMA loop.
-template <bool STATS, int ABL = 0, int PRIO = 0>
+// PD: K-sub-steps a fragment is read ahead of its MFMAs.  EARLY: residual / gate values of a tile are requested before its
+// MFMA loop (64 registers held through it) instead of at the start of the store phase.
+template <bool STATS, int ABL = 0, int PRIO = 0, int PD = 3, bool EARLY = false>
 static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom g, const half* __restrict__ A,
                                                                      const half* __restrict__ Bw, Epilogue ep, int tiles_x,
                                                                      int tiles_y, int ntiles) {
@@ -127,8 +129,38 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
       for (int r = 0; r < 16; ++r) st1[j][r] = st2[j][r] = 0.f;
   }
 
+  // residual and THE gate (res_gate or out_gate, never both: conv_halo_pp_applies) of a tile, in the store pattern
+  Half4View rv[2][2][4], gv[2][2][4];
+  auto pixel_offsets = [&](int tile, unsigned (&voff)[2], bool (&okp)[2]) __attribute__((always_inline)) {
+    int b, y0, x0;
+    tile_coords(tile, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rl = wq * 64 + i * 32 + l31;
+      const int y = y0 + (rl >> 4), x = x0 + (rl & 15);
+      okp[i] = y < gP && x < gQ;
+      voff[i] = okp[i] ? (unsigned)((((b * gP + y) * gQ + x) * ldc) * 2 + kh * 8) : kOob;
+    }
+  };
+  auto load_side = [&](int tile) __attribute__((always_inline)) {
+    if ((ABL & 4) != 0 || !(has_res || has_gate || has_ogate)) return;
+    unsigned voff[2];
+    bool okp[2];
+    pixel_offsets(tile, voff, okp);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rv[i][j][q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_res, (int)voff[i], j * 64 + q * 16, 0);
+          gv[i][j][q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_g1, (int)voff[i], j * 64 + q * 16, 0);
+        }
+  };
+
   const int prow = 4 * wq + (l31 >> 4), pcol = l31 & 15;
-  auto compute = [&]() __attribute__((always_inline)) {
+  auto compute = [&](int tile) __attribute__((always_inline)) {
+    if constexpr (EARLY) load_side(tile);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -141,7 +173,8 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
     // fragments of K-sub-step ks live in register slot ks; a sub-step's reads are issued two sub-steps (8 MFMAs, 256
     // matrix-pipe cycles) ahead of its MFMAs.  The tap loop is a real loop: fully unrolled, the 144 fragment addresses
     // get hoisted and spill.
-    constexpr int PD = 2;  // sub-steps a fragment is read ahead of its MFMAs
+    constexpr int SM = PD == 1 ? 1 : 3;  // fragments of sub-step ks live in register slot ks & SM
+    static_assert(PD >= 1 && PD <= 3, "read-ahead");
     PieceView<half> fa[4][2], fb[4][2];
     auto load_frags = [&](int tap, int ks) __attribute__((always_inline)) {
       if constexpr ((ABL & 2) != 0) return;
@@ -150,12 +183,12 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int hp = hp0 + i * 2 * HW;
-        fa[ks & (2 * PD - 1)][i].p = hbuf[hp * NP + (piece ^ ((hp >> 1) & 7))];
+        fa[ks & SM][i].p = hbuf[hp * NP + (piece ^ ((hp >> 1) & 7))];
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = j * 32 + l31;
-        fb[ks & (2 * PD - 1)][j].p = smem[tap * 512 + row * NP + (piece ^ ((row >> 1) & 7))];
+        fb[ks & SM][j].p = smem[tap * 512 + row * NP + (piece ^ ((row >> 1) & 7))];
       }
     };
     if constexpr ((ABL & 2) != 0) {
@@ -181,9 +214,9 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
 #pragma unroll
           for (int j = 0; j < 2; ++j) {  // weights = A operand (rows), pixels = B (columns)
             if constexpr ((ABL & 8) == 0) {
-              mma_piece<half>(fb[ks & (2 * PD - 1)][j], fa[ks & (2 * PD - 1)][i], acc[i][j]);
+              mma_piece<half>(fb[ks & SM][j], fa[ks & SM][i], acc[i][j]);
             } else {
-              asm volatile("" ::"v"(fa[ks & (2 * PD - 1)][i].p), "v"(fb[ks & (2 * PD - 1)][j].p));
+              asm volatile("" ::"v"(fa[ks & SM][i].p), "v"(fb[ks & SM][j].p));
             }
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -195,29 +228,10 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
   // memory-side phase of this group: the residual / gate values of the finished tile are requested first (loads return
   // in order: requested behind the halo they would wait for it), then the next tile's halo, then the tile is stored
   auto store_and_fetch = [&](int tile, int next_tile) __attribute__((always_inline)) {
-    int b, y0, x0;
-    tile_coords(tile, b, y0, x0);
     unsigned voff[2];
     bool okp[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rl = wq * 64 + i * 32 + l31;
-      const int y = y0 + (rl >> 4), x = x0 + (rl & 15);
-      okp[i] = y < gP && x < gQ;
-      voff[i] = okp[i] ? (unsigned)((((b * gP + y) * gQ + x) * ldc) * 2 + kh * 8) : kOob;
-    }
-    Half4View rv[2][2][4], gv[2][2][4];  // residual; THE gate: res_gate or out_gate (never both: conv_halo_pp_applies)
-    if ((ABL & 4) == 0 && (has_res || has_gate || has_ogate)) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            rv[i][j][q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_res, (int)voff[i], j * 64 + q * 16, 0);
-            gv[i][j][q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_g1, (int)voff[i], j * 64 + q * 16, 0);
-          }
-    }
+    pixel_offsets(tile, voff, okp);
+    if constexpr (!EARLY) load_side(tile);
     if ((ABL & 1) == 0 && next_tile >= 0) issue_halo(next_tile);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -257,7 +271,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
   __builtin_amdgcn_s_barrier();  // weights and both first halos visible
   for (int p = 0; p <= nitems; ++p) {
     if ((p & 1) == grp) {
-      if (p < nitems) compute();
+      if (p < nitems) compute(wl + p * G);
     } else if (p >= 1) {
       store_and_fetch(wl + (p - 1) * G, p + 1 < nitems ? wl + (p + 1) * G : -1);
     }
@@ -319,6 +333,14 @@ inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* 
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_HALO_PP_ABLATE") ? atoi(getenv("MN_HALO_PP_ABLATE")) : 0;
 #define PP_CASE(S, A_, P_) hipLaunchKernelGGL((conv_halo_pp_kernel<S, A_, P_>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return
+#define PP_VAR(S, PD_, E_) hipLaunchKernelGGL((conv_halo_pp_kernel<S, 0, 0, PD_, E_>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return
+  if (ep.stats_accum) {
+    switch (abl) {
+      case 200: case 201: PP_VAR(true, 2, false);
+      case 210: case 211: PP_VAR(true, 3, false);
+      default: break;
+    }
+  }
   if (!ep.stats_accum) {
     switch (abl) {
       case 1: PP_CASE(false, 1, 0);
@@ -330,10 +352,15 @@ inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* 
       case 13: PP_CASE(false, 13, 0);
       case 100: PP_CASE(false, 0, 1);  // not an ablation: MFMA loop at raised wave priority
       case 101: PP_CASE(false, 0, 3);
+      case 200: PP_VAR(false, 2, false);  // not ablations: fragment read-ahead, early residual / gate requests
+      case 201: PP_VAR(false, 2, true);
+      case 210: PP_VAR(false, 3, false);
+      case 211: PP_VAR(false, 3, true);
       default: break;
     }
   }
 #undef PP_CASE
+#undef PP_VAR
 #endif
   if (ep.stats_accum)
     hipLaunchKernelGGL(conv_halo_pp_kernel<true>, grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);

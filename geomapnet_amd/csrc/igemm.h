@@ -688,6 +688,24 @@ inline int maybe_launch_igemm_halo<half>(const GatherGeom& g, const half* A, con
   return level > 0 ? launch_igemm_halo(g, A, Bw, ep, stream, level, tile288_wanted) : -1;
 }
 
+// igemm_rt.h (MN_IGEMM_RT=1; 2 = also launches that do not fill two workgroups per CU): 256x128 tiles, 128x64 register
+// tiles per wave, chunk-resident A image
+inline bool igemm_rt_applies(const GatherGeom& g, const Epilogue& ep);
+inline int launch_igemm_rt(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream);
+template <typename T>
+inline int maybe_launch_igemm_rt(const GatherGeom&, const T*, const T*, const Epilogue&, hipStream_t) {
+  return -1;
+}
+template <>
+inline int maybe_launch_igemm_rt<half>(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep,
+                                       hipStream_t stream) {
+  static const int level = getenv("MN_IGEMM_RT") ? atoi(getenv("MN_IGEMM_RT")) : 0;
+  if (level <= 0 || !igemm_rt_applies(g, ep)) return -1;
+  // the shape runs two workgroups per CU: layer2 (1032 tiles at 192 images) fills them, layer4 (264 tiles) does not
+  if (level < 2 && (long)cdiv(g.M, 256) * (g.N / 128) < 512) return -1;
+  return launch_igemm_rt(g, A, Bw, ep, stream);
+}
+
 // returns the number of M-blocks used (= rows of the stats partial buffer that were written)
 template <typename T>
 inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
@@ -735,6 +753,10 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
     if (wide_k && g.N % 256 == 0 && tiles128 > 512 && tiles288 > 192 && tiles288 <= igemm_sk_blocks() / 2 && g.R * g.S <= 10)
       cfg = 12;
   }
+  if (!(cfg == 12 && wide_k && g.N % 256 == 0)) {
+    const int gm_rt = maybe_launch_igemm_rt<T>(g, A, Bw, ep, stream);
+    if (gm_rt >= 0) return gm_rt;
+  }
   {
     const int gm_halo = maybe_launch_igemm_halo<T>(g, A, Bw, ep, stream, cfg == 12 && wide_k && g.N % 256 == 0);
     if (gm_halo >= 0) return gm_halo;
@@ -777,3 +799,4 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
 }  // namespace mn
 
 #include "igemm_halo.h"
+#include "igemm_rt.h"

@@ -92,6 +92,23 @@ extern "C" int mn_op_conv_halo(const mn_gather_geom* gg, const void* A, const vo
 }
 extern "C" int mn_op_conv_halo_grid_m(const mn_gather_geom* gg) { return conv_halo_grid_m(to_geom(gg)); }
 
+extern "C" int mn_op_igemm_rt(const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc, float* stats,
+                             double* stats_accum, int stats_rows, int relu, const void* res, const void* res_gate,
+                             const void* out_gate, float alpha, void* stream) {
+  begin_call();
+  GatherGeom g = to_geom(gg);
+  if (int e = check_geom(g, MN_F16)) return e;
+  Epilogue ep;
+  ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = nullptr; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
+  ep.out_gate = out_gate; ep.alpha = alpha; ep.stats_accum = stats_accum; ep.stats_rows = stats_rows;
+  if (!igemm_rt_applies(g, ep))
+    return fail("igemm_rt: fp16 3x3 stride-1 same-size convolutions, C % 64 == 0, N % 128 == 0, image width <= 47, at most one gate, "
+                "no residual / gates together with statistics");
+  launch_igemm_rt(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream);
+  return check_launch("igemm_rt");
+}
+extern "C" int mn_op_igemm_rt_grid_m(const mn_gather_geom* gg) { return cdiv(to_geom(gg).M, 256); }
+
 extern "C" int mn_op_conv_halo_pp(const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc, double* stats_accum,
                                  int stats_rows, int relu, const void* res, const void* res_gate, const void* out_gate,
                                  float alpha, int wgs, void* stream) {

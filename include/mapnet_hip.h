@@ -204,6 +204,15 @@ int mn_op_conv_halo(const mn_gather_geom* g, const void* A, const void* Bw, void
                     const float* bias, int relu, const void* res, const void* res_gate, const void* out_gate, float alpha,
                     void* stream);
 int mn_op_conv_halo_grid_m(const mn_gather_geom* g);
+/* fp16 3x3 stride-1 same-size convolution (forward or, with the mirrored geometry, data gradient) of C % 64 == 0 input
+ * and N % 128 == 0 output channels on maps at most 47 pixels wide, with 256 x 128 tiles and 128 x 64 register tiles per wave
+ * (csrc/igemm_rt.h: ResNet layer2).  Operands and epilogue as mn_op_conv_halo (no bias; at most one gate; statistics --
+ * stats: [mn_op_igemm_rt_grid_m(g)][2][N] partial column sums, or stats_accum: [stats_rows][2][N] fp64 sums added to
+ * atomically -- only without residual / gates). */
+int mn_op_igemm_rt(const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
+                   double* stats_accum, int stats_rows, int relu, const void* res, const void* res_gate,
+                   const void* out_gate, float alpha, void* stream);
+int mn_op_igemm_rt_grid_m(const mn_gather_geom* g);
 /* The same convolution for exactly 64 output channels in the persistent form (csrc/halo_pp.h): one 8-wave workgroup per
  * CU, two wave groups alternating between the MFMA loop of one tile and the epilogue + next halo fetch of another, all
  * nine weight slices LDS-resident.  stats_accum: [stats_rows][2][64] fp64 column sums (sum, sum of squares), ADDED to

@@ -254,6 +254,61 @@ def check_conv_halo(lib, dev, B, H, W, Cout=64, dgrad=False, mode="plain", seed=
         assert (sums[1] - (ref * ref).sum(0)).abs().max().item() <= 2e-3 * (ref * ref).sum(0).max().item()
 
 
+def check_igemm_rt(lib, dev, B, H, W, Cin, Cout, dgrad=False, mode="plain", stats="none", seed=31):
+    """fp16 3x3 stride-1 convolution with 256 x 128 tiles / 128 x 64 register tiles (csrc/igemm_rt.h) vs torch fp64: forward
+    (statistics as partial rows or fp64 accumulator rows) or data gradient with the epilogue variants of
+    check_conv_halo; M not a multiple of 256 and several 64-channel chunks exercise the tails and the image reload"""
+    _fresh()
+    td, k = torch.float16, 3
+    gen = torch.Generator().manual_seed(seed)
+    if not dgrad:
+        g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, k, 1, 1)
+        x = torch.randn(B, Cin, H, W, generator=gen).to(td).float()
+        w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.05).to(td).float()
+        want = F.conv2d(x.double(), w.double(), padding=1).permute(0, 2, 3, 1).contiguous()
+        a = _nhwc(x, td, dev)
+        bw = w.permute(0, 2, 3, 1).contiguous().to(td).to(dev)
+        N = Cout
+    else:
+        g, Ho, Wo = dgrad_geom(B, H, W, Cout, Cin, k, 1, 1)   # conv(Cout -> Cin): gy has Cin channels, gx has Cout
+        gy = torch.randn(B, Cin, H, W, generator=gen).to(td).float()
+        w = (torch.randn(Cin, Cout, k, k, generator=gen) * 0.05).to(td).float()
+        xin = torch.zeros(B, Cout, H, W, dtype=torch.double, requires_grad=True)
+        F.conv2d(xin, w.double(), padding=1).backward(gy.double())
+        want = xin.grad.permute(0, 2, 3, 1).contiguous()
+        a = _nhwc(gy, td, dev)
+        bw = w.permute(1, 2, 3, 0).contiguous().to(td).to(dev)
+        N = Cout
+    res = rgate = ogate = None
+    if mode in ("res_gate", "out_gate"):
+        res = torch.randn(B, H, W, N, generator=gen).to(td)
+        if mode == "res_gate":
+            rgate = torch.randn(B, H, W, N, generator=gen).to(td)
+            want = want + torch.where(rgate.double() > 0, res.double(), torch.zeros_like(res.double()))
+            rgate = rgate.to(dev)
+        else:
+            want = want + res.double()
+            ogate = torch.randn(B, H, W, N, generator=gen).to(td)
+            want = torch.where(ogate.double() > 0, want, torch.zeros_like(want))
+            ogate = ogate.to(dev)
+        res = res.to(dev)
+    out = torch.full((B, H, W, N), 7.0, dtype=td, device=dev)
+    st = sta = None
+    if stats == "rows":
+        st = torch.zeros(lib.op_igemm_rt_grid_m(C.byref(g)), 2, N, device=dev)
+    elif stats == "accum":
+        sta = torch.zeros(3, 2, N, device=dev, dtype=torch.double)
+    lib.check(lib.op_igemm_rt(C.byref(g), K(a), K(bw), K(out), N, K(st), K(sta), 3, 0, K(res), K(rgate), K(ogate), f32(1), None))
+    dev_sync(dev)
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err <= OUT_TOL[1] * want.abs().max().item() + 1e-6, err
+    sums = st.cpu().double().sum(0) if st is not None else (sta.cpu().sum(0) if sta is not None else None)
+    if sums is not None:
+        ref = want.reshape(-1, N)
+        assert (sums[0] - ref.sum(0)).abs().max().item() <= 2e-3 * ref.abs().sum(0).max().item()
+        assert (sums[1] - (ref * ref).sum(0)).abs().max().item() <= 2e-3 * (ref * ref).sum(0).max().item()
+
+
 def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target_blocks=8, seed=2, ws=False):
     _fresh()
     td = TD[dtype]

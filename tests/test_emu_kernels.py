@@ -147,6 +147,20 @@ def test_conv_halo_pp(lib, case):
     checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=dgrad, mode=mode, pp_wgs=wgs)
 
 
+@pytest.mark.parametrize("case", [
+    (1, 9, 13, 64, 128, False, "plain", "rows"),      # one ragged tile, one chunk
+    (2, 12, 23, 128, 128, False, "plain", "accum"),   # three M tiles (552 rows), two chunks: image reload
+    (1, 20, 43, 64, 256, False, "plain", "none"),     # layer2's row width, two N tiles
+    (2, 12, 23, 128, 128, True, "out_gate", "none"),
+    (1, 17, 47, 64, 128, True, "res_gate", "none"),   # widest supported rows
+    (1, 12, 23, 192, 128, True, "plain", "none"),     # three chunks
+])
+def test_igemm_rt(lib, case):
+    """256 x 128 tiles with 128 x 64 register tiles per wave (csrc/igemm_rt.h)"""
+    B, H, W, Cin, Cout, dgrad, mode, stats = case
+    checks.check_igemm_rt(lib, DEV, B, H, W, Cin, Cout, dgrad=dgrad, mode=mode, stats=stats)
+
+
 def _random_cases(seed, n):
     import numpy as np
     rng = np.random.default_rng(seed)

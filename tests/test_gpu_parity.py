@@ -69,6 +69,20 @@ def test_conv_halo_pp(lib, case):
     checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=dgrad, mode=mode, pp_wgs=wgs)
 
 
+@pytest.mark.parametrize("case", [
+    (1, 9, 13, 64, 128, False, "plain", "rows"), (2, 12, 23, 128, 128, False, "plain", "accum"),
+    (1, 20, 43, 64, 256, False, "plain", "none"), (2, 12, 23, 128, 128, True, "out_gate", "none"),
+    (1, 17, 47, 64, 128, True, "res_gate", "none"), (1, 12, 23, 192, 128, True, "plain", "none"),
+    (12, 32, 43, 128, 128, False, "plain", "accum"),   # layer2 geometry at 256x341: 65 M tiles
+    (12, 32, 43, 128, 128, True, "out_gate", "none"),
+    (16, 8, 11, 512, 512, True, "res_gate", "none"),   # layer4 geometry: eight chunks, four N tiles
+])
+def test_igemm_rt(lib, case):
+    """256 x 128 tiles with 128 x 64 register tiles per wave (csrc/igemm_rt.h)"""
+    B, H, W, Cin, Cout, dgrad, mode, stats = case
+    checks.check_igemm_rt(lib, DEV, B, H, W, Cin, Cout, dgrad=dgrad, mode=mode, stats=stats)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape,mode", [
     ((2, 8, 11, 64, 128, 3, 2, 1), "plain"), ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"), ((1, 8, 12, 64, 128, 3, 2, 1), "res_gate"),

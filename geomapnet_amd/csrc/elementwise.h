@@ -128,18 +128,46 @@ struct BnParams {
 // (Round 1 derived them in the prologue of every workgroup of the apply kernel: 16 fp64 loads per channel in each of
 // up to 4096 workgroups -- for the late layers, whose tensors are 17-34 MB, that prologue was as long as the streaming.)
 // The accumulators are read-only here; the caller zeroes them before the next accumulation.
+// Threads: 32 channels x 8 row groups per workgroup (grid = cdiv(C, 32), kBnFinalizeChannels).  Group g adds rows g, g + 8,
+// ... in order and the eight group sums are combined in group order: the result depends only on the row contents, so with
+// one producer per row (MN_DETERMINISTIC: thousands of rows) it is reproducible, and with the default 8 rows it is the
+// plain sum of rows 0..7.
+constexpr int kBnFinalizeChannels = 32;
+__device__ __forceinline__ void bn_rows_sum(const double* __restrict__ accum, int rows, int C, int c, bool active,
+                                            double (*part)[2][kBnFinalizeChannels], double& sa, double& sb) {
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  sa = sb = 0;
+  if (active)
+    for (int r = grp; r < rows; r += 8) {
+      sa += accum[(long)r * 2 * C + c];
+      sb += accum[(long)r * 2 * C + C + c];
+    }
+  part[grp][0][cl] = sa;
+  part[grp][1][cl] = sb;
+  __syncthreads();
+  if (grp == 0) {
+    sa = sb = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      sa += part[g][0][cl];
+      sb += part[g][1][cl];
+    }
+  }
+  __syncthreads();
+}
+
 static __global__ void __launch_bounds__(256) bn_finalize_fwd_kernel(const double* __restrict__ accum, double count, BnParams p,
                                                                      int training, float* __restrict__ coef, int C,
                                                                      int accum_rows) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+  __shared__ double part[8][2][kBnFinalizeChannels];
+  for (int c0 = blockIdx.x * kBnFinalizeChannels; c0 < C; c0 += gridDim.x * kBnFinalizeChannels) {
+    const int c = c0 + (threadIdx.x & 31);
+    double sa, sb;  // accum: [accum_rows][2][C]
+    bn_rows_sum(accum, training ? accum_rows : 0, C, c, c < C, part, sa, sb);
+    if ((threadIdx.x >> 5) != 0 || c >= C) continue;
     float mean, var;
     double unbiased = 0;
     if (training) {
-      double sa = 0, sb = 0;  // accum: [accum_rows][2][C]
-      for (int r = 0; r < accum_rows; ++r) {
-        sa += accum[(long)r * 2 * C + c];
-        sb += accum[(long)r * 2 * C + C + c];
-      }
       double m = sa / count;
       double v = sb / count - m * m;
       if (v < 0) v = 0;
@@ -358,12 +386,12 @@ static __global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const doubl
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                      float grad_unscale, const float* __restrict__ sg_beta,
                                                                      float* __restrict__ coef, int C, int accum_rows) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-    double sg = 0, sgx = 0;  // accum: [accum_rows][2][C]
-    for (int r = 0; r < accum_rows; ++r) {
-      sg += accum[(long)r * 2 * C + c];
-      sgx += accum[(long)r * 2 * C + C + c];
-    }
+  __shared__ double part[8][2][kBnFinalizeChannels];
+  for (int c0 = blockIdx.x * kBnFinalizeChannels; c0 < C; c0 += gridDim.x * kBnFinalizeChannels) {
+    const int c = c0 + (threadIdx.x & 31);
+    double sg, sgx;  // accum: [accum_rows][2][C], rows summed in the fixed order of bn_rows_sum
+    bn_rows_sum(accum, accum_rows, C, c, c < C, part, sg, sgx);
+    if ((threadIdx.x >> 5) != 0 || c >= C) continue;
     const float k1 = gamma[c] * invstd[c];
     coef[c] = k1;
     coef[C + c] = (float)(sg / count);
@@ -502,7 +530,7 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   else
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)accum, (double)M, gamma, mean,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)accum, (double)M, gamma, mean,
                      invstd, dgamma, dbeta, grad_unscale, self_gate_beta, coef, C, accum_rows);
   if (!apply) return;
   long np = M * C / VEC;

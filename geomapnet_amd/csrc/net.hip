@@ -301,7 +301,8 @@ struct Plan : PlanBase {
     T* gy = nullptr;  // its gradient
     float *mean, *invstd;
     float *coef_f, *coef_b;  // per-channel coefficients of the forward apply [2][C] / backward apply [4][C] (finalize kernels)
-    double *accum_f, *accum_b;  // fp64 sums of the forward statistics / backward reductions, [ACC_ROWS][2][C] each
+    double *accum_f, *accum_b;  // fp64 sums of the forward statistics / backward reductions, [rows_f | rows_b][2][C]
+    int rows_f = 0, rows_b = 0; // accumulator rows (ACC_ROWS; MN_DETERMINISTIC: one row per producing workgroup)
     int ldw;           // row pitch of the master weight gradient
     const int* colmap = nullptr;
   };
@@ -333,11 +334,19 @@ struct Plan : PlanBase {
   // BatchNorm sums are accumulated with fp64 atomics straight from the producing kernels (conv epilogue, backward
   // reduction) into ACC_ROWS rows per unit (row = producer block % ACC_ROWS, to spread same-address contention);
   // the consuming apply kernels add the rows in their prologue.  No separate partial-reduction launches.
-  static constexpr int ACC_ROWS = 8;
+  // (MN_ACC_ROWS: 8 by default)
+  // MN_DETERMINISTIC=1: bit-reproducible training steps -- every floating-point sum the step takes is added in an order
+  // that does not depend on scheduling: BatchNorm sums through one accumulator row per producing workgroup (below),
+  // weight gradients through per-split workspace slices and an ordered reduction (conv_wgrad), the gradient norm through
+  // per-workgroup partial sums (optim.h).  Costs ~x ms per step.
+  const bool deterministic = getenv("MN_DETERMINISTIC") && atoi(getenv("MN_DETERMINISTIC")) != 0;
+  const int ACC_ROWS = getenv("MN_ACC_ROWS") && atoi(getenv("MN_ACC_ROWS")) > 0 ? atoi(getenv("MN_ACC_ROWS")) : 8;
   double* acc_region = nullptr;
   size_t acc_bytes = 0;
   int cur_training = 1;
   double* sqnorm;
+  static constexpr int kSqPartials = 8192;
+  double* sq_partials = nullptr;  // MN_DETERMINISTIC: per-workgroup sums of the gradient norm
   unsigned char* frozen;
   int* stem_colmap;
   RepackJob* repack_jobs;
@@ -360,8 +369,29 @@ struct Plan : PlanBase {
     Bump b;
     auto A = [&](size_t bytes) { return base ? base + b.take(bytes) : (b.take(bytes), (char*)nullptr); };
     // all BatchNorm accumulators live in one region so a single memset per step clears them
-    size_t acc_doubles = (size_t)ACC_ROWS * 4 * 64;
-    for (auto& blk : blocks) acc_doubles += (size_t)ACC_ROWS * 4 * blk.u1.cp.cout * (blk.down ? 3 : 2);
+    auto set_rows = [&](Unit& u, bool is_stem) {
+      u.rows_f = u.rows_b = ACC_ROWS;
+      if (!deterministic) return;
+      // one row per producing workgroup: every (row, channel) slot then receives exactly ONE atomic add onto zero, and the
+      // finalize kernels add the rows in a fixed order.  Forward producers: the stem kernel's persistent workgroups, the
+      // 16x16-pixel tiles of the layer1 kernels (halo.h; halo_pp.h's <= 256 workgroups), M-tiles of >= 128 rows elsewhere.
+      if (is_stem)
+        u.rows_f = use_stem_kernel && DT == MN_F16 ? 1024 : cdiv((int)u.M, 128);
+      else if (halo_path(u.gf))
+        u.rows_f = u.gf.B * cdiv(u.gf.P, kHaloTH) * cdiv(u.gf.Q, kHaloTW);
+      else
+        u.rows_f = cdiv((int)u.M, 128);
+      u.rows_b = 1024;  // >= the workgroups of a backward reduction (launch_bn_bwd: ~512)
+    };
+    set_rows(stem, true);
+    size_t acc_doubles = (size_t)(stem.rows_f + stem.rows_b) * 2 * 64;
+    for (auto& blk : blocks) {
+      set_rows(blk.u1, false);
+      set_rows(blk.u2, false);
+      if (blk.down) set_rows(blk.ud, false);
+      acc_doubles += (size_t)(blk.u1.rows_f + blk.u1.rows_b + blk.u2.rows_f + blk.u2.rows_b) * 2 * blk.u1.cp.cout;
+      if (blk.down) acc_doubles += (size_t)(blk.ud.rows_f + blk.ud.rows_b) * 2 * blk.ud.cp.cout;
+    }
     acc_bytes = acc_doubles * 8;
     acc_region = (double*)A(acc_bytes);
     double* acc_cursor = acc_region;
@@ -374,8 +404,8 @@ struct Plan : PlanBase {
       u.coef_f = (float*)A(2 * C * 4);
       u.coef_b = (float*)A(4 * C * 4);
       u.accum_f = acc_cursor;
-      u.accum_b = acc_cursor ? acc_cursor + (size_t)ACC_ROWS * 2 * C : nullptr;
-      if (acc_cursor) acc_cursor += (size_t)ACC_ROWS * 4 * C;
+      u.accum_b = acc_cursor ? acc_cursor + (size_t)u.rows_f * 2 * C : nullptr;
+      if (acc_cursor) acc_cursor += (size_t)(u.rows_f + u.rows_b) * 2 * C;
     };
     xpad = (T*)A((size_t)B * Hp * Wp * 4 * sizeof(T));
     // stem
@@ -422,11 +452,13 @@ struct Plan : PlanBase {
     fcT = (float*)A((size_t)512 * F * 4);
     loss_dev = (float*)A(256);
     sqnorm = (double*)A(256);
+    sq_partials = (double*)A((size_t)kSqPartials * 8);
     frozen = (unsigned char*)A(256);
     stem_colmap = (int*)A(224 * 4);
     repack_jobs = (RepackJob*)A(64 * sizeof(RepackJob));
     zero_page = (void*)A(256);
     wgf_ws_floats = DT == MN_F16 ? wgrad_fused_ws_floats(WGF_BLOCKS) : 0;
+    if (deterministic && wgf_ws_floats < (16L << 20)) wgf_ws_floats = 16L << 20;  // split slices of the plain weight gradients
     wgf_ws = wgf_ws_floats ? (float*)A((size_t)wgf_ws_floats * 4) : nullptr;
     sk_ws = (float*)A((size_t)igemm_sk_blocks() * 2 * 128 * 128 * 4);
     sk_counters = (int*)A((size_t)igemm_sk_blocks() * 4);
@@ -608,13 +640,13 @@ struct Plan : PlanBase {
     ep.res = nullptr; ep.res_gate = nullptr; ep.alpha = 1.f;
     if (training) {
       ep.stats_accum = u.accum_f;
-      ep.stats_rows = ACC_ROWS;
+      ep.stats_rows = u.rows_f;
     }
     ep.sk_ws = sk_ws;
     ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
     if (&u == &stem && DT == MN_F16 && use_stem_kernel)  // weights in registers, input pairs read straight from LDS (stem.h)
-      launch_stem_conv((const half*)x, (const half*)u.wf, (half*)u.y, training ? u.accum_f : nullptr, ACC_ROWS, B, H, W, Wp, s);
+      launch_stem_conv((const half*)x, (const half*)u.wf, (half*)u.y, training ? u.accum_f : nullptr, u.rows_f, B, H, W, Wp, s);
     else if (halo_path(u.gf) && use_halo_pp && conv_halo_pp_applies(u.gf, ep))
       launch_conv_halo_pp(u.gf, (const half*)x, (const half*)u.wf, ep, s);
     else if (halo_path(u.gf))
@@ -625,13 +657,13 @@ struct Plan : PlanBase {
   }
   // layer1's 64-channel 3x3 convolutions (forward and data gradient) run from an LDS-resident input halo (halo.h)
   bool use_halo = DT == MN_F16 && !(getenv("MN_HALO") && atoi(getenv("MN_HALO")) == 0);
-  // ... in the persistent two-group form (halo_pp.h) when MN_HALO_PP=1
-  bool use_halo_pp = getenv("MN_HALO_PP") && atoi(getenv("MN_HALO_PP")) != 0;
+  // ... in the persistent two-group form (halo_pp.h; MN_HALO_PP=0: one tile per workgroup, halo.h): 14.83 vs 15.08 ms / step
+  bool use_halo_pp = !(getenv("MN_HALO_PP") && atoi(getenv("MN_HALO_PP")) == 0);
   bool use_stem_kernel = !(getenv("MN_STEM_KERNEL") && atoi(getenv("MN_STEM_KERNEL")) == 0);
   bool halo_path(const GatherGeom& g) const { return use_halo && conv_halo_applies(g); }
   void bn_finalize(Unit& u, hipStream_t s) {  // statistics -> (scale, shift), mean / invstd, running statistics
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(u.cp.cout, 256)), dim3(256), 0, s, (const double*)u.accum_f, (double)u.M,
-                       bn_params(u), cur_training, u.coef_f, u.cp.cout, ACC_ROWS);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(u.cp.cout, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)u.accum_f, (double)u.M,
+                       bn_params(u), cur_training, u.coef_f, u.cp.cout, u.rows_f);
   }
   void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s) {
     long np = u.M * u.cp.cout / VEC;
@@ -730,7 +762,7 @@ struct Plan : PlanBase {
   void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s, bool self_gate = false) {
     launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
                      grads + u.bp.beta, u.gy, u.accum_b, u.coef_b, 1.f / cur_scale, s,
-                     (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr, PoolGradSrc(), ACC_ROWS);
+                     (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr, PoolGradSrc(), u.rows_b);
   }
   // bit 0: BatchNorm+ReLU+max-pool in one forward pass (-0.15 ms/step); bit 1: max-pool gradient gathered inside the
   // BatchNorm backward passes instead of a maxpool_bwd launch (measured +0.05 ms/step: the gather runs twice) -- off
@@ -747,6 +779,7 @@ struct Plan : PlanBase {
     a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
     a.alpha = 1.f / cur_scale; a.rows_per_split = 0;
     a.ws = wgf_ws; a.ws_floats = wgf_ws_floats;  // every weight-gradient launch of a step goes to the same stream (`ws`)
+    a.det = deterministic;
     auto* tp = timer.begin(1, ws);
     // reduction splits (measured, tools/conv_bench.py): one round of 2 workgroups per CU for the wide layers (half
     // the atomic traffic of 1024), more for layer1 and the stem whose pixel dimension is 4-16x longer
@@ -864,7 +897,8 @@ struct Plan : PlanBase {
     hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
                        (const float*)dpooled, last.gout, B, Hl * Wl, 512, pregate ? (const T*)last.out : (const T*)nullptr);
   }
-  bool use_stem_bwd = DT == MN_F16 && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
+  // (MN_DETERMINISTIC: the stem's backward goes through bn_bwd + the split-slice weight gradient instead)
+  bool use_stem_bwd = DT == MN_F16 && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
   void stem_backward(hipStream_t s) {
     if (use_stem_bwd) {
       // two tile-walking launches (stem_bwd.h): BatchNorm sums, then the weight gradient with d(conv output) computed tile
@@ -872,13 +906,13 @@ struct Plan : PlanBase {
       StemBwdArgs a;
       a.y = (const half*)stem.y; a.idx = pool_idx; a.gp = (const half*)gp0; a.gamma = params + stem.bp.gamma;
       a.beta = params + stem.bp.beta; a.coef = stem.coef_b; a.mean = stem.mean; a.invstd = stem.invstd; a.accum = stem.accum_b;
-      a.accum_rows = ACC_ROWS; a.xpad = (const half*)xpad; a.dW = grads + stem.cp.w; a.colmap = stem_colmap; a.ldw = stem.ldw;
+      a.accum_rows = stem.rows_b; a.xpad = (const half*)xpad; a.dW = grads + stem.cp.w; a.colmap = stem_colmap; a.ldw = stem.ldw;
       a.alpha = 1.f / cur_scale;
       launch_stem_bn_reduce(a, B, H, W, Wp, s);
-      hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(256), 0, s, (const double*)stem.accum_b, (double)stem.M,
+      hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(64 / kBnFinalizeChannels), dim3(256), 0, s, (const double*)stem.accum_b, (double)stem.M,
                          (const float*)(params + stem.bp.gamma), (const float*)stem.mean, (const float*)stem.invstd,
                          grads + stem.bp.gamma, grads + stem.bp.beta, 1.f / cur_scale, (const float*)(params + stem.bp.beta),
-                         stem.coef_b, 64, ACC_ROWS);
+                         stem.coef_b, 64, stem.rows_b);
       auto* tp = timer.begin(1, s);
       launch_stem_wgrad(a, B, H, W, Wp, s);
       timer.end(tp, s);
@@ -891,7 +925,7 @@ struct Plan : PlanBase {
       pg.idx = pool_idx; pg.gout = gp0; pg.H = H0; pg.W = W0; pg.Po = H1; pg.Qo = W1;
       launch_bn_bwd<T>((const T*)nullptr, (const T*)nullptr, (const T*)stem.y, stem.M, 64, params + stem.bp.gamma, stem.mean,
                        stem.invstd, grads + stem.bp.gamma, grads + stem.bp.beta, stem.gy, stem.accum_b, stem.coef_b,
-                       1.f / cur_scale, s, params + stem.bp.beta, pg, ACC_ROWS);
+                       1.f / cur_scale, s, params + stem.bp.beta, pg, stem.rows_b);
     } else {
       hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid((long)B * H0 * W0 * 64 / VEC)), dim3(256), 0, s,
                          (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
@@ -976,9 +1010,16 @@ struct Plan : PlanBase {
   int optim_step(float grad_mul, hipStream_t s) override {
     // squared gradient norm: for clip_grad_norm, and (fp16) as the overflow detector of this step
     if (max_grad_norm > 0.f || overflow_guard) {
-      hipMemsetAsync(sqnorm, 0, sizeof(double), s);
-      hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(ew_grid(L.model_floats)), dim3(256), 0, s, (const float*)grads,
-                         (long)L.model_floats, sqnorm);
+      const int nb = ew_grid(L.model_floats);
+      if (deterministic && nb <= kSqPartials) {
+        hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(nb), dim3(256), 0, s, (const float*)grads, (long)L.model_floats, sqnorm,
+                           sq_partials);
+        hipLaunchKernelGGL(sqnorm_fold_kernel, dim3(1), dim3(256), 0, s, (const double*)sq_partials, nb, sqnorm);
+      } else {
+        hipMemsetAsync(sqnorm, 0, sizeof(double), s);
+        hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(nb), dim3(256), 0, s, (const float*)grads, (long)L.model_floats, sqnorm,
+                           (double*)nullptr);
+      }
     }
     hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, step_dev, beta1, beta2, bc_dev, (const double*)sqnorm,
                        overflow_guard ? overflow_dev : (long long*)nullptr);

@@ -197,7 +197,7 @@ extern "C" int mn_op_stem_bwd(const void* y, const unsigned char* idx, const voi
   a.ldw = ldw; a.alpha = alpha;
   hipMemsetAsync(accum_scratch, 0, 2 * 64 * sizeof(double), s);
   launch_stem_bn_reduce(a, B, H, W, Wp, s);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(256), 0, s, (const double*)accum_scratch, (double)((long)B * H0 * W0), gamma,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(64 / kBnFinalizeChannels), dim3(256), 0, s, (const double*)accum_scratch, (double)((long)B * H0 * W0), gamma,
                      mean, invstd, dgamma, dbeta, alpha, beta, coef_scratch, 64, 1);
   launch_stem_wgrad(a, B, H, W, Wp, s);
   return check_launch("stem_bwd");
@@ -277,7 +277,7 @@ extern "C" int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t 
   if (max_norm > 0.f) {
     if (!sqnorm_scratch) return fail("adam: clipping needs a scratch double");
     hipMemsetAsync(sqnorm_scratch, 0, sizeof(double), s);
-    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(ew_grid(n_clip)), dim3(256), 0, s, g, (long)n_clip, sqnorm_scratch);
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(ew_grid(n_clip)), dim3(256), 0, s, g, (long)n_clip, sqnorm_scratch, (double*)nullptr);
   }
   AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.n_clip = n_clip; a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2;
@@ -303,7 +303,7 @@ static int bn_train_fwd_t(const void* y, int64_t M, int C, const float* gamma, c
   p.num_batches_tracked = nullptr; p.mean = mean; p.invstd = invstd; p.eps = eps; p.momentum = momentum;
   long np = M * C / ElemTraits<T>::VEC;
   float* coef = reinterpret_cast<float*>(accum + 2 * C);  // [2][C] floats behind the accumulators
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)accum, (double)M, p, 1, coef, C, 1);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)accum, (double)M, p, 1, coef, C, 1);
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)y, (const float*)coef, (const T*)res,
                      (T*)out, np, C, relu);
   return check_launch("bn_train_fwd");

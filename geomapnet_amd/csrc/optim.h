@@ -7,8 +7,10 @@
 
 namespace mn {
 
-// accum[0] += sum g[i]^2  (fp64)
-static __global__ void __launch_bounds__(256) grad_sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ accum) {
+// accum[0] += sum g[i]^2  (fp64); with `partials` (MN_DETERMINISTIC) the workgroup's sum goes to partials[blockIdx.x] instead
+// and sqnorm_fold_kernel adds those up in index order
+static __global__ void __launch_bounds__(256) grad_sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ accum,
+                                                                 double* __restrict__ partials = nullptr) {
   __shared__ double red[4];
   double s = 0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -18,7 +20,26 @@ static __global__ void __launch_bounds__(256) grad_sqnorm_kernel(const float* __
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(accum, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const double v = red[0] + red[1] + red[2] + red[3];
+    if (partials)
+      partials[blockIdx.x] = v;
+    else
+      atomicAdd(accum, v);
+  }
+}
+// one workgroup: thread t adds partials t, t + 256, ... in order, the 256 sums are added in thread order
+static __global__ void __launch_bounds__(256) sqnorm_fold_kernel(const double* __restrict__ partials, int n, double* __restrict__ accum) {
+  __shared__ double red[256];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0;
+    for (int i = 0; i < 256; ++i) v += red[i];
+    *accum = v;
+  }
 }
 
 // optim.learner.zero_grad(): 16-byte stores over the gradient arena (hipMemsetAsync's fill kernel took ~240 us for the

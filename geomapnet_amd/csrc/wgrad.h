@@ -32,6 +32,11 @@ struct WgradArgs {
   // launches that share it must be ordered on one stream
   float* ws = nullptr;
   long ws_floats = 0;
+  // det (MN_DETERMINISTIC): no two workgroups may add into the same float.  The split-K kernels below then write split z
+  // into its own slice dW + z * split_stride of the (zeroed) workspace and wgrad_split_reduce_kernel adds the slices into
+  // the gradient in split order; the fused kernel reduces its partial tiles with one group.
+  bool det = false;
+  long split_stride = 0;
 };
 
 template <typename T, int BMO, int BNO>
@@ -174,7 +179,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int n = n0 + wm * (BMO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.N && dst >= 0) unsafeAtomicAdd(a.dW + (long)n * a.ldw + dst, acc[i][j][r] * a.alpha);
+        if (n < g.N && dst >= 0) unsafeAtomicAdd(a.dW + (long)blockIdx.z * a.split_stride + (long)n * a.ldw + dst, acc[i][j][r] * a.alpha);
       }
     }
 }
@@ -497,7 +502,8 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int n = n0 + wm * (BMO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.N && dst >= 0) unsafeAtomicAdd(a.dW + (long)n * a.ldw + dst, acc[i][j][r] * a.alpha);
+        if (n < g.N && dst >= 0)
+          unsafeAtomicAdd(a.dW + (long)bz * a.split_stride + (long)n * a.ldw + dst, acc[i][j][r] * a.alpha);
       }
     }
 }
@@ -572,6 +578,17 @@ struct WgradDma<half> {
 inline bool wgrad_fused_applies(const WgradArgs& a);
 inline void launch_wgrad_fused(const WgradArgs& a, int target_blocks, hipStream_t stream);
 
+// dW[i] += sum over the split slices, in split order (the slices already carry alpha)
+static __global__ void __launch_bounds__(256) wgrad_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
+                                                                        long n, int splits, long stride) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += ws[(long)z * stride + i];
+    dW[i] += v;
+  }
+}
+inline void launch_zero_fill(float* p, long n, hipStream_t s);  // optim.h
+
 template <typename T>
 inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, const void* zero_page = nullptr) {
   const GatherGeom& g = a.g;
@@ -591,13 +608,25 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
   int max_splits = cdiv(g.M, 512);  // at least 8 steps of 64 rows per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  const long slice = (long)g.N * a.ldw;
+  float* const dW_final = a.dW;
+  if (a.det) {  // one zeroed slice of the workspace per split (fewer splits if the workspace is small; none without one)
+    const int fit = a.ws ? (int)(a.ws_floats / slice) : 1;
+    if (splits > fit) splits = fit < 1 ? 1 : fit;
+  }
   int rows = cdiv(cdiv(g.M, splits), 64) * 64;
   splits = cdiv(g.M, rows);
   a.rows_per_split = rows;
+  const bool sliced = a.det && splits > 1;
+  if (sliced) {
+    launch_zero_fill(a.ws, slice * splits, stream);
+    a.dW = a.ws;
+    a.split_stride = slice;
+  }
   dim3 grid(cdiv(g.N, bmo), cdiv(g.K, bno), splits), block(256);
   static const bool use_dma = !(getenv("MN_WGRAD_DMA") && atoi(getenv("MN_WGRAD_DMA")) == 0);
-  if (use_dma && WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) return;
-  if (bmo == 64 && bno == 64)
+  if (use_dma && WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) {
+  } else if (bmo == 64 && bno == 64)
     hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, block, 0, stream, a);
   else if (bmo == 64)
     hipLaunchKernelGGL((wgrad_kernel<T, 64, 128>), grid, block, 0, stream, a);
@@ -605,6 +634,9 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
     hipLaunchKernelGGL((wgrad_kernel<T, 128, 64>), grid, block, 0, stream, a);
   else
     hipLaunchKernelGGL((wgrad_kernel<T, 128, 128>), grid, block, 0, stream, a);
+  if (sliced)
+    hipLaunchKernelGGL(wgrad_split_reduce_kernel, dim3((unsigned)cdiv((int)((slice + 255) / 256), 1)), dim3(256), 0, stream,
+                       (const float*)a.ws, dW_final, slice, splits, slice);
 }
 
 }  // namespace mn

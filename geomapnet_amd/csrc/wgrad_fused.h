@@ -48,6 +48,7 @@ struct WgradFusedArgs {
   int ring;     // LDS rows of the X ring = (D+1)*BKM + 2*Gpad
   FastDiv dq, dp;  // divisors Q+1 and P+1
   float alpha;
+  bool det = false;  // MN_DETERMINISTIC: one reduction group (plain ordered sums, no atomics anywhere)
 };
 
 // LDS rows of the X ring: (D+1) steps + 2 Gpad; bounds the image width (Gpad <= 96 -> Q <= 94, i.e. inputs up to 376
@@ -329,7 +330,7 @@ inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
   // enough threads to pull the slabs at full bandwidth: split the chunk range over blockIdx.y while columns are few
   int groups = (int)(131072 / quads);
   if (groups > a.nchunks) groups = a.nchunks;
-  if (groups < 1) groups = 1;
+  if (groups < 1 || a.det) groups = 1;  // one group: every element is a plain ordered sum
   const int per = cdiv(a.nchunks, groups);
   groups = cdiv(a.nchunks, per);
   hipLaunchKernelGGL(wgrad_fused_reduce_kernel, dim3(cdiv(quads, 256), groups), dim3(256), 0, stream, (const float*)a.ws, a.dW,
@@ -367,6 +368,7 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   a.dq = make_fastdiv(a.Qp);
   a.dp = make_fastdiv(g.P + 1);
   a.alpha = w.alpha;
+  a.det = w.det;
   // pixel ranges: one round of resident workgroups (two 4-wave or one 8-wave workgroup per CU), each range at least 8
   // halos long (the ring prologue fetches 2 Gpad + D steps of rows that belong to the neighbouring ranges)
   const int pairs = a.tiles_n * a.tiles_c;

@@ -1084,6 +1084,52 @@ def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3):
         G.set_compute_dtype("fp16", loss_scale=1024.0)
 
 
+def check_deterministic(lib, dev, dtype_name, N=2, H=40, W=53, steps=3, max_grad_norm=5.0):
+    """MN_DETERMINISTIC=1 (read when a plan is created): two runs of `steps` training steps from the same state are
+    BIT-identical in parameters, Adam moments and loss -- BatchNorm sums through one accumulator row per producing
+    workgroup, weight gradients through ordered slice / chunk reductions, the gradient norm through ordered partial sums --
+    and the mode takes the same step as the default one up to the rounding of the summation order.  Returns the largest
+    parameter difference between the two modes."""
+    _fresh()
+    import geomapnet_amd as G
+    G.set_compute_dtype(dtype_name)
+    x, t = oracle.make_batch("mapnet", N, H, W, seed=7)
+    x, t = x.to(dev), t.to(dev)
+
+    def run(det):
+        old = os.environ.pop("MN_DETERMINISTIC", None)
+        if det:
+            os.environ["MN_DETERMINISTIC"] = "1"
+        try:
+            _, net = build_pair(lib, dev)
+            c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+            opt = G.Optimizer([{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}], "adam",
+                              base_lr=1e-4, weight_decay=5e-4)
+            net.train()
+            losses = []
+            for _ in range(steps):
+                loss, _ = G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True, max_grad_norm=max_grad_norm)
+                losses.append(float(loss))
+            dev_sync(dev)
+            eng = net.mapnet._engine
+            return eng.params.clone().cpu(), eng.opt_state.clone().cpu(), losses
+        finally:
+            os.environ.pop("MN_DETERMINISTIC", None)
+            if old is not None:
+                os.environ["MN_DETERMINISTIC"] = old
+
+    p1, o1, l1 = run(True)
+    p2, o2, l2 = run(True)
+    assert torch.equal(p1, p2) and torch.equal(o1, o2) and l1 == l2, "deterministic mode is not reproducible"
+    p0, o0, l0 = run(False)
+    assert torch.isfinite(p1).all()
+    # same step up to summation order: losses to 1e-4 (fp32) / 2e-3 (fp16); parameters move by lr per step
+    tol = 1e-4 if dtype_name == "fp32" else 2e-3
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), (l0, l1)
+    return float((p0 - p1).abs().max())
+
+
 # ---- BASELINE full-size parity against the oracle (both dtypes) ---------------------------------------------------------
 def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, lr=1e-4, wd=5e-4, filter_nans=False,
                            fp32_loss_rtol=1e-4, fp32_pose_atol=1e-3):

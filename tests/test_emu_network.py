@@ -76,3 +76,10 @@ def test_training_target_layout_is_validated_before_launch(lib):
         opt = G.Optimizer([{"params": net.parameters()}], "adam", base_lr=1e-4, weight_decay=0.0)
         with pytest.raises(ValueError):
             G.step_feedfwd(x, net, False, targ, crit, opt, True)
+
+
+def test_deterministic_mode(lib):
+    """MN_DETERMINISTIC=1 runs the ordered-reduction paths (per-producer BatchNorm rows, split-slice and one-group weight
+    gradients, partial-sum gradient norm) and takes the default mode's step; reproducibility proper is the GPU test"""
+    diff = checks.check_deterministic(lib, DEV, "fp16", N=1, H=32, W=40, steps=1)
+    assert diff < 1e-3

@@ -459,3 +459,18 @@ def test_experimental_chunk_resident_a_kernel():
     env = dict(os.environ, MN_IGEMM_HALO="2")                                     # the 128-column shape (layers 2 and 4)
     env.pop("MN_IGEMM_CONFIG", None)
     _run_experimental(env)
+
+
+@pytest.mark.parametrize("dtype_name", ["fp16", "fp32"])
+def test_deterministic_mode_is_bit_reproducible(lib, dtype_name):
+    """MN_DETERMINISTIC=1: three MapNet training steps (clipping on) twice from the same state -> identical bits; the
+    default mode's atomics only differ from it by summation order"""
+    diff = checks.check_deterministic(lib, DEV, dtype_name, N=2, H=64, W=85, steps=3)
+    assert diff < 1e-3
+
+
+def test_deterministic_mode_benchmark_shape(lib):
+    """... at the benchmark's tensor shapes (192 images of 256 x 341: layer1's 4608 accumulator rows, 8-wave fused weight
+    gradients, persistent layer1 kernels)"""
+    diff = checks.check_deterministic(lib, DEV, "fp16", N=64, H=256, W=341, steps=2)
+    assert diff < 1e-3

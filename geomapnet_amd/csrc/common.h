@@ -56,6 +56,13 @@ union PieceView<half> {
   half8 v;
 };
 
+// 8 bytes = four halves (register epilogues: halo_pp.h, igemm_rt.h)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+union Half4View {
+  u32x2 p;
+  half e[4];
+};
+
 // ---- wave reductions (64 lanes) ---------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

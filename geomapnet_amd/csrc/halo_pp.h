@@ -31,12 +31,6 @@ constexpr int kPpWeightPieces = 9 * 512;  // nine 64 x 64 fp16 slices
 constexpr int kPpWaveRegion = 640;        // pieces of a halo buffer one wave DMAs
 constexpr int kPpHaloBuf = 2624;          // 4 x 640 + the 32-piece tail (padded to one wave-wide DMA)
 
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-union Half4View {
-  u32x2 p;
-  half e[4];
-};
-
 // ABL (timing experiments only, ablation build, results are wrong): bit 0 = halo DMA only for each group's first tile,
 // bit 1 = no fragment reads, bit 2 = no stores / residual / gate loads, bit 3 = no MFMA.  PRIO: s_setprio of the MFMA loop.
 // PD: K-sub-steps a fragment is read ahead of its MFMAs.  EARLY: residual / gate values of a tile are requested before its

@@ -46,6 +46,7 @@ _PROTOS = {
     "mn_destroy": (None, [c_void]),
     "mn_set_learn_flags": (c_i, [c_void, c_i, c_i]),
     "mn_set_optim": (c_i, [c_void, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "mn_set_optim_method": (c_i, [c_void, c_i, c_i]),
     "mn_set_step_count": (c_i, [c_void, c_i64]),
     "mn_get_step_count": (c_i64, [c_void]),
     "mn_set_loss_host": (c_i, [c_void, c_void]),
@@ -92,6 +93,8 @@ _PROTOS = {
                               C.c_double, c_i, c_void]),
     "mn_op_adam": (c_i, [c_void, c_void, c_void, c_void, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_void,
                          c_i, c_void]),
+    "mn_op_optim": (c_i, [c_i, c_i, c_void, c_void, c_void, c_void, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_void,
+                          c_i, c_void]),
     "mn_op_bn_train_fwd": (c_i, [c_i, c_void, c_i64, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_i,
                                  c_void, c_f, c_f, c_void, c_void]),
     "mn_op_bn_bwd": (c_i, [c_i, c_void, c_void, c_void, c_i64, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_void,

@@ -277,6 +277,7 @@ struct PlanBase {
   }
   Layout L{2048};
   float lr = 1e-4f, wd = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, max_grad_norm = 0.f;
+  int optim_method = 0, nesterov = 0;  // optim.h AdamArgs::method; beta1 / beta2 carry momentum / dampening | alpha
   int64_t step = 0;
   bool weights_dirty = true;
   int learn_beta = 0, learn_gamma = 0;
@@ -1029,6 +1030,7 @@ struct Plan : PlanBase {
     a.bc1 = 1.f; a.bc2 = 1.f; a.bc_dev = bc_dev;
     a.grad_mul = grad_mul; a.max_norm = max_grad_norm; a.sqnorm = sqnorm; a.frozen = frozen; a.eps_mode = cfg.eps_mode;
     a.skip = overflow_guard ? overflow_dev : nullptr;
+    a.method = optim_method; a.nesterov = nesterov;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(L.param_floats)), dim3(256), 0, s, a);
     if (overflow_guard && overflow_host)
       hipMemcpyAsync(overflow_host, overflow_dev, 2 * sizeof(long long), hipMemcpyDeviceToHost, s);
@@ -1120,6 +1122,14 @@ extern "C" int mn_set_optim(mn_handle* h, float lr, float weight_decay, float be
       P.max_grad_norm != max_grad_norm)
     P.hyper_version++;  // captured graphs bake these in
   P.lr = lr; P.wd = weight_decay; P.beta1 = beta1; P.beta2 = beta2; P.eps = eps; P.max_grad_norm = max_grad_norm;
+  return 0;
+}
+extern "C" int mn_set_optim_method(mn_handle* h, int method, int nesterov) {
+  MN_H(h);
+  if (method < 0 || method > 2) return fail("set_optim_method: method must be 0 (adam), 1 (sgd) or 2 (rmsprop)");
+  if (P.optim_method != method || P.nesterov != nesterov) P.hyper_version++;
+  P.optim_method = method;
+  P.nesterov = nesterov ? 1 : 0;
   return 0;
 }
 extern "C" int mn_set_step_count(mn_handle* h, int64_t step) {

@@ -269,10 +269,20 @@ extern "C" int mn_pgo_optimize(const double* poses, const double* vos, double* o
   return check_launch("pgo");
 }
 
+extern "C" int mn_op_optim(int method, int nesterov, float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip,
+                           float lr, float wd, float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm,
+                           double* sqnorm_scratch, int eps_mode, void* stream);
 extern "C" int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip, float lr, float wd,
                           float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm,
                           double* sqnorm_scratch, int eps_mode, void* stream) {
+  return mn_op_optim(0, 0, p, g, m, v, n, n_clip, lr, wd, beta1, beta2, eps, step, grad_mul, max_norm, sqnorm_scratch, eps_mode,
+                     stream);
+}
+extern "C" int mn_op_optim(int method, int nesterov, float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip,
+                           float lr, float wd, float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm,
+                           double* sqnorm_scratch, int eps_mode, void* stream) {
   begin_call();
+  if (method < 0 || method > 2) return fail("optim: method must be 0 (adam), 1 (sgd) or 2 (rmsprop)");
   hipStream_t s = (hipStream_t)stream;
   if (max_norm > 0.f) {
     if (!sqnorm_scratch) return fail("adam: clipping needs a scratch double");
@@ -284,8 +294,9 @@ extern "C" int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t 
   a.eps = eps; a.bc1 = (float)(1.0 - pow((double)beta1, (double)step)); a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   a.grad_mul = grad_mul; a.max_norm = max_norm; a.sqnorm = sqnorm_scratch; a.frozen = nullptr; a.eps_mode = eps_mode;
   a.bc_dev = nullptr;
+  a.method = method; a.nesterov = nesterov ? 1 : 0; a.first_step = step <= 1 ? 1 : 0;
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, s, a);
-  return check_launch("adam");
+  return check_launch("optim");
 }
 
 template <typename T>

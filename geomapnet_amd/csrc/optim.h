@@ -73,6 +73,12 @@ struct AdamArgs {
   int eps_mode;      // 0: torch>=1.0  denom = sqrt(v)/sqrt(bc2)+eps ; 1: torch 0.4.1  denom = sqrt(v)+eps
   const float* bc_dev;  // optional device copy of {bc1, bc2} (written by adam_prep_kernel); overrides bc1/bc2
   const long long* skip = nullptr;  // optional overflow word (adam_prep_kernel): non-zero = leave everything untouched
+  // method (common/optimizer.py:16-26: torch.optim.SGD / Adam / RMSprop): 0 = Adam; 1 = SGD with `momentum` (beta1),
+  // `dampening` (beta2), `nesterov` -- momentum buffer in m; 2 = RMSprop (not centered) with `alpha` (beta2), eps,
+  // `momentum` (beta1) -- square average in v, momentum buffer in m
+  int method = 0;
+  int nesterov = 0;
+  int first_step = 0;  // SGD: this is the first step (the momentum buffer starts as the gradient); bc_dev[2] overrides
 };
 
 // Advances the device-resident step counter and derives the bias corrections from it, so a captured
@@ -99,6 +105,7 @@ static __global__ void adam_prep_kernel(long long* step, float beta1, float beta
     *step = t;
     bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
     bc[1] = (float)(1.0 - pow((double)beta2, (double)t));
+    bc[2] = t == 1 ? 1.f : 0.f;  // first step (SGD's momentum buffer)
   }
 }
 
@@ -118,6 +125,30 @@ static __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
     float g = a.g[i] * a.grad_mul;
     if (i < a.n_clip) g *= coef;
     if (a.wd != 0.f) g += a.wd * p;
+    if (a.method == 1) {  // torch.optim.SGD: buf = g on the first step, else momentum * buf + (1 - dampening) * g
+      float d = g;
+      if (a.beta1 != 0.f) {
+        const bool first = a.bc_dev ? a.bc_dev[2] != 0.f : a.first_step != 0;
+        const float buf = first ? g : a.beta1 * a.m[i] + (1.f - a.beta2) * g;
+        a.m[i] = buf;
+        d = a.nesterov ? g + a.beta1 * buf : buf;
+      }
+      a.p[i] = p - a.lr * d;
+      continue;
+    }
+    if (a.method == 2) {  // torch.optim.RMSprop (centered = False)
+      const float sq = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+      a.v[i] = sq;
+      const float avg = sqrtf(sq) + a.eps;
+      if (a.beta1 > 0.f) {
+        const float buf = a.beta1 * a.m[i] + g / avg;
+        a.m[i] = buf;
+        a.p[i] = p - a.lr * buf;
+      } else {
+        a.p[i] = p - a.lr * (g / avg);
+      }
+      continue;
+    }
     float m = a.m[i];
     m = m + (g - m) * (1.f - a.beta1);  // lerp form, as torch.optim.Adam
     float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;

@@ -210,9 +210,12 @@ class Engine:
         self.lib.check(self.lib.forward(p["handle"], ptr(images), ptr(out), int(bool(training)), _stream(images)))
         return out
 
-    def configure_step(self, p, lr, weight_decay, betas, eps, max_grad_norm, learn_beta, learn_gamma):
+    def configure_step(self, p, lr, weight_decay, betas, eps, max_grad_norm, learn_beta, learn_gamma, method=(0, 0)):
         h = p["handle"]
         self.lib.check(self.lib.set_optim(h, lr, weight_decay, betas[0], betas[1], eps, max_grad_norm))
+        if p.get("method", (0, 0)) != tuple(method):
+            self.lib.check(self.lib.set_optim_method(h, int(method[0]), int(method[1])))
+            p["method"] = tuple(method)
         flags = (bool(learn_beta), bool(learn_gamma))
         if p.get("flags") != flags:
             self.lib.check(self.lib.set_learn_flags(h, int(flags[0]), int(flags[1])))

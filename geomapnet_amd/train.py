@@ -63,7 +63,8 @@ def step_feedfwd(data, model, cuda, target=None, criterion=None, optim=None, tra
     _bind(engine, criterion, optim)
     plan = engine.plan(mode, n, t, H, W)
     lr, wd, betas, eps = optim.learner.hyper()
-    engine.configure_step(plan, lr, wd, betas, eps, float(max_grad_norm), criterion.learn_beta, criterion.learn_gamma)
+    engine.configure_step(plan, lr, wd, betas, eps, float(max_grad_norm), criterion.learn_beta, criterion.learn_gamma,
+                          method=optim.learner.method())
     if dp.world_size() > 1 or _FORCE_STAGED:
         loss, poses = dp.train_step(engine, plan, data, target)
     else:

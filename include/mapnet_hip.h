@@ -98,6 +98,11 @@ int mn_set_learn_flags(mn_handle* h, int learn_beta, int learn_gamma);
  * and max_grad_norm (common/train.py:357-358) */
 int mn_set_optim(mn_handle* h, float lr, float weight_decay, float beta1, float beta2, float eps,
                  float max_grad_norm);
+/* The other two methods of the reference's Optimizer (common/optimizer.py:16-26; every shipped config uses 'adam'):
+ * method 0 = Adam (default); 1 = torch.optim.SGD -- mn_set_optim's beta1 is `momentum`, beta2 is `dampening`, eps unused;
+ * 2 = torch.optim.RMSprop (centered = False) -- beta1 is `momentum`, beta2 is `alpha`.  The momentum buffer lives in the
+ * first moment arena (opt_state + param_floats), RMSprop's square average in the second. */
+int mn_set_optim_method(mn_handle* h, int method, int nesterov);
 int mn_set_step_count(mn_handle* h, int64_t step); /* Adam step counter (checkpoint resume) */
 /* Early read-back of the training loss (the reference's `loss.item()`, common/train.py:361): with a pinned host float
  * registered, every training step copies the loss there as soon as the criterion has run and records an event;
@@ -268,6 +273,11 @@ int mn_pgo_optimize(const double* poses, const double* vos, double* out, int32_t
 int mn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip, float lr, float wd,
                float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm, double* sqnorm_scratch,
                int eps_mode, void* stream);
+/* the same launch for any method of mn_set_optim_method (method, nesterov as there; beta1 / beta2 carry momentum and
+ * dampening | alpha); step = 1 is SGD's first step */
+int mn_op_optim(int method, int nesterov, float* p, const float* g, float* m, float* v, int64_t n, int64_t n_clip, float lr,
+                float wd, float beta1, float beta2, float eps, int64_t step, float grad_mul, float max_norm,
+                double* sqnorm_scratch, int eps_mode, void* stream);
 
 /* elementwise / reduction operators (NHWC, C multiple of 16 bytes).
  * Scratch: mn_op_bn_train_fwd's accum_scratch = 2*C doubles followed by 2*C floats; mn_op_bn_bwd's accum_scratch = 2*C

@@ -591,6 +591,88 @@ def check_adam(lib, dev, n=10007, steps=3, max_norm=0.0, wd=5e-4, seed=6):
         assert bad.float().mean().item() <= 1e-5 and d.max().item() <= 2e-3
 
 
+def check_sgd_rmsprop(lib, dev, method, n=10007, steps=4, max_norm=0.0, wd=5e-4, seed=6, **kw):
+    """the fused update in its SGD / RMSprop forms (common/optimizer.py:16-26) vs torch.optim.SGD / RMSprop"""
+    _fresh()
+    gen = torch.Generator().manual_seed(seed)
+    p0 = torch.randn(n, generator=gen)
+    pt = p0.clone().requires_grad_(True)
+    if method == "sgd":
+        opt = torch.optim.SGD([pt], lr=1e-2, weight_decay=wd, **kw)
+        mid, nest = 1, int(kw.get("nesterov", False))
+        b1, b2, eps = kw.get("momentum", 0.0), kw.get("dampening", 0.0), 0.0
+    else:
+        opt = torch.optim.RMSprop([pt], lr=1e-3, weight_decay=wd, **kw)
+        mid, nest = 2, 0
+        b1, b2, eps = kw.get("momentum", 0.0), kw.get("alpha", 0.99), kw.get("eps", 1e-8)
+    lr = opt.param_groups[0]["lr"]
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    sq = torch.zeros(1, dtype=torch.float64, device=dev)
+    for step in range(1, steps + 1):
+        g = torch.randn(n, generator=gen) * (5.0 if step == 1 else 0.1)
+        pt.grad = g.clone()
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([pt], max_norm)
+        opt.step()
+        lib.check(lib.op_optim(mid, nest, K(p), K(g.to(dev)), K(m), K(v), n, n, f32(lr), f32(wd), f32(b1), f32(b2), f32(eps),
+                               step, f32(1.0), f32(max_norm), K(sq), 0, None))
+        dev_sync(dev)
+        d = (p.cpu() - pt.detach()).abs()
+        bad = d > (2e-6 + 1e-5 * pt.detach().abs())
+        assert bad.float().mean().item() <= 1e-5 and d.max().item() <= 2e-3, (step, d.max().item())
+    st = opt.state[pt]
+    if "momentum_buffer" in st:
+        assert (m.cpu() - st["momentum_buffer"]).abs().max().item() <= 1e-5 * max(1.0, st["momentum_buffer"].abs().max().item())
+    if "square_avg" in st:
+        assert (v.cpu() - st["square_avg"]).abs().max().item() <= 1e-5 * max(1.0, st["square_avg"].abs().max().item())
+
+
+def check_train_other_optimizers(lib, dev, method, N=1, H=32, W=40, steps=2, **kw):
+    """step_feedfwd with Optimizer(method='sgd' | 'rmsprop') vs the oracle's torch.optim counterpart: parameters after
+    `steps` steps, the optimiser state in torch's state_dict format, the SGD step schedule of the wrapper"""
+    _fresh()
+    import geomapnet_amd as G
+    G.set_compute_dtype("fp32")
+    onet, net = build_pair(lib, dev)
+    x, t = oracle.make_batch("mapnet", N, H, W, seed=7)
+    oc = oracle.MapNetCriterion(0.0, -3.0, 0.0, -3.0, True, True)
+    c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+    og = [{"params": onet.parameters()}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}]
+    gg = [{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}]
+    lr = 1e-4 if method == "sgd" else 1e-5
+    oopt = oracle.Optimizer(og, method, base_lr=lr, weight_decay=5e-4, **dict(kw))
+    opt = G.Optimizer(gg, method, base_lr=lr, weight_decay=5e-4, **dict(kw))
+    if method == "sgd":  # the wrapper's step schedule (common/optimizer.py:28-42)
+        for ep in (0, 3, 7):
+            assert abs(opt.adjust_lr(ep) - oopt.adjust_lr(ep)) < 1e-12
+            assert opt.learner.param_groups[0]["lr"] == oopt.learner.param_groups[0]["lr"]
+        opt.adjust_lr(0), oopt.adjust_lr(0)
+    onet.train()
+    net.train()
+    p_init = {k: v.detach().clone() for k, v in onet.named_parameters()}
+    for step in range(steps):
+        lo, po = oracle.step_feedfwd(x, onet, False, t, oc, oopt, True, 0.0)
+        l, p = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True, 0.0)
+        if step == 0:
+            assert abs(l - lo) <= 1e-4 * max(1.0, abs(lo)), (l, lo)
+    dev_sync(dev)
+    hp = dict(net.named_parameters())
+    num = den = 0.0
+    for k, v in onet.named_parameters():
+        d_or = (v.detach() - p_init[k]).double()
+        d_hip = (hp[k].detach().cpu() - p_init[k]).double()
+        num += float((d_hip - d_or).pow(2).sum())
+        den += float(d_or.pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 5e-2, (num, den)
+    # state in torch's format: loadable by the real optimiser, same keys as the oracle's
+    sd, osd = opt.learner.state_dict(), oopt.learner.state_dict()
+    assert set(sd["state"].keys()) == set(osd["state"].keys())
+    for k in osd["state"]:
+        assert set(sd["state"][k].keys()) == set(osd["state"][k].keys()), (sd["state"][k].keys(), osd["state"][k].keys())
+    oopt.learner.load_state_dict(sd)
+    return (num / den) ** 0.5
+
+
 # ---- whole network --------------------------------------------------------------------------------------
 def build_pair(lib, dev, seed=7, filter_nans=False):
     import geomapnet_amd as G

@@ -93,6 +93,15 @@ def test_fused_adam(lib, max_norm):
     checks.check_adam(lib, DEV, max_norm=max_norm)
 
 
+@pytest.mark.parametrize("method,kw,max_norm", [
+    ("sgd", {}, 0.0), ("sgd", {"momentum": 0.9}, 5.0), ("sgd", {"momentum": 0.9, "dampening": 0.1}, 0.0),
+    ("sgd", {"momentum": 0.8, "nesterov": True}, 0.0),
+    ("rmsprop", {}, 0.0), ("rmsprop", {"momentum": 0.5, "alpha": 0.9}, 5.0),
+])
+def test_fused_sgd_rmsprop(lib, method, kw, max_norm):
+    checks.check_sgd_rmsprop(lib, DEV, method, max_norm=max_norm, **kw)
+
+
 def test_pose_graph_golden(lib, golden_dir):
     checks.check_pgo_golden(lib, DEV, golden_dir)
 

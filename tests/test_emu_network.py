@@ -83,3 +83,12 @@ def test_deterministic_mode(lib):
     gradients, partial-sum gradient norm) and takes the default mode's step; reproducibility proper is the GPU test"""
     diff = checks.check_deterministic(lib, DEV, "fp16", N=1, H=32, W=40, steps=1)
     assert diff < 1e-3
+
+
+@pytest.mark.parametrize("method,kw", [
+    ("sgd", {"momentum": 0.9, "lr_decay": 0.1, "lr_stepvalues": [3, 6]}),
+    ("rmsprop", {"momentum": 0.5}),
+])
+def test_training_step_with_sgd_and_rmsprop(lib, method, kw):
+    """the reference wrapper's other two methods (common/optimizer.py:16-26) through step_feedfwd, vs the oracle"""
+    checks.check_train_other_optimizers(lib, DEV, method, N=1, H=32, W=40, steps=2, **kw)

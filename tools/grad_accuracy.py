@@ -71,3 +71,7 @@ print("worst tensors of the HIP path:   HIP        fp32 oracle")
 for eh, eo, name, nr in rows[:15]:
     print("  %-52s %.3e  %.3e  |g| %.2e" % (name, eh, eo, nr))
 print("median tensor: HIP %.3e" % rows[len(rows) // 2][0])
+if os.environ.get("GA_ALL"):  # every tensor, in the engine's (network) order
+    order = {("mapnet." + e.name.decode()): i for i, e in enumerate(eng.entries)}
+    for eh, eo, name, nr in sorted(rows, key=lambda r: order[r[2]]):
+        print("  %-52s %.3e  %.3e  |g| %.2e" % (name, eh, eo, nr))

@@ -624,10 +624,11 @@ def check_sgd_rmsprop(lib, dev, method, n=10007, steps=4, max_norm=0.0, wd=5e-4,
         frac = 1e-5 if method == "sgd" else 1e-3
         assert bad.float().mean().item() <= frac and d.max().item() <= 2e-3, (step, bad.float().mean().item(), d.max().item())
     st = opt.state[pt]
-    if "momentum_buffer" in st:
-        assert (m.cpu() - st["momentum_buffer"]).abs().max().item() <= 1e-5 * max(1.0, st["momentum_buffer"].abs().max().item())
-    if "square_avg" in st:
-        assert (v.cpu() - st["square_avg"]).abs().max().item() <= 1e-5 * max(1.0, st["square_avg"].abs().max().item())
+    for key, mine in (("momentum_buffer", m), ("square_avg", v)):
+        if key in st:  # the same ill-conditioned elements carry their difference into RMSprop's momentum buffer
+            dd = (mine.cpu() - st[key]).abs()
+            badm = dd > 1e-5 * max(1.0, st[key].abs().max().item())
+            assert badm.float().mean().item() <= (0.0 if method == "sgd" else 1e-3), (key, badm.float().mean().item())
 
 
 def check_train_other_optimizers(lib, dev, method, N=1, H=32, W=40, steps=2, **kw):
@@ -676,7 +677,9 @@ def check_train_other_optimizers(lib, dev, method, N=1, H=32, W=40, steps=2, **k
     # the first step's update is the optimiser formula applied to gradients that agree to ~1e-3; later steps also carry
     # the network's own amplification of that difference (tools/oracle_sensitivity.py) and the momentum / square-average
     # state of the first
-    assert rel[0] < 2e-2 and rel[-1] < 0.3, rel
+    # (RMSprop's first update g / sqrt((1 - alpha) g^2) is sign-like: every element whose tiny gradient changes sign moves
+    # the other way by a full step -- see the ReLU-gate note in DESIGN.md section 6)
+    assert rel[0] < (2e-2 if method == "sgd" else 0.15) and rel[-1] < 0.3, rel
     # state in torch's format: loadable by the real optimiser, same keys as the oracle's
     sd, osd = opt.learner.state_dict(), oopt.learner.state_dict()
     assert set(sd["state"].keys()) == set(osd["state"].keys())

@@ -64,7 +64,7 @@ def summarize(t_loss, q_loss):
 
 
 def evaluate(model, batches, pose_m=(0.0, 0.0, 0.0), pose_s=(1.0, 1.0, 1.0), cuda=True, pose_graph=False, fc_vos=False,
-             sax=1, saq=1, srx=1, srq=1):
+             sax=1, saq=1, srx=1, srq=1, indices_of=None, length=None):
     """Inference loop of eval.py:153-190.
 
     With `pose_graph` (eval.py:177-182) every target carries the window's VOs after its T absolute poses
@@ -74,6 +74,10 @@ def evaluate(model, batches, pose_m=(0.0, 0.0, 0.0), pose_s=(1.0, 1.0, 1.0), cud
     `batches`: iterable of (data, target) as the reference's DataLoader yields them with batch_size 1:
     data [1,3,H,W] (PoseNet) or [1,T,3,H,W] (MapNet, `--model mapnet*`), target [1,6] / [1,T,6].  For
     every batch the MIDDLE prediction of the window is kept (eval.py:187-190: `output[len(output)/2]`).
+    `indices_of(batch_idx)` (the MF dataset's `get_indices`, eval.py:158-163) with `length` = len(dataset): the middle
+    prediction of batch i is WRITTEN at row `indices_of(i)[middle]` of zero-initialised [length, 7] arrays as the
+    reference does -- windows clamped at the ends of a sequence repeat a middle index and overwrite each other, rows no
+    window centres on stay zero -- instead of being appended one row per batch.
     Returns (summary dict, pred_poses [L,7], targ_poses [L,7])."""
     pred, targ, win_out, win_vos = [], [], [], []
     was_training = model.training
@@ -104,5 +108,13 @@ def evaluate(model, batches, pose_m=(0.0, 0.0, 0.0), pose_s=(1.0, 1.0, 1.0), cud
         opt[:, :, :3] = (opt[:, :, :3] * np.asarray(pose_s, dtype=np.float64)) + np.asarray(pose_m, dtype=np.float64)
         pred = [o[len(o) // 2] for o in opt]
     pred_poses, targ_poses = np.asarray(pred), np.asarray(targ)
+    if indices_of is not None:
+        n = int(length) if length is not None else len(pred_poses)
+        pp, tp = np.zeros((n, 7)), np.zeros((n, 7))
+        for i in range(len(pred_poses)):
+            idx = list(indices_of(i))
+            pp[idx[len(idx) // 2]] = pred_poses[i]
+            tp[idx[len(idx) // 2]] = targ_poses[i]
+        pred_poses, targ_poses = pp, tp
     t_loss, q_loss = pose_errors(pred_poses, targ_poses)
     return summarize(t_loss, q_loss), pred_poses, targ_poses

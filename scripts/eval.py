@@ -127,8 +127,11 @@ def run(args, dataset=None, pose_stats=None, _binding=None, log=print):
     if CUDA:
         model.cuda()
 
+    # eval.py:158-163: with --pose_graph the middle prediction of a window goes to the row of ITS frame
+    scatter = data_set.get_indices if (args.pose_graph and hasattr(data_set, "get_indices")) else None
     summary, pred_poses, targ_poses = E.evaluate(model, loader, pose_m, pose_s, cuda=CUDA, pose_graph=args.pose_graph,
-                                                 fc_vos=fc_vos if windows else False, **sig)
+                                                 fc_vos=fc_vos if windows else False, indices_of=scatter,
+                                                 length=len(data_set) if scatter else None, **sig)
     log("Error in translation: median {:3.2f} m,  mean {:3.2f} m\n"
         "Error in rotation: median {:3.2f} degrees, mean {:3.2f} degree".format(
             summary["median_t"], summary["mean_t"], summary["median_q"], summary["mean_q"]))

@@ -43,6 +43,10 @@ def build_parser():
     parser.add_argument("--suffix", type=str, default="", help="Experiment name suffix (as is)")
     # additions
     parser.add_argument("--dtype", choices=("fp16", "fp32"), default="fp16", help="compute precision of the HIP kernels")
+    parser.add_argument("--pretrained", choices=("auto", "yes", "no"), default="auto",
+                        help="start from the torchvision ImageNet ResNet-34 ($TORCH_MODEL_ZOO/resnet34-333f7ec4.pth, as the "
+                             "reference does: models.resnet34(pretrained=True), scripts/train.py:76) and re-initialise only the "
+                             "three linear layers; auto = yes when that file exists (there is no network to fetch it)")
     parser.add_argument("--synthetic_length", type=int, default=1024, help="frames in the synthetic sequence")
     parser.add_argument("--synthetic_val_length", type=int, default=None, help="frames in the validation sequence "
                         "(default: a quarter of --synthetic_length)")
@@ -118,8 +122,11 @@ def run(args, datasets=None, _binding=None, log=print):
 
     # model (random initialisation: there is no model zoo offline; load weights with --checkpoint)
     torch.manual_seed(seed)
-    feature_extractor = G.resnet34(pretrained=False, **kw)
-    posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=False, filter_nans=(args.model == "mapnet++"), **kw)
+    zoo_file = os.path.join(os.environ.get("TORCH_MODEL_ZOO", os.path.join("..", "data", "models")), "resnet34-333f7ec4.pth")
+    pretrained = args.pretrained == "yes" or (args.pretrained == "auto" and os.path.isfile(zoo_file))
+    print("ResNet-34 weights: %s" % ("ImageNet (%s)" % zoo_file if pretrained else "random initialisation"))
+    feature_extractor = G.resnet34(pretrained=pretrained, **kw)
+    posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=pretrained, filter_nans=(args.model == "mapnet++"), **kw)
     model = posenet if args.model == "posenet" else G.MapNet(mapnet=posenet)
 
     if args.u8_input:  # the DataLoader ships decoded frames; normalisation happens in the input-conversion kernel

@@ -1201,7 +1201,7 @@ def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3):
         G.set_compute_dtype("fp16", loss_scale=1024.0)
 
 
-def check_deterministic(lib, dev, dtype_name, N=2, H=40, W=53, steps=3, max_grad_norm=5.0):
+def check_deterministic(lib, dev, dtype_name, N=2, H=40, W=53, steps=3, max_grad_norm=5.0, repeat=True):
     """MN_DETERMINISTIC=1 (read when a plan is created): two runs of `steps` training steps from the same state are
     BIT-identical in parameters, Adam moments and loss -- BatchNorm sums through one accumulator row per producing
     workgroup, weight gradients through ordered slice / chunk reductions, the gradient norm through ordered partial sums --
@@ -1236,8 +1236,9 @@ def check_deterministic(lib, dev, dtype_name, N=2, H=40, W=53, steps=3, max_grad
                 os.environ["MN_DETERMINISTIC"] = old
 
     p1, o1, l1 = run(True)
-    p2, o2, l2 = run(True)
-    assert torch.equal(p1, p2) and torch.equal(o1, o2) and l1 == l2, "deterministic mode is not reproducible"
+    if repeat:  # (the emulator executes workgroups in order: nothing to reproduce there)
+        p2, o2, l2 = run(True)
+        assert torch.equal(p1, p2) and torch.equal(o1, o2) and l1 == l2, "deterministic mode is not reproducible"
     p0, o0, l0 = run(False)
     assert torch.isfinite(p1).all()
     # same step up to summation order: losses to 1e-4 (fp32) / 2e-3 (fp16); parameters move by lr per step

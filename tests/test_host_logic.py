@@ -184,3 +184,32 @@ def test_shipped_k_loops_have_no_scratch_access_and_asm_reads_skip_the_dma_wait(
         k = next(i for i, t in enumerate(toks) if re.fullmatch(r"Rx\d+", t) and toks[i + 1].startswith("M"))
         d = max(i for i in range(k) if toks[i].startswith("D"))  # the last LDS-DMA issue before the transpose reads
         assert not any(t.startswith("V") for t in toks[d:k]), (name, sig)
+
+
+def test_evaluate_scatters_middle_predictions_by_frame_index(monkeypatch):
+    """eval.py:158-190: with an index callback the middle prediction of batch i is written at row get_indices(i)[middle]
+    of zero-initialised [L, 7] arrays (later windows overwrite earlier ones on the same frame)"""
+    import numpy as np
+    import torch
+    from geomapnet_amd import evaluate as E
+
+    class M:
+        training = False
+
+        def eval(self):
+            return self
+
+        def train(self, mode=True):
+            return self
+
+    outs = [torch.full((1, 3, 6), float(i + 1)) * 0.1 for i in range(4)]
+    it = iter(outs)
+    monkeypatch.setattr(E, "step_feedfwd", lambda data, model, cuda, train=False: (0, next(it)))
+    batches = [(torch.zeros(1, 3, 3, 4, 4), torch.full((1, 3, 6), float(i))) for i in range(4)]
+    idx = {0: [0, 0, 1], 1: [0, 1, 2], 2: [1, 2, 3], 3: [2, 2, 3]}  # frames 0 and 2 are the middle of two windows each
+    summary, pred, targ = E.evaluate(M(), batches, cuda=False, indices_of=lambda i: idx[i], length=5)
+    assert pred.shape == (5, 7) and targ.shape == (5, 7)
+    assert np.allclose(pred[0, :3], 0.1) and np.allclose(pred[1, :3], 0.2)
+    assert np.allclose(pred[2, :3], 0.4), "the later window overwrites the earlier one"
+    assert np.allclose(pred[3], 0) and np.allclose(pred[4], 0)  # no window centres there: rows stay zero, as in the reference
+    assert np.allclose(targ[2, :3], 3.0)

@@ -313,7 +313,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
 inline bool conv_halo_pp_applies(const GatherGeom& g, const Epilogue& ep) {
   return conv_halo_applies(g) && g.N == 64 && ep.ldc == 64 && ep.stats == nullptr && ep.bias == nullptr && !ep.om_on &&
          (ep.stats_accum == nullptr || (ep.stats_rows > 0 && !ep.res && !ep.res_gate && !ep.out_gate)) &&
-         !(ep.res_gate && ep.out_gate);
+         !(ep.res_gate && ep.out_gate) && (long)g.B * g.P * g.Q * ep.ldc * 2L < 0x7ffffff0l;  // (masked lanes use offset 2^31)
 }
 
 // wgs: persistent workgroups (0 = one per CU, or MN_HALO_PP_WGS)

@@ -288,7 +288,7 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __
 // reduce: accum[0][c] += sum gm, accum[1][c] += sum gm * xhat,  gm = g * (gate > 0 if gate)
 // POOL: the gradient is gathered from (argmax, pooled gradient) -- a separate instantiation so that the common form does
 // not carry the gather's registers
-template <typename T, bool POOL = false>
+template <typename T, bool POOL = false, int U = 4>
 static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ gate,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long M, int C,
@@ -316,8 +316,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
   }
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  // four rows per iteration, all loads issued before the arithmetic (memory-level parallelism)
-  constexpr int U = 4;
+  // U rows per iteration, all loads issued before the arithmetic (memory-level parallelism; MN_BN_REDUCE_UNROLL = 4 | 8)
   for (long r = r0 + rl; r < r1; r += (long)U * rlanes) {
     PieceView<T> vg[U], vy[U], vm[U];
 #pragma unroll
@@ -524,8 +523,12 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   if (rows < 4L * rlanes) rows = 4L * rlanes;
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
+  static const int unroll = getenv("MN_BN_REDUCE_UNROLL") ? atoi(getenv("MN_BN_REDUCE_UNROLL")) : 4;
   if (pg.idx)
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
+                       rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
+  else if (unroll == 8)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false, 8>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   else
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,

@@ -11,7 +11,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collect
 try:
     for r in csv.DictReader(open('/tmp/pmc_$n/r_counter_collection.csv')):
         k=r['Kernel_Name'][:70]
-        if 'igemm' not in k and 'wgrad' not in k: continue
+        if 'igemm' not in k and 'wgrad' not in k and 'halo' not in k: continue
         agg[k][r['Counter_Name']]+=float(r['Counter_Value']); cnt[(k,r['Counter_Name'])]+=1
     for k,d in agg.items():
         print(k)

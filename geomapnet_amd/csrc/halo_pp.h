@@ -1,7 +1,7 @@
 // 3x3 stride-1 convolution of 64 -> 64 channel fp16 tensors (ResNet layer1, forward and data gradient): persistent
 // "ping-pong" form of halo.h.
 //
-// halo.h runs one 16x16-pixel tile per 4-wave workgroup: halo DMA -> wait -> nine taps with a barrier each (the tap's
+// halo.h runs one 16x16-pixel tile per 4-wave workgroup (this kernel: 8x32-pixel tiles, see kPpTH below): halo DMA -> wait -> nine taps with a barrier each (the tap's
 // weight slice streams through a two-slot ring) -> epilogue through an LDS staging block.  Its ablations (profiles/r02)
 // show the three phases ADD: a CU holds two such workgroups and they drift into the same phase, so the matrix pipe
 // idles through the DMA waits, nine barrier bubbles per tile and the epilogue (123 us for a launch whose MFMA time is
@@ -14,7 +14,7 @@
 //   one s_barrier per phase.
 //
 // So the matrix pipe of each SIMD always has one wave in its MFMA loop while the other wave of that SIMD does the
-// memory-side work of the neighbouring tiles.  LDS: weights 72 KB + two halo images 2 x 41 KB + column sums = 158 KB.
+// memory-side work of the neighbouring tiles.  LDS: weights 72 KB + two halo images 2 x 43 KB = 158 KB.
 //
 // The epilogue uses NO LDS (a staging block would have to live in the halo buffer and delay the next halo's DMA behind
 // the stores): the MFMA operands are swapped -- weights as the A operand, pixels as B -- so that the accumulator of a
@@ -28,8 +28,14 @@
 namespace mn {
 
 constexpr int kPpWeightPieces = 9 * 512;  // nine 64 x 64 fp16 slices
-constexpr int kPpWaveRegion = 640;        // pieces of a halo buffer one wave DMAs
-constexpr int kPpHaloBuf = 2624;          // 4 x 640 + the 32-piece tail (padded to one wave-wide DMA)
+// Tile: 8 rows x 32 columns (halo.h: 16 x 16).  The 32 pixel lanes of an MFMA operand are then 32 CONSECUTIVE pixels of one
+// halo row = 32 consecutive LDS rows, the conflict-free ds_read_b128 pattern of igemm.h; with 16 x 16 tiles lanes 16-31 sit
+// one halo row (18 pixels) below lanes 0-15 and collide with lanes 2-17 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.31,
+// profiles/r02/c27_sq_counters_*.txt).  Same number of tiles for 64 x 86 maps (8 x 3 instead of 4 x 6), 340 instead of 324
+// halo pixels.
+constexpr int kPpTH = 8, kPpTW = 32;
+constexpr int kPpHaloPasses = ((kPpTH + 2) * (kPpTW + 2) * 8 + 63) / 64;  // wave-wide DMA instructions per halo: 43
+constexpr int kPpHaloBuf = kPpHaloPasses * 64;                            // 2752 pieces
 
 // ABL (timing experiments only, ablation build, results are wrong): bit 0 = halo DMA only for each group's first tile,
 // bit 1 = no fragment reads, bit 2 = no stores / residual / gate loads, bit 3 = no MFMA.  PRIO: s_setprio of the MFMA loop.
@@ -40,11 +46,11 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
                                                                      const half* __restrict__ Bw, Epilogue ep, int tiles_x,
                                                                      int tiles_y, int ntiles) {
   constexpr int NP = 8;
-  constexpr int TH = kHaloTH, TW = kHaloTW, HW = TW + 2, HPIX = HW * (TH + 2);
+  constexpr int TH = kPpTH, TW = kPpTW, HW = TW + 2, HPIX = HW * (TH + 2);
   constexpr unsigned kOob = 0x80000000u;  // byte offset of a masked lane: beyond every tensor, no wrap when offsets are added
-  static_assert(HPIX * NP == 4 * kPpWaveRegion + 32, "halo split");
-  __shared__ piece_t smem[kPpWeightPieces + 2 * kPpHaloBuf + 256];
-  float* red = reinterpret_cast<float*>(&smem[kPpWeightPieces + 2 * kPpHaloBuf]);  // [8 waves][64][2]
+  static_assert((kPpWeightPieces + 2 * kPpHaloBuf) * 16 <= 160 * 1024 && kPpHaloBuf >= 256, "LDS");
+  __shared__ piece_t smem[kPpWeightPieces + 2 * kPpHaloBuf];
+  float* red = reinterpret_cast<float*>(&smem[kPpWeightPieces]);  // [8 waves][64][2]: the first halo buffer, after the last phase
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -84,22 +90,23 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
     y0 = tyi * TH;
     x0 = txi * TW;
   };
-  // halo of a tile -> this group's buffer: wave wq DMAs pieces [640 wq, 640 wq + 640), wave 0 also the 32-piece tail
+  // halo of a tile -> this group's buffer: 43 wave-wide DMA instructions dealt round-robin to the group's four waves
   auto issue_halo = [&](int tile) __attribute__((always_inline)) {
     int b, y0, x0;
     tile_coords(tile, b, y0, x0);
     const int oy = y0 + off_h, ox = x0 + off_w;
-    auto one = [&](int q, piece_t* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < (kPpHaloPasses + 3) / 4; ++i) {
+      const int pass = i * 4 + wq;
+      if (pass >= kPpHaloPasses) continue;  // wave-uniform
+      const int q = pass * 64 + lane;
       const int hp = q >> 3, pc = q & 7;
       const int hy = hp / HW, hx = hp - hy * HW;
       const int iy = oy + hy, ix = ox + hx;
       const bool ok = hp < HPIX && (unsigned)iy < (unsigned)gHi && (unsigned)ix < (unsigned)gWi;
       const unsigned off = ok ? (unsigned)((((b * gHi + iy) * gWi + ix) * gC) * 2) + (unsigned)((pc ^ ((hp >> 1) & 7)) * 16) : ~0u;
-      dma16(rsrc_a, off, 0u, dst);
-    };
-#pragma unroll
-    for (int i = 0; i < kPpWaveRegion / 64; ++i) one(wq * kPpWaveRegion + i * 64 + lane, hbuf + wq * kPpWaveRegion + i * 64);
-    if (wq == 0) one(4 * kPpWaveRegion + lane, hbuf + 4 * kPpWaveRegion);
+      dma16(rsrc_a, off, 0u, hbuf + pass * 64);
+    }
   };
 
   // ---- prologue: all nine weight slices (pass i = tap i: 64 rows x 8 pieces, swizzled on the source side), the first
@@ -112,7 +119,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
   }
   if (grp < nitems) issue_halo(wl + grp * G);
 
-  // acc[i][j]: pixel tile i (pixels wq * 64 + i * 32 + (lane & 31) of the 16 x 16 tile) x channel tile j; register r =
+  // acc[i][j]: pixel tile i (tile row 2 wq + i, column lane & 31) x channel tile j; register r =
   // channel 32 j + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   floatx16 acc[2][2];
   float st1[STATS ? 2 : 1][16], st2[STATS ? 2 : 1][16];  // per-lane column sums over this lane's pixels
@@ -130,8 +137,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
     tile_coords(tile, b, y0, x0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int rl = wq * 64 + i * 32 + l31;
-      const int y = y0 + (rl >> 4), x = x0 + (rl & 15);
+      const int y = y0 + 2 * wq + i, x = x0 + l31;
       okp[i] = y < gP && x < gQ;
       voff[i] = okp[i] ? (unsigned)((((b * gP + y) * gQ + x) * ldc) * 2 + kh * 8) : kOob;
     }
@@ -152,7 +158,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
         }
   };
 
-  const int prow = 4 * wq + (l31 >> 4), pcol = l31 & 15;
+  const int prow = 2 * wq, pcol = l31;  // MFMA pixel tile i = tile row prow + i
   auto compute = [&](int tile) __attribute__((always_inline)) {
     if constexpr (EARLY) load_side(tile);
 #pragma unroll
@@ -176,7 +182,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
       const int hp0 = hpf + sg * ((tap / 3) * HW + tap % 3);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int hp = hp0 + i * 2 * HW;
+        const int hp = hp0 + i * HW;
         fa[ks & SM][i].p = hbuf[hp * NP + (piece ^ ((hp >> 1) & 7))];
       }
 #pragma unroll
@@ -319,7 +325,7 @@ inline bool conv_halo_pp_applies(const GatherGeom& g, const Epilogue& ep) {
 // wgs: persistent workgroups (0 = one per CU, or MN_HALO_PP_WGS)
 inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
                                 int wgs_arg = 0) {
-  const int tx = cdiv(g.Q, kHaloTW), ty = cdiv(g.P, kHaloTH);
+  const int tx = cdiv(g.Q, kPpTW), ty = cdiv(g.P, kPpTH);
   const int ntiles = g.B * tx * ty;
   static const int wgs_env = getenv("MN_HALO_PP_WGS") ? atoi(getenv("MN_HALO_PP_WGS")) : 256;  // one per CU
   const int wgs = wgs_arg > 0 ? wgs_arg : wgs_env;

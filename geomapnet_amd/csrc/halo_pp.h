@@ -1,7 +1,7 @@
 // 3x3 stride-1 convolution of 64 -> 64 channel fp16 tensors (ResNet layer1, forward and data gradient): persistent
 // "ping-pong" form of halo.h.
 //
-// halo.h runs one 16x16-pixel tile per 4-wave workgroup (this kernel: 8x32-pixel tiles, see kPpTH below): halo DMA -> wait -> nine taps with a barrier each (the tap's
+// halo.h runs one 16x16-pixel tile per 4-wave workgroup (this kernel: 8x32- or 16x16-pixel tiles, template parameter TW): halo DMA -> wait -> nine taps with a barrier each (the tap's
 // weight slice streams through a two-slot ring) -> epilogue through an LDS staging block.  Its ablations (profiles/r02)
 // show the three phases ADD: a CU holds two such workgroups and they drift into the same phase, so the matrix pipe
 // idles through the DMA waits, nine barrier bubbles per tile and the epilogue (123 us for a launch whose MFMA time is
@@ -33,20 +33,22 @@ constexpr int kPpWeightPieces = 9 * 512;  // nine 64 x 64 fp16 slices
 // one halo row (18 pixels) below lanes 0-15 and collide with lanes 2-17 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.31,
 // profiles/r02/c27_sq_counters_*.txt).  Same number of tiles for 64 x 86 maps (8 x 3 instead of 4 x 6), 340 instead of 324
 // halo pixels.
-constexpr int kPpTH = 8, kPpTW = 32;
-constexpr int kPpHaloPasses = ((kPpTH + 2) * (kPpTW + 2) * 8 + 63) / 64;  // wave-wide DMA instructions per halo: 43
-constexpr int kPpHaloBuf = kPpHaloPasses * 64;                            // 2752 pieces
+// TW = 32 (TH = 8) or 16 (TH = 16): template parameter, MN_HALO_PP_TILE selects (same-box A/B in profiles/r02/c29_*).
+constexpr int pp_halo_passes(int TW) { return ((256 / TW + 2) * (TW + 2) * 8 + 63) / 64; }  // wave-wide DMAs per halo: 43 | 41
 
 // ABL (timing experiments only, ablation build, results are wrong): bit 0 = halo DMA only for each group's first tile,
 // bit 1 = no fragment reads, bit 2 = no stores / residual / gate loads, bit 3 = no MFMA.  PRIO: s_setprio of the MFMA loop.
 // PD: K-sub-steps a fragment is read ahead of its MFMAs.  EARLY: residual / gate values of a tile are requested before its
 // MFMA loop (64 registers held through it) instead of at the start of the store phase.
-template <bool STATS, int ABL = 0, int PRIO = 0, int PD = 3, bool EARLY = false>
+template <bool STATS, int ABL = 0, int PRIO = 0, int PD = 3, bool EARLY = false, int TW = 32>
 static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom g, const half* __restrict__ A,
                                                                      const half* __restrict__ Bw, Epilogue ep, int tiles_x,
                                                                      int tiles_y, int ntiles) {
   constexpr int NP = 8;
-  constexpr int TH = kPpTH, TW = kPpTW, HW = TW + 2, HPIX = HW * (TH + 2);
+  static_assert(TW == 16 || TW == 32, "tile width");
+  constexpr int TH = 256 / TW, HW = TW + 2, HPIX = HW * (TH + 2);
+  constexpr int RM = 32 / TW;  // tile rows per 32-pixel MFMA operand
+  constexpr int kPpHaloPasses = pp_halo_passes(TW), kPpHaloBuf = kPpHaloPasses * 64;
   constexpr unsigned kOob = 0x80000000u;  // byte offset of a masked lane: beyond every tensor, no wrap when offsets are added
   static_assert((kPpWeightPieces + 2 * kPpHaloBuf) * 16 <= 160 * 1024 && kPpHaloBuf >= 256, "LDS");
   __shared__ piece_t smem[kPpWeightPieces + 2 * kPpHaloBuf];
@@ -119,7 +121,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
   }
   if (grp < nitems) issue_halo(wl + grp * G);
 
-  // acc[i][j]: pixel tile i (tile row 2 wq + i, column lane & 31) x channel tile j; register r =
+  // acc[i][j]: pixel tile i (32 pixels: tile row 2 wq + i for TW = 32, rows 4 wq + 2 i, + 1 for TW = 16) x channel tile j; register r =
   // channel 32 j + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   floatx16 acc[2][2];
   float st1[STATS ? 2 : 1][16], st2[STATS ? 2 : 1][16];  // per-lane column sums over this lane's pixels
@@ -137,7 +139,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
     tile_coords(tile, b, y0, x0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int y = y0 + 2 * wq + i, x = x0 + l31;
+      const int y = y0 + (2 * wq + i) * RM + l31 / TW, x = x0 + l31 % TW;
       okp[i] = y < gP && x < gQ;
       voff[i] = okp[i] ? (unsigned)((((b * gP + y) * gQ + x) * ldc) * 2 + kh * 8) : kOob;
     }
@@ -158,7 +160,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
         }
   };
 
-  const int prow = 2 * wq, pcol = l31;  // MFMA pixel tile i = tile row prow + i
+  const int prow = 2 * wq * RM + l31 / TW, pcol = l31 % TW;  // MFMA pixel tile i: RM tile rows further down
   auto compute = [&](int tile) __attribute__((always_inline)) {
     if constexpr (EARLY) load_side(tile);
 #pragma unroll
@@ -182,7 +184,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
       const int hp0 = hpf + sg * ((tap / 3) * HW + tap % 3);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int hp = hp0 + i * HW;
+        const int hp = hp0 + i * RM * HW;
         fa[ks & SM][i].p = hbuf[hp * NP + (piece ^ ((hp >> 1) & 7))];
       }
 #pragma unroll
@@ -325,7 +327,8 @@ inline bool conv_halo_pp_applies(const GatherGeom& g, const Epilogue& ep) {
 // wgs: persistent workgroups (0 = one per CU, or MN_HALO_PP_WGS)
 inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
                                 int wgs_arg = 0) {
-  const int tx = cdiv(g.Q, kPpTW), ty = cdiv(g.P, kPpTH);
+  static const int tw = getenv("MN_HALO_PP_TILE") && atoi(getenv("MN_HALO_PP_TILE")) == 16 ? 16 : 32;
+  const int tx = cdiv(g.Q, tw), ty = cdiv(g.P, 256 / tw);
   const int ntiles = g.B * tx * ty;
   static const int wgs_env = getenv("MN_HALO_PP_WGS") ? atoi(getenv("MN_HALO_PP_WGS")) : 256;  // one per CU
   const int wgs = wgs_arg > 0 ? wgs_arg : wgs_env;
@@ -362,6 +365,13 @@ inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* 
 #undef PP_CASE
 #undef PP_VAR
 #endif
+  if (tw == 16) {
+    if (ep.stats_accum)
+      hipLaunchKernelGGL((conv_halo_pp_kernel<true, 0, 0, 3, false, 16>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
+    else
+      hipLaunchKernelGGL((conv_halo_pp_kernel<false, 0, 0, 3, false, 16>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
+    return;
+  }
   if (ep.stats_accum)
     hipLaunchKernelGGL(conv_halo_pp_kernel<true>, grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
   else

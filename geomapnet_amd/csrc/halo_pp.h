@@ -28,11 +28,12 @@
 namespace mn {
 
 constexpr int kPpWeightPieces = 9 * 512;  // nine 64 x 64 fp16 slices
-// Tile: 8 rows x 32 columns (halo.h: 16 x 16).  The 32 pixel lanes of an MFMA operand are then 32 CONSECUTIVE pixels of one
-// halo row = 32 consecutive LDS rows, the conflict-free ds_read_b128 pattern of igemm.h; with 16 x 16 tiles lanes 16-31 sit
-// one halo row (18 pixels) below lanes 0-15 and collide with lanes 2-17 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.31,
-// profiles/r02/c27_sq_counters_*.txt).  Same number of tiles for 64 x 86 maps (8 x 3 instead of 4 x 6), 340 instead of 324
-// halo pixels.
+// Tile: 16 x 16 pixels (halo.h's) or 8 rows x 32 columns.  With 8 x 32 the 32 pixel lanes of an MFMA operand are 32
+// CONSECUTIVE pixels of one halo row = 32 consecutive LDS rows, the conflict-free ds_read_b128 pattern of igemm.h; with
+// 16 x 16 tiles lanes 16-31 sit one halo row (18 pixels) below lanes 0-15 and collide with lanes 2-17
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.31 vs 0, profiles/r02/c27_sq_counters_layer1.txt, c28_*).  Same number of
+// tiles for 64 x 86 maps (8 x 3 instead of 4 x 6), 340 instead of 324 halo pixels.  Measured EQUAL (c29_*): the default
+// stays 16 x 16.
 // TW = 32 (TH = 8) or 16 (TH = 16): template parameter, MN_HALO_PP_TILE selects (same-box A/B in profiles/r02/c29_*).
 constexpr int pp_halo_passes(int TW) { return ((256 / TW + 2) * (TW + 2) * 8 + 63) / 64; }  // wave-wide DMAs per halo: 43 | 41
 
@@ -40,7 +41,7 @@ constexpr int pp_halo_passes(int TW) { return ((256 / TW + 2) * (TW + 2) * 8 + 6
 // bit 1 = no fragment reads, bit 2 = no stores / residual / gate loads, bit 3 = no MFMA.  PRIO: s_setprio of the MFMA loop.
 // PD: K-sub-steps a fragment is read ahead of its MFMAs.  EARLY: residual / gate values of a tile are requested before its
 // MFMA loop (64 registers held through it) instead of at the start of the store phase.
-template <bool STATS, int ABL = 0, int PRIO = 0, int PD = 3, bool EARLY = false, int TW = 32>
+template <bool STATS, int ABL = 0, int PRIO = 0, int PD = 3, bool EARLY = false, int TW = 16>
 static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom g, const half* __restrict__ A,
                                                                      const half* __restrict__ Bw, Epilogue ep, int tiles_x,
                                                                      int tiles_y, int ntiles) {
@@ -327,7 +328,9 @@ inline bool conv_halo_pp_applies(const GatherGeom& g, const Epilogue& ep) {
 // wgs: persistent workgroups (0 = one per CU, or MN_HALO_PP_WGS)
 inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
                                 int wgs_arg = 0) {
-  static const int tw = getenv("MN_HALO_PP_TILE") && atoi(getenv("MN_HALO_PP_TILE")) == 16 ? 16 : 32;
+  // 16 (default): 16 x 16 tiles; 32: 8 x 32 tiles, whose fragment reads have no bank conflicts -- measured the same per
+  // launch and 0.3 % slower per step (15.27 vs 15.21 ms, same box): the conflicts are not what bounds the MFMA loop
+  static const int tw = getenv("MN_HALO_PP_TILE") && atoi(getenv("MN_HALO_PP_TILE")) == 32 ? 32 : 16;
   const int tx = cdiv(g.Q, tw), ty = cdiv(g.P, 256 / tw);
   const int ntiles = g.B * tx * ty;
   static const int wgs_env = getenv("MN_HALO_PP_WGS") ? atoi(getenv("MN_HALO_PP_WGS")) : 256;  // one per CU
@@ -365,11 +368,11 @@ inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* 
 #undef PP_CASE
 #undef PP_VAR
 #endif
-  if (tw == 16) {
+  if (tw == 32) {
     if (ep.stats_accum)
-      hipLaunchKernelGGL((conv_halo_pp_kernel<true, 0, 0, 3, false, 16>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
+      hipLaunchKernelGGL((conv_halo_pp_kernel<true, 0, 0, 3, false, 32>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
     else
-      hipLaunchKernelGGL((conv_halo_pp_kernel<false, 0, 0, 3, false, 16>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
+      hipLaunchKernelGGL((conv_halo_pp_kernel<false, 0, 0, 3, false, 32>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
     return;
   }
   if (ep.stats_accum)

@@ -1241,10 +1241,11 @@ def check_deterministic(lib, dev, dtype_name, N=2, H=40, W=53, steps=3, max_grad
         assert torch.equal(p1, p2) and torch.equal(o1, o2) and l1 == l2, "deterministic mode is not reproducible"
     p0, o0, l0 = run(False)
     assert torch.isfinite(p1).all()
-    # same step up to summation order: losses to 1e-4 (fp32) / 2e-3 (fp16); parameters move by lr per step
+    # same step up to summation order: the first loss to 1e-4 (fp32) / 2e-3 (fp16); every further step amplifies the
+    # summation-order difference ~30x (tools/oracle_sensitivity.py: the oracle against itself under another thread count)
     tol = 1e-4 if dtype_name == "fp32" else 2e-3
-    for a, b in zip(l0, l1):
-        assert abs(a - b) <= tol * max(1.0, abs(a)), (l0, l1)
+    for i, (a, b) in enumerate(zip(l0, l1)):
+        assert abs(a - b) <= min(5e-2, tol * 30.0 ** i) * max(1.0, abs(a)), (l0, l1)
     return float((p0 - p1).abs().max())
 
 

@@ -15,12 +15,24 @@ typedef _Float16 half;
 typedef half half8 __attribute__((ext_vector_type(8)));
 typedef half half4 __attribute__((ext_vector_type(4)));
 typedef half half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t piece_t __attribute__((ext_vector_type(4)));  // one 16-byte piece
 
 enum { MN_F32 = 0, MN_F16 = 1 };
+
+// Matrix-core arithmetic of the fp32-STORAGE kernels (igemm.h, wgrad.h; GatherGeom::mma):
+//   MMA_NATIVE  v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain (157 TF peak)
+//   MMA_F16X3   every fp32 operand is split in registers into hi + lo fp16 halves (x*s = hi + lo to ~2^-22) and a product
+//               costs three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): fp32-class results on the
+//               2.5 PF pipe.  Used for the forward pass (operands are O(1): activations and weights, the latter pre-scaled
+//               by kX3WeightScale so that their lo halves stay normal fp16 numbers).
+//   MMA_BF16X3  the same with bf16 halves (x = hi + lo to ~2^-16, fp32's exponent range: no scaling, nothing can over- or
+//               underflow).  Used for the backward pass, whose operands (activation gradients) span many binades.
+enum { MMA_NATIVE = 0, MMA_F16X3 = 1, MMA_BF16X3 = 2 };
+constexpr float kX3WeightScale = 256.f;
 
 template <typename T>
 struct ElemTraits;
@@ -62,6 +74,28 @@ union Half4View {
   u32x2 p;
   half e[4];
 };
+
+// ---- fp32 -> (hi, lo) operand splits of the x3 matrix-core modes -----------------------------------------
+// x[0..7] * s = hi + lo.  fp16: hi = rn16(x s), lo = rn16(x s - hi) (the difference is exact in fp32): |x s - hi - lo| <=
+// 2^-22 |x s| while lo is a normal fp16 number, <= 2^-25 absolute below that.
+__device__ __forceinline__ void split8_f16(const float (&x)[8], float s, half8& hi, half8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = x[e] * s;
+    const half h = (half)v;
+    hi[e] = h;
+    lo[e] = (half)(v - (float)h);
+  }
+}
+// bf16: 8 + 8 significand bits, fp32's exponent range
+__device__ __forceinline__ void split8_bf16(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)x[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(x[e] - (float)h);
+  }
+}
 
 // ---- wave reductions (64 lanes) ---------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -52,6 +52,9 @@ struct GatherGeom {
   // R x S taps, the WEIGHT walk maps them to taps (bt_r0 + 2 r, bt_s0 + 2 s) of a bt_S-wide full kernel, and a weight
   // row is ldb elements long (0 = K).  Needs the taps-fastest order.
   int ldb = 0, bt_on = 0, bt_r0 = 0, bt_s0 = 0, bt_S = 0;
+  // matrix-core arithmetic for fp32 tensors (common.h MMA_*; not part of the C ABI of the operator entry points, which
+  // set it from their dtype argument): ignored by the fp16 kernels
+  int mma = MMA_NATIVE;
 };
 
 // n / d for 0 <= n < 2^31 without the ~35-instruction software division (Granlund-Montgomery round-up
@@ -114,6 +117,39 @@ __device__ __forceinline__ void mma_piece<float>(const PieceView<float>& a, cons
   for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.e[j], b.e[j], c, 0, 0, 0);
 }
 
+// x3 modes (common.h): one fragment = 8 consecutive k of one row = TWO fp32 pieces, split into hi / lo halves in registers
+template <int MM>
+struct X3Frag;
+template <>
+struct X3Frag<MMA_F16X3> {
+  half8 hi, lo;
+};
+template <>
+struct X3Frag<MMA_BF16X3> {
+  bf16x8 hi, lo;
+};
+template <int MM>
+__device__ __forceinline__ void x3_split(const PieceView<float>& p0, const PieceView<float>& p1, float s, X3Frag<MM>& f) {
+  const float x[8] = {p0.e[0], p0.e[1], p0.e[2], p0.e[3], p1.e[0], p1.e[1], p1.e[2], p1.e[3]};
+  if constexpr (MM == MMA_F16X3)
+    split8_f16(x, s, f.hi, f.lo);
+  else
+    split8_bf16(x, f.hi, f.lo);
+}
+// c += a b without the lo*lo term (2^-22 / 2^-16 of the product); small terms first
+template <int MM>
+__device__ __forceinline__ void x3_mma(const X3Frag<MM>& a, const X3Frag<MM>& b, floatx16& c) {
+  if constexpr (MM == MMA_F16X3) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+  }
+}
+
 // slot swizzle for rows of NP 16-byte pieces: rows r, r+1, .. of a 16-lane ds_read_b128 group land in
 // distinct slots of the 256-byte bank row
 template <int NP>
@@ -169,8 +205,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (A "rotated" loop -- K-step boundary before the last MFMA sub-step, first fragments of the next tile read there so
 // that their LDS latency hides under the previous tile's MFMAs -- was implemented, emulator-verified and measured
 // neutral on the 288x256, 128x128 and 128x64 configurations; removed.)
+// MM (fp32 tensors only): MMA_F16X3 / MMA_BF16X3 run the contraction on the f16 / bf16 matrix pipe with every operand split
+// into hi + lo halves after its LDS read, three MFMAs per product (common.h): the K-step's pieces are consumed in groups
+// of four (16 k: lanes 0-31 take pieces 4 kp, 4 kp + 1, lanes 32-63 pieces 4 kp + 2, 4 kp + 3 -- any k order is valid as
+// long as A and B agree).  In MMA_F16X3 the B operand (the weights) is pre-scaled by kX3WeightScale, divided out of alpha.
 template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SK = false, bool SPL = false,
-          int ABL = 0>
+          int ABL = 0, int MM = MMA_NATIVE>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                          const T* __restrict__ zero_page, RowDiv rd,
@@ -396,7 +436,6 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     const piece_t* ta = &smem[cur * TILE_PIECES];
     // fragments are register double-buffered: the ds_reads of sub-step ks+1 are issued before the MFMAs
     // of sub-step ks so LDS latency hides under the matrix pipe
-    PieceView<T> fa[2][TM], fb[2][TN];
     // Fragment row = (wave tile origin, a multiple of 32) + 32 * tile + (lane & 31): the swizzle only looks at row
     // bits 1..3, so it is lds_swz(lane & 31) for every fragment, and the fragments of one operand differ by the constant
     // 32 * NP pieces -- two base addresses and immediate offsets instead of one address register per fragment (which
@@ -411,6 +450,41 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #else
     const int ln = lane;
 #endif
+    if constexpr (MM != MMA_NATIVE) {
+      static_assert(sizeof(T) == 4 && NP % 4 == 0 && ABL == 0 && !SK, "x3 modes: fp32 tensors, whole groups of four pieces");
+      constexpr int NKP = NP / 4;
+      PieceView<float> ra[TM][2], rb[TN][2];
+      auto load_raw = [&](int kp) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pxs = (kp * 4 + (ln >> 5) * 2 + h) ^ lds_swz<NP>(ln & 31);
+          const piece_t* pa = ta + (wm * WTM + (ln & 31)) * NP + pxs;
+          const piece_t* pb = ta + (BM + wn * WTN + (ln & 31)) * NP + pxs;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) ra[i][h].p = pa[i * 32 * NP];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) rb[j][h].p = pb[j * 32 * NP];
+        }
+      };
+      load_raw(0);
+#pragma unroll
+      for (int kp = 0; kp < NKP; ++kp) {
+        X3Frag<MM> xa[TM], xb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) x3_split<MM>(ra[i][0], ra[i][1], 1.f, xa[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) x3_split<MM>(rb[j][0], rb[j][1], kX3WeightScale, xb[j]);
+        if (kp + 1 < NKP) load_raw(kp + 1);  // the raw registers are free again: next group's reads fly under these MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) x3_mma<MM>(xa[i], xb[j], acc[i][j]);
+        if constexpr (SPL) {
+          if (more) issue_part(nxt, kp * IPT / NKP, (kp + 1) * IPT / NKP);
+        }
+      }
+    } else {
+    PieceView<T> fa[2][TM], fb[2][TN];
     auto load_frags = [&](int ks, int slot) {
       const int pxs = (ks * 2 + (ln >> 5)) ^ lds_swz<NP>(ln & 31);
       const piece_t* pa = ta + (wm * WTM + (ln & 31)) * NP + pxs;
@@ -444,6 +518,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    }  // native / x3
     cur = cur + 1 == NBUF ? 0 : cur + 1;
     nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
   }
@@ -502,6 +577,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   const T* res = reinterpret_cast<const T*>(ep.res);
   const T* gate = reinterpret_cast<const T*>(ep.res_gate);
   const T* ogate = reinterpret_cast<const T*>(ep.out_gate);
+  const float alpha = MM == MMA_F16X3 ? ep.alpha * (1.f / kX3WeightScale) : ep.alpha;
   float* stage = reinterpret_cast<float*>(&smem[0]);  // [64][SC] fp32 sub-block
   constexpr int SC = BN < 128 ? BN : 128;             // columns staged per round
   constexpr int CPR = SC / VEC;                       // output pieces per staged row
@@ -525,7 +601,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
               const float bias = (ep.bias && n0 + lc < g.N) ? ep.bias[n0 + lc] : 0.f;
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] * ep.alpha + bias;
+                float v = acc[i][j][r] * alpha + bias;
                 if (ep.relu & 1) v = fmaxf(v, 0.f);
                 s1[j] += v;
                 s2[j] += v * v;
@@ -660,6 +736,18 @@ inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const 
   RowDiv rd;
   rd.q = make_fastdiv(g.Q);
   rd.p = make_fastdiv(g.P);
+  if constexpr (sizeof(T) == 4 && NP % 4 == 0 && !ALLOW_SK && !SPL && ABL == 0 && TM * TN <= 4) {  // (launch_igemm_x3's configurations)
+    if (g.mma == MMA_F16X3) {
+      hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL, 0, MMA_F16X3>), dim3(gm * gn),
+                         dim3(WM * WN * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
+      return gm;
+    }
+    if (g.mma == MMA_BF16X3) {
+      hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL, 0, MMA_BF16X3>), dim3(gm * gn),
+                         dim3(WM * WN * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
+      return gm;
+    }
+  }
   if constexpr (UNI && ALLOW_SK) {
     if (sk_blocks > 0 && sk_blocks < gm * gn && ep.sk_ws && ep.sk_counters) {
       hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, true>), dim3(sk_blocks), dim3(WM * WN * 64), 0,
@@ -721,6 +809,22 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   static const int spl = getenv("MN_SPLIT_DMA") ? atoi(getenv("MN_SPLIT_DMA")) : 1;
   const bool wide_k = (g.C / VEC) % 8 == 0;  // 128-byte K-steps need taps that are a multiple of them
   int cfg = igemm_config();
+  if constexpr (sizeof(T) == 4) {
+    // x3 modes: 128-row tiles of 4 waves, two workgroups per CU (the split operands and the raw pieces need the 256
+    // registers that occupancy leaves a wave)
+    if (g.mma != MMA_NATIVE) {
+      if ((g.C / VEC) % 4 != 0) {
+        if (g.N <= 64) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);
+        return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);
+      }
+      if (g.N <= 64) {
+        if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
+        return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
+      }
+      if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
+      return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
+    }
+  }
   // channel counts that are not a multiple of the K-step (stem pixel pairs, odd test shapes): per-lane tap walk
   if ((g.C / VEC) % 4 != 0) {
     if (g.N <= 64) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);

@@ -487,11 +487,21 @@ struct Plan : PlanBase {
     u.gf = fwd_geom(B, Hin, Win, c, u.Hout, u.Wout);
     u.ldw = c.k * c.k * c.cin;
     u.dg = make_dgrad_geom(B, Hin, Win, c.cin, c.cout, c.k, c.stride, c.pad, u.Hout, u.Wout, VEC);
+    u.gf.mma = mma_fwd;
+    u.dg.full.mma = mma_bwd;
+    for (int i = 0; i < u.dg.n_pc; ++i) u.dg.pc[i].g.mma = mma_bwd;
   }
 
+  // MN_DTYPE_F32X3 (Plan<float> only): fp32 tensors, contractions on the f16 / bf16 matrix pipe with split operands
+  // (common.h MMA_*): forward f16x3, backward bf16x3; the fc / pose head stay on the exact fp32 MFMA
+  int mma_fwd = MMA_NATIVE, mma_bwd = MMA_NATIVE;
   Plan(const mn_config& c) {
     cfg = c;
     cur_scale = c.loss_scale;
+    if (c.dtype == MN_DTYPE_F32X3) {
+      mma_fwd = MMA_F16X3;
+      mma_bwd = MMA_BF16X3;
+    }
     overflow_guard = DT == MN_F16 && !(getenv("MN_OVERFLOW_GUARD") && atoi(getenv("MN_OVERFLOW_GUARD")) == 0);
     L = Layout(c.feat_dim);
     frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
@@ -511,6 +521,7 @@ struct Plan : PlanBase {
     g.B = B; g.Hi = Hp; g.Wi = Wp / 2; g.C = 8; g.P = H0; g.Q = W0; g.R = 7; g.S = 4;
     g.mul_p = 2; g.mul_q = 1; g.rsign = 1; g.ssign = 1; g.off_h = 0; g.off_w = 0; g.div = 1;
     g.M = B * H0 * W0; g.N = 64; g.K = 224;
+    g.mma = mma_fwd;
     stem.gf = g;
     stem.ldw = 147;
     H1 = (H0 + 2 - 3) / 2 + 1;
@@ -778,6 +789,7 @@ struct Plan : PlanBase {
   void conv_wgrad(Unit& u, const T* x, hipStream_t ws) {
     WgradArgs a;
     a.g = u.gf; a.dY = u.gy; a.ldy = u.cp.cout; a.X = x; a.dW = grads + u.cp.w; a.ldw = u.ldw; a.colmap = u.colmap;
+    a.g.mma = mma_bwd;
     a.alpha = 1.f / cur_scale; a.rows_per_split = 0;
     a.ws = wgf_ws; a.ws_floats = wgf_ws_floats;  // every weight-gradient launch of a step goes to the same stream (`ws`)
     a.det = deterministic;
@@ -1047,7 +1059,7 @@ struct mn_handle {
 static int validate(const mn_config* c) {
   if (!c) return fail("null config");
   if (c->mode < 0 || c->mode > 3) return fail("config: bad mode");
-  if (c->dtype != MN_DTYPE_F32 && c->dtype != MN_DTYPE_F16) return fail("config: bad dtype");
+  if (c->dtype != MN_DTYPE_F32 && c->dtype != MN_DTYPE_F16 && c->dtype != MN_DTYPE_F32X3) return fail("config: bad dtype");
   if (c->windows < 1 || c->T < 1 || c->T > kMaxT) return fail("config: windows >= 1 and 1 <= T <= 8 required");
   if (c->mode == MN_MODE_POSENET && c->T != 1) return fail("config: PoseNet mode requires T = 1");
   if (c->mode >= MN_MODE_MAPNET && c->T < 2) return fail("config: MapNet modes require T >= 2");

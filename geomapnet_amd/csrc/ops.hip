@@ -70,6 +70,7 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   Epilogue ep;
   ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
   ep.alpha = alpha;
+  if (dtype == MN_DTYPE_F32X3) g.mma = MMA_F16X3;  // fp32 tensors, f16 matrix pipe with split operands
   if (dtype == MN_F16)
     launch_igemm<half>(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, (const half*)zero_page);
   else
@@ -167,6 +168,7 @@ static int op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy
   int vec = dtype == MN_F16 ? 8 : 4;
   if (a.g.C % vec != 0 || a.g.N % vec != 0) return fail("wgrad: channel counts must be multiples of the piece");
   a.dY = dY; a.ldy = ldy; a.X = X; a.dW = dW; a.ldw = ldw; a.colmap = colmap; a.alpha = alpha; a.rows_per_split = 0;
+  if (dtype == MN_DTYPE_F32X3) a.g.mma = MMA_BF16X3;  // fp32 tensors, bf16 matrix pipe with split operands
   if (dtype == MN_F16)
     launch_wgrad<half>(a, target_blocks, (hipStream_t)stream, zero_page);
   else
@@ -246,6 +248,10 @@ extern "C" int mn_op_conv_dgrad(int dtype, int B, int Hin, int Win, int Cin, int
   Epilogue ep;
   ep.out = gx; ep.ldc = Cin; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = res; ep.res_gate = res_gate;
   ep.out_gate = out_gate; ep.alpha = 1.f;
+  if (dtype == MN_DTYPE_F32X3) {
+    d.full.mma = MMA_BF16X3;
+    for (int i = 0; i < d.n_pc; ++i) d.pc[i].g.mma = MMA_BF16X3;
+  }
   if (dtype == MN_F16)
     launch_conv_dgrad<half>(d, (const half*)gy, (const half*)wd, ep, (hipStream_t)stream, (const half*)zero_page, parity != 0);
   else

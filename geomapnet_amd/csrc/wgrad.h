@@ -39,7 +39,9 @@ struct WgradArgs {
   long split_stride = 0;
 };
 
-template <typename T, int BMO, int BNO>
+// MM (fp32 tensors): MMA_BF16X3 contracts on the bf16 matrix pipe, both operands split into hi + lo halves in registers
+// (common.h; g.mma selects it): a fragment is then 8 consecutive m of one channel instead of 4.
+template <typename T, int BMO, int BNO, int MM = MMA_NATIVE>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int BKM = 32;              // m rows per step
@@ -143,6 +145,40 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   for (int mt = m_begin; mt < m_end; mt += BKM) {
     const bool more = mt + BKM < m_end;
     if (more) load_tile(mt + BKM);
+    if constexpr (MM != MMA_NATIVE) {
+      static_assert(sizeof(T) == 4, "x3 modes: fp32 tensors");
+#pragma unroll
+      for (int kp = 0; kp < BKM / 16; ++kp) {
+        X3Frag<MM> xa[TM], xb[TN];
+        const int kb = kp * 16 + (lane >> 5) * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int col = wm * (BMO / 2) + i * 32 + (lane & 31);
+          PieceView<float> p0, p1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p0.e[e] = ldsY[cur][kb + e][col];
+            p1.e[e] = ldsY[cur][kb + 4 + e][col];
+          }
+          x3_split<MM>(p0, p1, 1.f, xa[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * (BNO / 2) + j * 32 + (lane & 31);
+          PieceView<float> p0, p1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p0.e[e] = ldsX[cur][kb + e][col];
+            p1.e[e] = ldsX[cur][kb + 4 + e][col];
+          }
+          x3_split<MM>(p0, p1, 1.f, xb[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) x3_mma<MM>(xa[i], xb[j], acc[i][j]);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < BKM / (2 * VEC); ++ks) {
       PieceView<T> fa[TM], fb[TN];
@@ -164,6 +200,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) mma_piece<T>(fa[i], fb[j], acc[i][j]);
     }
+    }  // native / x3
     if (more) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -625,7 +662,18 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
   }
   dim3 grid(cdiv(g.N, bmo), cdiv(g.K, bno), splits), block(256);
   static const bool use_dma = !(getenv("MN_WGRAD_DMA") && atoi(getenv("MN_WGRAD_DMA")) == 0);
-  if (use_dma && WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) {
+  if (sizeof(T) == 4 && g.mma == MMA_BF16X3) {
+    if constexpr (sizeof(T) == 4) {
+      if (bmo == 64 && bno == 64)
+        hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, MMA_BF16X3>), grid, block, 0, stream, a);
+      else if (bmo == 64)
+        hipLaunchKernelGGL((wgrad_kernel<T, 64, 128, MMA_BF16X3>), grid, block, 0, stream, a);
+      else if (bno == 64)
+        hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, MMA_BF16X3>), grid, block, 0, stream, a);
+      else
+        hipLaunchKernelGGL((wgrad_kernel<T, 128, 128, MMA_BF16X3>), grid, block, 0, stream, a);
+    }
+  } else if (use_dma && WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) {
   } else if (bmo == 64 && bno == 64)
     hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, block, 0, stream, a);
   else if (bmo == 64)

@@ -13,15 +13,18 @@ from . import _binding
 from ._binding import Config, MapNetHipError, ptr
 
 MODE_POSENET, MODE_MAPNET, MODE_ONLINE, MODE_GPS = 0, 1, 2, 3
-DTYPES = {"fp32": 0, "fp16": 1}
+# "fp32x3": fp32 tensors exactly as "fp32", every convolution contracted on the f16 / bf16 matrix pipe with operands
+# split into hi + lo halves in registers (three MFMAs per product; include/mapnet_hip.h MN_DTYPE_F32X3)
+DTYPES = {"fp32": 0, "fp16": 1, "fp32x3": 2}
 
 _default_dtype = "fp16"
 _default_loss_scale = 1024.0
 
 
 def set_compute_dtype(name, loss_scale=None):
-    """'fp16' (MFMA f16 operands, fp32 accumulate; the benchmark configuration) or 'fp32'
-    (v_mfma_f32_32x32x2_f32; the parity configuration)."""
+    """'fp16' (fp16 tensors, fp32 accumulate; the benchmark configuration), 'fp32x3' (fp32 tensors, split-operand
+    contractions on the f16 / bf16 matrix pipe: the parity configuration) or 'fp32' (fp32 tensors on
+    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain)."""
     global _default_dtype, _default_loss_scale
     if name not in DTYPES:
         raise ValueError(name)

@@ -28,7 +28,16 @@
 extern "C" {
 #endif
 
-enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1 };
+/* MN_DTYPE_F32:   fp32 tensors, contractions on v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain; 157 TF peak).
+ * MN_DTYPE_F16:   fp16 activations / gradients / conv operands, fp32 accumulate, fp32 master weights (the benchmark mode).
+ * MN_DTYPE_F32X3: fp32 tensors exactly as MN_DTYPE_F32, but every convolution contracts on the f16 / bf16 matrix pipe:
+ *                 each fp32 operand is split in registers into hi + lo halves and a product costs three
+ *                 v_mfma_f32_32x32x16_{f16,bf16} (fp16 halves in the forward pass, bf16 halves -- fp32's exponent range --
+ *                 in the backward pass).  fp32-class results (the reference computes in fp32, common/train.py:322-363)
+ *                 at several times the fp32 pipe's rate: the mode the parity bar is met in.  Operator entry points accept
+ *                 it where their dtype argument selects the arithmetic (mn_op_igemm, mn_op_wgrad, mn_op_conv_dgrad: 2 =
+ *                 f16x3 for igemm, bf16x3 for wgrad / dgrad; tensors are fp32). */
+enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1, MN_DTYPE_F32X3 = 2 };
 /* criterion / batch-layout modes */
 enum {
   MN_MODE_POSENET = 0,      /* PoseNetCriterion,        common/criterion.py:33-52   */

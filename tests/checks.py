@@ -14,9 +14,11 @@ import oracle
 from geomapnet_amd._binding import GatherGeom, ptr
 from geomapnet_amd.posenet import _view
 
-TD = {0: torch.float32, 1: torch.float16}
-# output rounding of the storage type relative to the largest output magnitude
-OUT_TOL = {0: 2e-5, 1: 2e-3}
+# dtype 2 = MN_DTYPE_F32X3: fp32 tensors, contraction on the f16 / bf16 matrix pipe with split (hi + lo) operands
+TD = {0: torch.float32, 1: torch.float16, 2: torch.float32}
+# output rounding of the storage type relative to the largest output magnitude (x3: 2^-22 per product with fp16 halves,
+# 2^-16 with the bf16 halves of the backward operators)
+OUT_TOL = {0: 2e-5, 1: 2e-3, 2: 5e-5}
 
 
 def f32(x):

@@ -243,6 +243,33 @@ inline emu_floatx16 __builtin_amdgcn_mfma_f32_32x32x16_f16(emu_half8 a, emu_half
   return c;
 }
 
+// v_mfma_f32_32x32x16_bf16: the same lane maps with bf16 operands
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+struct emu_mfma_slot_b {
+  emu_bf16x8 a, b;
+};
+inline emu_floatx16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_floatx16 c, int, int,
+                                                            int) {
+  int l = emu::cur->lane;
+  emu_mfma_slot_b s{a, b};
+  memcpy(emu::wave_slot(l), &s, sizeof(s));
+  emu::wave_sync();
+  int j = l & 31;
+  for (int reg = 0; reg < 16; ++reg) {
+    int i = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
+    float acc = c[reg];
+    for (int k = 0; k < 16; ++k) {
+      emu_mfma_slot_b sa, sb;
+      memcpy(&sa, emu::wave_slot(i + 32 * (k >> 3)), sizeof(sa));
+      memcpy(&sb, emu::wave_slot(j + 32 * (k >> 3)), sizeof(sb));
+      acc += (float)sa.a[k & 7] * (float)sb.b[k & 7];
+    }
+    c[reg] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
 // v_mfma_f32_16x16x32_f16: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15],
 // D: col=l&15, row=4*(l>>4)+reg
 inline emu_floatx4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu_half8 a, emu_half8 b, emu_floatx4 c, int, int, int) {

@@ -13,7 +13,7 @@ def lib():
     return emu_lib.load()
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1),     # layer1-like, BN=64 tile
     (2, 9, 11, 64, 128, 3, 2, 1),    # stride-2 3x3
@@ -35,7 +35,7 @@ def test_conv_stream_k(lib, dtype, shape, blocks):
     checks.check_conv_streamk(lib, DEV, dtype, *shape, blocks=blocks)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1),
     (2, 9, 11, 64, 128, 3, 2, 1),    # stride-2 data gradient (div = 2 gather)
@@ -46,7 +46,7 @@ def test_conv_data_gradient(lib, dtype, shape):
     checks.check_conv_dgrad(lib, DEV, dtype, *shape)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape,blocks", [
     ((2, 9, 11, 64, 64, 3, 1, 1), 8),
     ((3, 9, 11, 64, 128, 3, 2, 1), 8),
@@ -58,7 +58,7 @@ def test_conv_weight_gradient(lib, dtype, shape, blocks):
     checks.check_conv_wgrad(lib, DEV, dtype, *shape, target_blocks=blocks)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("hw", [(20, 27), (21, 26)])
 def test_stem_conv(lib, dtype, hw):
     checks.check_stem(lib, DEV, dtype, 2, *hw)
@@ -116,7 +116,7 @@ def test_pose_graph_properties(lib):
     checks.check_pgo_properties(lib, DEV, W=24, N=7, fc=True)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape,mode", [
     ((2, 8, 11, 64, 128, 3, 2, 1), "plain"),      # odd width: the parity classes have 6 and 5 columns
     ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"),   # odd height

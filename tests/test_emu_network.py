@@ -18,6 +18,12 @@ def test_mapnet_train_step_fp32_parity(lib):
     assert rep[0][2] < 1e-3
 
 
+def test_mapnet_train_step_fp32x3_parity(lib):
+    """fp32 tensors, f16x3 (forward) / bf16x3 (backward) split-operand contractions: held to the fp32 build's bar"""
+    rep = checks.check_train_step(lib, DEV, "fp32x3", mode="mapnet", N=2, H=64, W=85, steps=1)
+    assert rep[0][2] < 1e-3
+
+
 def test_eval_forward_fp32(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=2, H=40, W=53)
 

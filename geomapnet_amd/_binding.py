@@ -49,6 +49,7 @@ _PROTOS = {
     "mn_set_optim_method": (c_i, [c_void, c_i, c_i]),
     "mn_set_step_count": (c_i, [c_void, c_i64]),
     "mn_get_step_count": (c_i64, [c_void]),
+    "mn_stuck_overflow_steps": (c_i64, [c_void]),
     "mn_set_loss_host": (c_i, [c_void, c_void]),
     "mn_wait_loss": (c_i, [c_void]),
     "mn_set_loss_scale": (c_i, [c_void, c_f, c_i]),

@@ -78,6 +78,68 @@ union Half4View {
 // ---- fp32 -> (hi, lo) operand splits of the x3 matrix-core modes -----------------------------------------
 // x[0..7] * s = hi + lo.  fp16: hi = rn16(x s), lo = rn16(x s - hi) (the difference is exact in fp32): |x s - hi - lo| <=
 // 2^-22 |x s| while lo is a normal fp16 number, <= 2^-25 absolute below that.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MN_X3_ASM)
+// Hand-picked instructions: hipcc lowers the portable form below to ~5 VALU operations per element (v_cvt_f32_f16 +
+// v_sub_f32 + conversions; its SLP pass pairs the subtractions into v_pk_fma_f32 and with that loses the fused
+// conversions).  Here a pair of elements costs 3 (s = 1: v_cvt_pkrtz_f16_f32 for the hi halves -- round-toward-zero is as
+// good as any rounding, the residual below is exact either way -- and one v_fma_mix{lo,hi}_f16 per lo half, which
+// computes x - hi in fp32 and rounds it to fp16 in one operation) or 4 (s != 1: the hi halves by v_fma_mix as well).
+// The statements are volatile so that they stay in program order ahead of x3_fence() (below).
+// (v_fma_mixlo_f16 writes bits 15:0 of its destination and keeps 31:16, v_fma_mixhi_f16 the reverse: lo first, then hi.)
+__device__ __forceinline__ void split8_f16(const float (&x)[8], float s, half8& hi, half8& lo) {
+  union {
+    unsigned u[4];
+    half8 v;
+  } H, L;
+  // ONE statement per fragment (hipcc pads every asm statement boundary with an s_nop; VALU -> VALU dependences inside
+  // the string are interlocked by the hardware).  Outputs are early-clobber: they are written while inputs are still live.
+  if (s == 1.f) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) H.u[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * p], x[2 * p + 1]));
+    asm volatile(
+        "v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(L.u[0]), "=&v"(L.u[1]), "=&v"(L.u[2]), "=&v"(L.u[3])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(H.u[0]), "v"(H.u[1]),
+          "v"(H.u[2]), "v"(H.u[3]));
+  } else {
+    asm volatile(
+        "v_fma_mixlo_f16 %0, %8, %16, 0\n\t"
+        "v_fma_mixlo_f16 %1, %10, %16, 0\n\t"
+        "v_fma_mixlo_f16 %2, %12, %16, 0\n\t"
+        "v_fma_mixlo_f16 %3, %14, %16, 0\n\t"
+        "v_fma_mixhi_f16 %0, %9, %16, 0\n\t"
+        "v_fma_mixhi_f16 %1, %11, %16, 0\n\t"
+        "v_fma_mixhi_f16 %2, %13, %16, 0\n\t"
+        "v_fma_mixhi_f16 %3, %15, %16, 0\n\t"
+        "v_fma_mixlo_f16 %4, %8, %16, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %5, %10, %16, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %6, %12, %16, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %7, %14, %16, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %4, %9, %16, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %5, %11, %16, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %6, %13, %16, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %7, %15, %16, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(H.u[0]), "=&v"(H.u[1]), "=&v"(H.u[2]), "=&v"(H.u[3]), "=&v"(L.u[0]), "=&v"(L.u[1]), "=&v"(L.u[2]), "=&v"(L.u[3])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "s"(s));
+  }
+  hi = H.v;
+  lo = L.v;
+}
+// The MFMAs that consume split operands must not issue in the two wait states behind the VALU instruction that wrote
+// them; hipcc pads that hazard for instructions it knows, not for the inside of an asm statement.  Call once after the
+// last split of a group, before the first MFMA (the statements above are volatile: they stay ahead of this one).
+__device__ __forceinline__ void x3_fence() {
+  asm volatile("s_nop 1");
+  __builtin_amdgcn_sched_barrier(0);
+}
+#else
 __device__ __forceinline__ void split8_f16(const float (&x)[8], float s, half8& hi, half8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -87,6 +149,8 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], float s, half8& 
     lo[e] = (half)(v - (float)h);
   }
 }
+__device__ __forceinline__ void x3_fence() {}
+#endif
 // bf16: 8 + 8 significand bits, fp32's exponent range
 __device__ __forceinline__ void split8_bf16(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll

@@ -475,6 +475,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #pragma unroll
         for (int j = 0; j < TN; ++j) x3_split<MM>(rb[j][0], rb[j][1], kX3WeightScale, xb[j]);
         if (kp + 1 < NKP) load_raw(kp + 1);  // the raw registers are free again: next group's reads fly under these MFMAs
+        x3_fence();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

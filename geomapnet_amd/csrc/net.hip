@@ -238,6 +238,7 @@ struct PlanBase {
   }
   virtual void after_optim_host() = 0;
   virtual int sync_step_to_device(hipStream_t s) = 0;
+  virtual int64_t applied_steps() = 0;  // the device's count of optimiser steps that were applied (waits for the device)
   virtual int forward(const void* images, float* poses_out, int training, hipStream_t s) = 0;
   bool input_u8 = false;  // images are uint8 NHWC, normalised on the device (mn_set_input_u8)
   InputNorm input_norm{{1.f, 1.f, 1.f}, {0.f, 0.f, 0.f}};
@@ -255,22 +256,37 @@ struct PlanBase {
   // one or two steps late; until then the device keeps skipping, so no non-finite value reaches weights or moments.
   float cur_scale = 1.f;
   bool overflow_guard = false;
-  long long* overflow_host = nullptr;  // pinned: {last step skipped, skipped steps in total}
+  long long* overflow_host = nullptr;  // pinned: {last step skipped, skipped steps in total, last skipped attempt}
   long long skipped_seen = 0;
+  int64_t attempts = 0;           // optimiser steps enqueued on this plan (skipped ones included)
+  int64_t scale_set_at = 0;       // `attempts` when the loss scale last changed: later attempts ran under cur_scale
+  int64_t stuck_skips = 0;        // skips seen while the scale already was 1 (nothing left to lower)
   int clean_steps = 0;
   int scale_growth_interval = getenv("MN_SCALE_GROWTH") ? atoi(getenv("MN_SCALE_GROWTH")) : 2000;
   void poll_overflow() {
     if (!overflow_guard || !overflow_host) return;
     const long long seen = *(volatile long long*)(overflow_host + 1);
+    const long long last_bad = *(volatile long long*)(overflow_host + 2);
     if (seen > skipped_seen) {
-      for (long long i = skipped_seen; i < seen && cur_scale > 1.f; ++i) cur_scale *= 0.5f;
+      // The host reads the count one or two steps late, and the steps enqueued meanwhile overflow under the OLD scale too:
+      // a burst is ONE overflow event.  Halve once per burst -- i.e. only when a skipped step was enqueued after the
+      // scale last changed.
+      if (last_bad > scale_set_at) {
+        if (cur_scale > 1.f) {
+          cur_scale *= 0.5f;
+          scale_set_at = attempts;
+          hyper_version++;
+        } else {
+          stuck_skips += seen - skipped_seen;  // non-finite values that no loss scale can fix (inputs, forward pass)
+        }
+      }
       skipped_seen = seen;
       clean_steps = 0;
-      hyper_version++;
     } else if (scale_growth_interval > 0 && ++clean_steps >= scale_growth_interval) {
       clean_steps = 0;
       if (cur_scale < 65536.f) {
         cur_scale *= 2.f;
+        scale_set_at = attempts;
         hyper_version++;
       }
     }
@@ -563,11 +579,11 @@ struct Plan : PlanBase {
     hipStreamSynchronize(s);  // cm is a host temporary
     stem.colmap = stem_colmap;
     if (overflow_guard && !overflow_host) {
-      if (hipHostMalloc((void**)&overflow_host, 2 * sizeof(long long)) != hipSuccess) {
+      if (hipHostMalloc((void**)&overflow_host, 3 * sizeof(long long)) != hipSuccess) {
         overflow_host = nullptr;
         (void)hipGetLastError();
       } else {
-        overflow_host[0] = overflow_host[1] = 0;
+        overflow_host[0] = overflow_host[1] = overflow_host[2] = 0;
       }
     }
     build_repack_table(s);
@@ -944,8 +960,10 @@ struct Plan : PlanBase {
                          (const unsigned char*)pool_idx, (const T*)gp0, ga0, B, H0, W0, 64, H1, W1);
       bn_bwd(stem, ga0, a0, s, true);
     }
-    // the input gradient of the stem is not needed (nothing consumes it); last launch of the step: main stream
-    conv_wgrad(stem, xpad, s);
+    // The input gradient of the stem is not needed (nothing consumes it).  The weight gradient goes to the stream every
+    // other weight gradient of the step runs on: they share the partial-tile / split-slice workspace (wgf_ws), and the
+    // last layer1 launches forked a moment ago may still be using it (joined at the end of the stage).
+    conv_wgrad(stem, xpad, fork_wgrad(s));
   }
   int backward_stage(int stage, hipStream_t s) override {
     if (stage < 0 || stage > 3) return fail("backward_stage: stage must be 0..3");
@@ -1020,6 +1038,12 @@ struct Plan : PlanBase {
     hipStreamSynchronize(s);
     return check_launch("sync_step");
   }
+  int64_t applied_steps() override {
+    long long v = 0;
+    hipDeviceSynchronize();
+    if (hipMemcpy(&v, step_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
+  }
   int optim_step(float grad_mul, hipStream_t s) override {
     // squared gradient norm: for clip_grad_norm, and (fp16) as the overflow detector of this step
     if (max_grad_norm > 0.f || overflow_guard) {
@@ -1034,8 +1058,9 @@ struct Plan : PlanBase {
                            (double*)nullptr);
       }
     }
+    attempts += 1;
     hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, step_dev, beta1, beta2, bc_dev, (const double*)sqnorm,
-                       overflow_guard ? overflow_dev : (long long*)nullptr);
+                       overflow_guard ? overflow_dev : (long long*)nullptr, (long long)attempts);
     AdamArgs a;
     a.p = params; a.g = grads; a.m = m1; a.v = m2; a.n = L.param_floats; a.n_clip = L.model_floats; a.lr = lr; a.wd = wd;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
@@ -1045,7 +1070,7 @@ struct Plan : PlanBase {
     a.method = optim_method; a.nesterov = nesterov;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(L.param_floats)), dim3(256), 0, s, a);
     if (overflow_guard && overflow_host)
-      hipMemcpyAsync(overflow_host, overflow_dev, 2 * sizeof(long long), hipMemcpyDeviceToHost, s);
+      hipMemcpyAsync(overflow_host, overflow_dev, 3 * sizeof(long long), hipMemcpyDeviceToHost, s);
     return check_launch("optim_step");
   }
 };
@@ -1146,13 +1171,10 @@ extern "C" int mn_set_optim_method(mn_handle* h, int method, int nesterov) {
 }
 extern "C" int mn_set_step_count(mn_handle* h, int64_t step) {
   MN_H(h);
-  if (P.step != step) {
-    P.step = step;
-    return P.sync_step_to_device(nullptr);
-  }
-  return 0;
+  P.step = step;
+  return P.sync_step_to_device(nullptr);
 }
-extern "C" int64_t mn_get_step_count(mn_handle* h) { return (h && h->plan) ? h->plan->step : -1; }
+extern "C" int64_t mn_get_step_count(mn_handle* h) { return (h && h->plan) ? h->plan->applied_steps() : -1; }
 extern "C" int mn_set_loss_host(mn_handle* h, float* pinned_host) {
   MN_H(h);
   P.loss_host = pinned_host;
@@ -1181,12 +1203,14 @@ extern "C" int mn_get_loss_scale(mn_handle* h, float* scale, int64_t* skipped_st
   if (skipped_steps) *skipped_steps = P.overflow_host ? (int64_t) * (volatile long long*)(P.overflow_host + 1) : 0;
   return 0;
 }
+extern "C" int64_t mn_stuck_overflow_steps(mn_handle* h) { return (h && h->plan) ? h->plan->stuck_skips : -1; }
 extern "C" int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval) {
   MN_H(h);
   if (!(scale > 0.f)) return fail("mn_set_loss_scale: scale must be positive");
   if (P.cfg.dtype != MN_DTYPE_F16 && scale != 1.f) return fail("mn_set_loss_scale: fp32 plans do not scale the loss");
   if (P.cur_scale != scale) P.hyper_version++;
   P.cur_scale = scale;
+  P.scale_set_at = P.attempts;
   P.scale_growth_interval = growth_interval;
   P.clean_steps = 0;
   if (P.overflow_host) {  // skips of steps still in flight belong to the old scale: do not halve the new one for them

@@ -89,8 +89,10 @@ struct AdamArgs {
 // trains in fp32 and cannot overflow; with clipping on, inf * coef(=0) would even turn into NaN): overflow[0] = 1 tells
 // adam_kernel to return, the step counter is not advanced, and overflow[1] counts the skipped steps (the host halves
 // the loss scale when it sees the count move, net.hip).
+// `attempt`: the host's count of enqueued optimiser steps; overflow[2] remembers the last attempt that was skipped, so the
+// host can tell a skip of a step enqueued BEFORE it lowered the loss scale from one that happened under the new scale.
 static __global__ void adam_prep_kernel(long long* step, float beta1, float beta2, float* bc, const double* sqnorm,
-                                        long long* overflow) {
+                                        long long* overflow, long long attempt = 0) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     if (overflow) {
       const double v = *sqnorm;
@@ -98,6 +100,7 @@ static __global__ void adam_prep_kernel(long long* step, float beta1, float beta
       overflow[0] = bad ? 1 : 0;
       if (bad) {
         overflow[1] += 1;
+        overflow[2] = attempt;
         return;
       }
     }

@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
           }
           x3_split<MM>(p0, p1, 1.f, xb[j]);
         }
+        x3_fence();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -25,6 +25,27 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+# Measurement hook (bench.py): with profiling on, every staged step brackets its wait for the gradient all-reduces with two
+# timed events on the compute stream.  Their distance is the EXPOSED communication time of the step: how long the optimiser
+# was held back by collectives that backward did not hide (0 when every bucket had landed before the last stage ended).
+_profile = {"on": False, "pairs": []}
+
+
+def set_profiling(on):
+    _profile["on"] = bool(on)
+    _profile["pairs"] = []
+
+
+def exposed_comm_ms():
+    """-> list of exposed-communication times (ms), one per profiled step; synchronises the recorded events"""
+    out = []
+    for a, b in _profile["pairs"]:
+        b.synchronize()
+        out.append(a.elapsed_time(b))
+    _profile["pairs"] = []
+    return out
+
+
 def train_step(engine, plan, images, targets):
     import ctypes as C
     import contextlib
@@ -64,8 +85,15 @@ def _staged_step(engine, plan, images, targets, lib, h, s):
         # async: RCCL runs on its own stream, ordered after the kernels enqueued so far
         if multi:
             works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+    timed = _profile["on"] and s is not None
+    if timed:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     for w in works:
         w.wait()  # stream-level wait on CUDA/HIP; blocking on gloo
+    if timed:
+        ev[1].record()
+        _profile["pairs"].append(ev)
     lib.check(lib.optim_step(h, 1.0 / world_size(), s))
     engine._stepped(plan)
     # reported loss = mean of the rank losses (one scalar all-reduce)

@@ -74,7 +74,11 @@ class Engine:
         self.opt_state = None  # [3 * n_params] grads | exp_avg | exp_avg_sq, created on first train step
         self.plans = {}
         self.version = 0  # bumped whenever parameters change outside a plan
+        # Optimiser steps APPLIED (Adam's `step`).  The truth lives in the device counter of the plan that stepped last
+        # (`_step_owner`; an fp16 step skipped on overflow does not advance it); `step_count` is the host's view: exact
+        # after every read-back (effective_step, plan switch, drop_plans), otherwise it counts attempts.
         self.step_count = 0
+        self._step_owner = None
         self.dtype = None  # None -> module default at plan creation
         self.loss_scale = None
         self.eps_mode = 0
@@ -97,9 +101,32 @@ class Engine:
             self.opt_state = self.opt_state.to(new.device)
 
     def drop_plans(self):
+        self._read_step()
+        self._step_owner = None
         for p in self.plans.values():
             self.lib.destroy(p["handle"])
         self.plans = {}
+
+    def _read_step(self):
+        """host view := the owning plan's device counter (waits for the device)"""
+        if self._step_owner is not None:
+            v = int(self.lib.get_step_count(self._step_owner["handle"]))
+            if v >= 0:
+                self.step_count = v
+        return self.step_count
+
+    def set_step(self, step):
+        """a loaded optimiser state: `step` becomes the count every plan continues from"""
+        self.step_count = int(step)
+        self._step_owner = None
+
+    def _own_step(self, p):
+        """plan `p` is about to run: its device counter continues from the applied count, wherever that lives"""
+        if self._step_owner is p:
+            return
+        self._read_step()
+        self.lib.check(self.lib.set_step_count(p["handle"], self.step_count))
+        self._step_owner = p
 
     def __del__(self):
         try:
@@ -155,7 +182,7 @@ class Engine:
                 mean, std = ((C.c_float * 3)(*[float(v) for v in vals]) for vals in self.input_u8)
                 self.lib.check(self.lib.set_input_u8(p["handle"], 1, mean, std))
             p["input_u8"] = self.input_u8
-        self.lib.check(self.lib.set_step_count(p["handle"], self.step_count))
+        self._own_step(p)
         return p
 
     def params_touched(self):
@@ -176,8 +203,17 @@ class Engine:
         return scale, skipped
 
     def effective_step(self):
-        """optimiser steps actually applied (Adam's `step`): attempts minus the steps skipped on overflow"""
-        return self.step_count - self.loss_scale_state()[1] if self.plans else self.step_count
+        """optimiser steps actually applied (Adam's `step`; fp16 steps skipped on overflow are not steps): read back from
+        the device counter of the plan that stepped last"""
+        return self._read_step()
+
+    def check_overflow_progress(self, p, limit=8):
+        """fp16: steps that overflowed although the loss scale already was 1 cannot be fixed by scaling (a NaN input, a
+        forward pass that overflowed); the device skips them forever.  Raise instead of printing losses that train nothing."""
+        stuck = int(self.lib.stuck_overflow_steps(p["handle"]))
+        if stuck >= limit:
+            raise MapNetHipError("%d training steps were skipped with non-finite gradients at loss scale 1: the inputs or "
+                                 "the forward pass are not finite (fp16 range?); no parameter has been updated since" % stuck)
 
     def debug_tensor(self, plan, name):
         """a named activation / gradient of the plan's work arena as a tensor VIEW (tests, tools/layer_error.py)"""
@@ -283,5 +319,7 @@ class Engine:
 
     def _stepped(self, p):
         self.step_count += 1
+        if p.get("dtype") == "fp16" and self.step_count % 16 == 0:
+            self.check_overflow_progress(p)
         self.version += 1
         p["version"] = self.version  # this plan repacks by itself after its own optimiser step

@@ -28,7 +28,9 @@ class _FusedLearner:
             for k, v in self.defaults.items():
                 g.setdefault(k, v)
             self.param_groups.append(g)
-        hp = [tuple(repr(g[k]) for k in sorted(self.defaults)) for g in self.param_groups]
+        def norm(v):  # a config file / JSON gives betas as a list, the default is a tuple: the same hyper-parameter
+            return tuple(v) if isinstance(v, (list, tuple)) else v
+        hp = [tuple(repr(norm(g[k])) for k in sorted(self.defaults)) for g in self.param_groups]
         if len(set(hp)) > 1:
             raise NotImplementedError("the fused step applies one set of hyper-parameters to all groups, as the "
                                       "reference's scripts do (scripts/train.py:104-112)")
@@ -70,11 +72,13 @@ class _FusedLearner:
     def state_dict(self):
         state, groups, idx = {}, [], 0
         eng = self._engine
-        have = eng is not None and eng.opt_state is not None and eng.step_count > 0
+        # the optimiser's own count (torch keeps no state before the first APPLIED step: fp16 steps skipped on overflow are
+        # not steps), read back from the device
+        step = eng.effective_step() if eng is not None and eng.opt_state is not None else 0
+        have = step > 0
         # a state that was loaded but has not reached the device yet (the optimiser meets its engine in the first
         # step_feedfwd) is returned as loaded: save -> load -> save without a step in between keeps the moments
         pend = getattr(self, "_pending", None)
-        step = eng.effective_step() if have else 0  # the optimiser's own count: fp16 steps skipped on overflow are not steps
         keys = self._state_keys()
         for g in self.param_groups:
             ids = []
@@ -123,12 +127,12 @@ class _FusedLearner:
                 if st is not None:
                     views = self._moment_views(p)
                     for key, arena in keys:
-                        if key in st:
+                        if st.get(key) is not None:  # (torch's SGD stores momentum_buffer = None before a first gradient)
                             views[arena].copy_(st[key].to(views[arena].device).reshape(views[arena].shape))
                     # SGD keeps no step: a loaded momentum buffer means "not the first step"
                     step = max(step, int(st.get("step", 1 if st else 0)))
                 idx += 1
-        eng.step_count = step
+        eng.set_step(step)
         self._pending = None
 
     def _attach(self, engine):

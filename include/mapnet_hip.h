@@ -112,13 +112,15 @@ int mn_set_optim(mn_handle* h, float lr, float weight_decay, float beta1, float 
  * 2 = torch.optim.RMSprop (centered = False) -- beta1 is `momentum`, beta2 is `alpha`.  The momentum buffer lives in the
  * first moment arena (opt_state + param_floats), RMSprop's square average in the second. */
 int mn_set_optim_method(mn_handle* h, int method, int nesterov);
-int mn_set_step_count(mn_handle* h, int64_t step); /* Adam step counter (checkpoint resume) */
+int mn_set_step_count(mn_handle* h, int64_t step); /* Adam step counter (checkpoint resume): writes the device counter */
 /* Early read-back of the training loss (the reference's `loss.item()`, common/train.py:361): with a pinned host float
  * registered, every training step copies the loss there as soon as the criterion has run and records an event;
  * mn_wait_loss blocks on that event only (0 = *pinned_host holds this step's loss, 1 = nothing was posted -- read the
  * device scalar passed as loss_out instead), while backward and the optimiser of the same step are still running. */
 int mn_set_loss_host(mn_handle* h, float* pinned_host);
 int mn_wait_loss(mn_handle* h);
+/* optimiser steps APPLIED so far = the device-resident counter Adam's bias corrections use (steps skipped on an fp16
+ * overflow are not steps); synchronises the device */
 int64_t mn_get_step_count(mn_handle* h);
 
 /* replaces model(data_var) in step_feedfwd (common/train.py:343) = MapNet.forward / PoseNet.forward
@@ -162,6 +164,10 @@ int mn_optim_step(mn_handle* h, float grad_mul, void* stream);
  * count). */
 int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval);
 int mn_get_loss_scale(mn_handle* h, float* scale, int64_t* skipped_steps);
+/* Steps that were skipped although the loss scale already was 1 (as seen by the host so far): non-finite values no loss
+ * scale can remove -- a NaN input or a forward pass that overflowed.  Training makes no progress while this number grows;
+ * the Python mirror raises after a few of them (the reference, in fp32, would print NaN losses). */
+int64_t mn_stuck_overflow_steps(mn_handle* h);
 
 /* Inspection for parity tooling (tests/, tools/layer_error.py): device pointer, element count and MN_DTYPE_* of a named
  * tensor of the work arena as the last step left it.  Names: "xpad", "stem.y", "stem.gy", "p0", "gp0", "pooled", "feat",

@@ -709,7 +709,8 @@ def grad_views(net):
 
 
 def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps=1, max_grad_norm=0.0, lr=1e-4, wd=5e-4,
-                     loss_rtol=1e-4, pose_atol=1e-3, grad_l2_rtol=2e-2, gps=False, filter_nans=False, adam_eps=None):
+                     loss_rtol=1e-4, pose_atol=1e-3, grad_l2_rtol=2e-2, gps=False, filter_nans=False, adam_eps=None,
+                     pose_abs=None):
     """one (or more) full training steps, HIP library vs the oracle on identical inputs and weights.
     adam_eps: Adam's epsilon for both sides.  With the default 1e-8 the update m/(sqrt(v)+eps) is +-1 for every element
     however small its gradient, so last-bit differences of near-zero gradients move parameters by a full lr and later
@@ -754,6 +755,8 @@ def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps
         lt, pt = (loss_rtol, pose_atol) if step == 0 or adam_eps is not None else (max(loss_rtol, 5e-3), max(pose_atol, 2e-2))
         assert abs(l - lo) <= lt * max(1.0, abs(lo)), (step, l, lo)
         assert pose_err <= pt * max(1.0, po.abs().max().item()), (step, pose_err)
+        if step == 0 and pose_abs is not None:  # the north-star bar as written: max abs over all predicted components
+            assert pose_err <= pose_abs, (step, pose_err)
         if step == 0 and grad_l2_rtol is not None and max_grad_norm == 0.0:
             eng = (net.mapnet if hasattr(net, "mapnet") else net)._engine
             prefix = "mapnet." if hasattr(onet, "mapnet") else ""
@@ -1199,6 +1202,15 @@ def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3):
         assert eng.loss_scale_state() == (1024.0, 1 + more)
         assert not torch.equal(eng.params[:-4], p0[:-4]) and torch.isfinite(eng.params).all()
         assert int(opt.learner.state_dict()["state"][0]["step"]) == 1
+        # a second plan (another batch size, e.g. the last partial batch of an epoch) continues from the APPLIED count, not
+        # from the number of attempts: Adam's bias corrections and the checkpointed `step` stay in agreement
+        eng.loss_scale = 1024.0
+        x2, t2 = oracle.make_batch("mapnet", N + 1, H, W, seed=8)
+        G.step_feedfwd(x2.to(dev), net, dev != "cpu", t2.to(dev), c, opt, True)
+        dev_sync(dev)
+        assert len(eng.plans) == 2 and int(opt.learner.state_dict()["state"][0]["step"]) == 2
+        G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)  # ... and back on the first plan
+        assert int(opt.learner.state_dict()["state"][0]["step"]) == 3
     finally:
         G.set_compute_dtype("fp16", loss_scale=1024.0)
 
@@ -1251,12 +1263,22 @@ def check_deterministic(lib, dev, dtype_name, N=2, H=40, W=53, steps=3, max_grad
     return float((p0 - p1).abs().max())
 
 
-# ---- BASELINE full-size parity against the oracle (both dtypes) ---------------------------------------------------------
+# ---- BASELINE full-size parity against the oracle (all three modes) ----------------------------------------------------
+# What fp16 STORAGE costs at the 64-window shapes, i.e. the deviation of the oracle from itself when the tensors the fp16
+# build keeps in fp16 are rounded (profiles/r02/fp16_budget_cpu.txt: pose 1.29e-2 max; profiles/r03/
+# fp16_budget_backward_cpu.txt: gradients), and the largest values measured on MI355X over the three BASELINE shapes
+# (profiles/r02/parity_full_size.jsonl: loss 7.9e-4, pose 1.44e-2, gradients 0.158 overall / 0.389 worst tensor), x 1.5.
+FP16_ENVELOPE = {"loss_rel": 1.2e-3, "pose_abs_max": 2.2e-2, "grad_l2_rel_all": 0.25, "grad_l2_rel_worst_tensor": 0.6}
+
+
+
 def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, lr=1e-4, wd=5e-4, filter_nans=False,
                            fp32_loss_rtol=1e-4, fp32_pose_atol=1e-3):
-    """One training step of a BASELINE.json configuration at FULL size: oracle (CPU fp32) once, HIP in fp32 (asserted to
-    the north-star bar: 1e-4 on loss relative to max(1,|loss|), 1e-3 on pose) and in fp16 (recorded; asserted only to
-    stay within the documented envelope).  Returns the measurements."""
+    """One training step of a BASELINE.json configuration at FULL size: oracle (CPU fp32) once, then HIP in fp32x3 (the
+    parity mode on the f16 / bf16 matrix pipe) and fp32, both asserted to the north-star bar as written -- 1e-4 on loss
+    relative to max(1,|loss|), 1e-3 on pose (max abs) -- and in fp16, asserted to stay within 1.5x of what its storage
+    format costs the ORACLE (tools/fp16_budget.py, tools/fp16_budget_backward.py replay the oracle with fp16 rounding at
+    the build's storage points: FP16_ENVELOPE below).  Returns the measurements."""
     _fresh()
     import time
     import geomapnet_amd as G
@@ -1284,7 +1306,7 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
     rec = {"mode": mode, "windows": N, "images": N * frames, "H": H, "W": W, "oracle_step_s": round(oracle_s, 1),
            "loss_oracle": lo, "pose_scale": po.abs().max().item()}
     del omodel, oopt
-    for dtype_name in ("fp32", "fp16"):
+    for dtype_name in ("fp32x3", "fp32", "fp16"):
         G.set_compute_dtype(dtype_name)
         net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, filter_nans=filter_nans, _binding=lib))
         net.load_state_dict(sd0)
@@ -1322,9 +1344,16 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
                            "pose_abs_rms": d.pow(2).mean().sqrt().item(),
                            "grad_l2_rel_all": (num / den) ** 0.5 if den > 0 else None, "grad_l2_rel_worst_tensor": worst}
         del net, model, opt, c
-    assert rec["fp32"]["loss_rel"] <= fp32_loss_rtol, rec
-    assert rec["fp32"]["pose_abs_max"] <= fp32_pose_atol * max(1.0, rec["pose_scale"]), rec
-    assert rec["fp16"]["loss_rel"] <= 5e-3 and rec["fp16"]["pose_abs_max"] <= 5e-2 * max(1.0, rec["pose_scale"]), rec
+    for name in ("fp32x3", "fp32"):
+        assert rec[name]["loss_rel"] <= fp32_loss_rtol, (name, rec)
+        assert rec[name]["pose_abs_max"] <= fp32_pose_atol, (name, rec)
+        if rec[name]["grad_l2_rel_all"] is not None:  # (gate flips: DESIGN.md section 6)
+            assert rec[name]["grad_l2_rel_all"] <= 2e-2 and rec[name]["grad_l2_rel_worst_tensor"] <= 5e-2, (name, rec)
+    env = FP16_ENVELOPE
+    assert rec["fp16"]["loss_rel"] <= env["loss_rel"] and rec["fp16"]["pose_abs_max"] <= env["pose_abs_max"], rec
+    if rec["fp16"]["grad_l2_rel_all"] is not None:
+        assert rec["fp16"]["grad_l2_rel_all"] <= env["grad_l2_rel_all"], rec
+        assert rec["fp16"]["grad_l2_rel_worst_tensor"] <= env["grad_l2_rel_worst_tensor"], rec
     return rec
 
 

@@ -23,7 +23,7 @@ def lib():
     return b
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1), (2, 9, 11, 64, 128, 3, 2, 1), (1, 8, 10, 64, 128, 1, 2, 0), (3, 5, 6, 128, 192, 3, 1, 1),
     (2, 64, 86, 64, 64, 3, 1, 1),      # layer1 geometry at 256x341
@@ -34,7 +34,7 @@ def test_conv_forward(lib, dtype, shape):
     checks.check_conv_fwd(lib, DEV, dtype, *shape)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1), (2, 9, 11, 64, 128, 3, 2, 1), (2, 8, 10, 64, 128, 1, 2, 0), (2, 7, 9, 64, 128, 1, 2, 0),
     (2, 64, 86, 64, 128, 3, 2, 1), (2, 16, 22, 256, 512, 1, 2, 0), (4, 8, 11, 512, 512, 3, 1, 1),
@@ -83,7 +83,7 @@ def test_igemm_rt(lib, case):
     checks.check_igemm_rt(lib, DEV, B, H, W, Cin, Cout, dgrad=dgrad, mode=mode, stats=stats)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape,mode", [
     ((2, 8, 11, 64, 128, 3, 2, 1), "plain"), ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"), ((1, 8, 12, 64, 128, 3, 2, 1), "res_gate"),
     ((2, 8, 11, 64, 128, 1, 2, 0), "inplace"), ((2, 9, 11, 64, 64, 3, 1, 1), "out_gate"),
@@ -106,7 +106,7 @@ def test_conv_stream_k(lib, dtype, shape, blocks):
     checks.check_conv_streamk(lib, DEV, dtype, *shape, blocks=blocks)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape,blocks", [
     ((2, 9, 11, 64, 64, 3, 1, 1), 8), ((3, 9, 11, 64, 128, 3, 2, 1), 8), ((2, 8, 10, 64, 128, 1, 2, 0), 1),
     ((5, 5, 6, 128, 128, 3, 1, 1), 40), ((2, 64, 86, 64, 64, 3, 1, 1), 1024), ((4, 8, 11, 512, 512, 3, 1, 1), 1024),
@@ -125,7 +125,7 @@ def test_fused_weight_gradient_through_workspace(lib, shape):
     checks.check_conv_wgrad(lib, DEV, 1, *shape, ws=True)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("hw", [(20, 27), (21, 26), (256, 341)])
 def test_stem_conv(lib, dtype, hw):
     checks.check_stem(lib, DEV, dtype, 2, *hw)
@@ -187,7 +187,25 @@ def test_mapnet_train_step_fp32_parity_graph_replay(lib, monkeypatch):
 
 def test_mapnet_train_step_fp32_parity_full_resolution(lib):
     """(N=2, T=3, 3, 256, 341): north-star tolerances 1e-4 on loss (relative, |loss| > 1) and 1e-3 on pose"""
-    checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3)
+    checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3,
+                            pose_abs=1e-3)
+
+
+def test_mapnet_train_step_fp32x3_parity_full_resolution(lib):
+    """the parity mode on the fast matrix pipe (fp32 tensors, f16x3 forward / bf16x3 backward split-operand contractions):
+    north-star tolerances as written, 1e-4 on loss (relative, |loss| > 1) and 1e-3 on pose (max abs), gradients to the
+    fp32 build's 2e-2 per tensor"""
+    checks.check_train_step(lib, DEV, "fp32x3", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3,
+                            pose_abs=1e-3)
+
+
+def test_mapnet_train_step_fp32x3_two_steps_small(lib):
+    checks.check_train_step(lib, DEV, "fp32x3", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+
+
+def test_mapnet_online_train_step_fp32x3_parity_clip_and_nan_filter(lib):
+    checks.check_train_step(lib, DEV, "fp32x3", mode="mapnet++", N=2, H=64, W=85, steps=1, max_grad_norm=5.0, lr=1e-5, wd=0.0,
+                            filter_nans=True, grad_l2_rtol=None)
 
 
 def test_posenet_train_step_fp32_parity(lib):
@@ -423,42 +441,46 @@ def test_train_and_eval_command_lines(tmp_path):
     np.testing.assert_allclose(np.linalg.norm(pred[:, 3:], axis=1), 1.0, atol=1e-9)
 
 
-def _run_experimental(env):
-    """off-by-default kernel variants run in a process of their own (their knobs are read once).  They have been
-    parity-checked in the emulator but never on hardware: a failure here is reported as xfail with the output's tail --
-    it says the variant is not ready, not that the product path (the rest of this file) lost parity."""
+def _run_forced(env, default_path):
+    """kernel variants selected by knobs that are read once run in a process of their own.  default_path=True: the knobs
+    only pin what the product runs anyway (race screens of the default kernels at layer geometries) -- a failure FAILS the
+    suite.  default_path=False: an off-by-default variant, parity-checked in the emulator; a failure is reported as xfail
+    with the output's tail: the variant is not ready, the product path (the rest of this file) has not lost parity."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     knobs = {k: v for k, v in env.items() if k.startswith("MN_")}
+    report = pytest.fail if default_path else pytest.xfail
     try:
         r = subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "hip"], env=env, timeout=300,
                            capture_output=True, text=True)
     except subprocess.TimeoutExpired:
-        pytest.xfail("experimental variant %s did not finish in 300 s" % knobs)
+        report("kernel variant %s did not finish in 300 s" % knobs)
     if r.returncode != 0:
-        pytest.xfail("experimental variant %s failed on the GPU:\n%s" % (knobs, (r.stdout + r.stderr)[-1500:]))
+        report("kernel variant %s failed on the GPU:\n%s" % (knobs, (r.stdout + r.stderr)[-1500:]))
 
 
 def test_weight_gradient_with_assembly_transpose_reads():
     """the plain-GEMM fp16 weight-gradient kernel (MN_WGRAD_FUSED=0 routes the 3x3 layers to it) with its transpose reads
     issued from inline assembly and hand-placed waits, against torch fp64 at small and layer-sized shapes, repeated."""
-    for variant in ("1", "0"):  # 32-row steps (default) and 64-row steps
-        _run_experimental(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT=variant, MN_WGRAD_FUSED="0"))
+    # 32-row steps: what the stride-2 / 1x1 layers run by default; 64-row steps: an off-by-default variant
+    _run_forced(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT="1", MN_WGRAD_FUSED="0"), True)
+    _run_forced(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT="0", MN_WGRAD_FUSED="0"), False)
 
 
 def test_fused_weight_gradient_race_screen():
     """wgrad_fused.h (default for the 3x3 stride-1 layers) at layer geometries with hundreds of concurrent workgroups,
     repeated, in a process of its own"""
-    _run_experimental(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_FUSED="1"))
+    _run_forced(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_FUSED="1"), True)
 
 
-def test_experimental_chunk_resident_a_kernel():
-    """MN_IGEMM_HALO=1|2 (2 is the default since round 2): igemm_halo.h against torch fp64, plus layer2-4 geometries repeated."""
-    _run_experimental(dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1"))  # the 256-column shape (layer3)
+def test_chunk_resident_a_kernel_race_screen():
+    """igemm_halo.h (the default for the 3x3 stride-1 convolutions of layers 2-4) against torch fp64, plus layer2-4
+    geometries repeated, in a process of its own: both tile shapes"""
+    _run_forced(dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1"), True)  # the 256-column shape (layer3)
     env = dict(os.environ, MN_IGEMM_HALO="2")                                     # the 128-column shape (layers 2 and 4)
     env.pop("MN_IGEMM_CONFIG", None)
-    _run_experimental(env)
+    _run_forced(env, True)
 
 
 @pytest.mark.parametrize("dtype_name", ["fp16", "fp32"])

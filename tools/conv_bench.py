@@ -1,5 +1,5 @@
 """GPU micro-benchmark of the conv MFMA kernels at the BASELINE layer shapes (B=192, fp16 by default).
-usage: python tools/conv_bench.py [fp16|fp32] [B]"""
+usage: python tools/conv_bench.py [fp16|fp32|fp32x3] [B]"""
 import ctypes as C
 import os
 import sys
@@ -15,7 +15,7 @@ from geomapnet_amd._binding import ptr  # noqa: E402
 
 # MN_LIB: an alternative build of the library (the ablation build, `make -C geomapnet_amd/csrc ablation`)
 lib = _binding.Binding(C.CDLL(os.environ["MN_LIB"])) if os.environ.get("MN_LIB") else _binding.hip()
-dtype = 1 if (len(sys.argv) < 2 or sys.argv[1] == "fp16") else 0
+dtype = {"fp16": 1, "fp32": 0, "fp32x3": 2}[sys.argv[1] if len(sys.argv) > 1 else "fp16"]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 td = checks.TD[dtype]
 one = C.c_float(1.0)
@@ -80,7 +80,7 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
           % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, io / t_f / 1e6, t_d, flops / t_d / 1e6, t_r, t_w, flops / t_w / 1e6), flush=True)
 
 
-print("dtype", "fp16" if dtype else "fp32", "B", B)
+print("dtype", {1: "fp16", 0: "fp32", 2: "fp32x3 (fp32 tensors, f16x3 igemm / bf16x3 wgrad)"}[dtype], "B", B)
 WS = torch.empty(int(lib.op_wgrad_ws_floats()), device="cuda")
 ONLY_GEMM = os.environ.get("CB_ONLY") == "gemm"
 if ONLY_GEMM:

@@ -143,6 +143,13 @@ def hip():
     """The product binding: libmapnet_hip.so or an exception."""
     global _hip
     if _hip is None:
+        alt = os.environ.get("MN_LIB")  # measurement builds of the SAME library (tools/ablation/*.so); must be a hip backend
+        if alt:
+            import torch  # noqa: F401
+            _hip = Binding(C.CDLL(alt))
+            if _hip.backend_name != "hip":
+                raise MapNetHipError("unexpected backend %r in %s" % (_hip.backend_name, alt))
+            return _hip
         if not os.path.isfile(LIB_PATH):
             raise MapNetHipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                  "(make -C geomapnet_amd/csrc); there is no CPU fallback" % LIB_PATH)

@@ -27,12 +27,12 @@ enum { MN_F32 = 0, MN_F16 = 1 };
 //   MMA_NATIVE  v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain (157 TF peak)
 //   MMA_F16X3   every fp32 operand is split in registers into hi + lo fp16 halves (x*s = hi + lo to ~2^-22) and a product
 //               costs three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): fp32-class results on the
-//               2.5 PF pipe.  Used for the forward pass (operands are O(1): activations and weights, the latter pre-scaled
-//               by kX3WeightScale so that their lo halves stay normal fp16 numbers).
+//               2.5 PF pipe.  Used for the forward pass (operands are O(1): activations and weights; the lo halves of small
+//               values are subnormal fp16 numbers, which v_mfma_f32_32x32x16_f16 honours -- measured,
+//               tools/probes/mfma_denorm_probe.hip -- so their absolute error stays below 2^-25).
 //   MMA_BF16X3  the same with bf16 halves (x = hi + lo to ~2^-16, fp32's exponent range: no scaling, nothing can over- or
 //               underflow).  Used for the backward pass, whose operands (activation gradients) span many binades.
 enum { MMA_NATIVE = 0, MMA_F16X3 = 1, MMA_BF16X3 = 2 };
-constexpr float kX3WeightScale = 256.f;
 
 template <typename T>
 struct ElemTraits;
@@ -76,59 +76,38 @@ union Half4View {
 };
 
 // ---- fp32 -> (hi, lo) operand splits of the x3 matrix-core modes -----------------------------------------
-// x[0..7] * s = hi + lo.  fp16: hi = rn16(x s), lo = rn16(x s - hi) (the difference is exact in fp32): |x s - hi - lo| <=
-// 2^-22 |x s| while lo is a normal fp16 number, <= 2^-25 absolute below that.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(MN_X3_ASM)
-// Hand-picked instructions: hipcc lowers the portable form below to ~5 VALU operations per element (v_cvt_f32_f16 +
+// x[0..7] = hi + lo.  fp16: hi = rn16(x), lo = rn16(x - hi) (the difference is exact in fp32): |x - hi - lo| <= 2^-22 |x|
+// while lo is a normal fp16 number, <= 2^-25 absolute below that.
+#if defined(__HIP_DEVICE_COMPILE__)  // (the emulator build and hipcc's host pass take the portable form below)
+// Hand-picked instructions (measured on MI355X, round 3: whole fp32x3 step 43.3 -> 42.1 ms, layer3 forward 340 -> 313 us):
+// hipcc lowers the portable form below to ~5 VALU operations per element (v_cvt_f32_f16 +
 // v_sub_f32 + conversions; its SLP pass pairs the subtractions into v_pk_fma_f32 and with that loses the fused
-// conversions).  Here a pair of elements costs 3 (s = 1: v_cvt_pkrtz_f16_f32 for the hi halves -- round-toward-zero is as
-// good as any rounding, the residual below is exact either way -- and one v_fma_mix{lo,hi}_f16 per lo half, which
-// computes x - hi in fp32 and rounds it to fp16 in one operation) or 4 (s != 1: the hi halves by v_fma_mix as well).
+// conversions).  Here a pair of elements costs 3: v_cvt_pkrtz_f16_f32 for the hi halves -- round-toward-zero is as good as
+// any rounding, the residual below is exact either way -- and one v_fma_mix{lo,hi}_f16 per lo half, which computes
+// x - hi in fp32 and rounds it to fp16 in one operation.
 // The statements are volatile so that they stay in program order ahead of x3_fence() (below).
 // (v_fma_mixlo_f16 writes bits 15:0 of its destination and keeps 31:16, v_fma_mixhi_f16 the reverse: lo first, then hi.)
-__device__ __forceinline__ void split8_f16(const float (&x)[8], float s, half8& hi, half8& lo) {
+__device__ __forceinline__ void split8_f16(const float (&x)[8], half8& hi, half8& lo) {
   union {
     unsigned u[4];
     half8 v;
   } H, L;
   // ONE statement per fragment (hipcc pads every asm statement boundary with an s_nop; VALU -> VALU dependences inside
   // the string are interlocked by the hardware).  Outputs are early-clobber: they are written while inputs are still live.
-  if (s == 1.f) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) H.u[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * p], x[2 * p + 1]));
-    asm volatile(
-        "v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(L.u[0]), "=&v"(L.u[1]), "=&v"(L.u[2]), "=&v"(L.u[3])
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(H.u[0]), "v"(H.u[1]),
-          "v"(H.u[2]), "v"(H.u[3]));
-  } else {
-    asm volatile(
-        "v_fma_mixlo_f16 %0, %8, %16, 0\n\t"
-        "v_fma_mixlo_f16 %1, %10, %16, 0\n\t"
-        "v_fma_mixlo_f16 %2, %12, %16, 0\n\t"
-        "v_fma_mixlo_f16 %3, %14, %16, 0\n\t"
-        "v_fma_mixhi_f16 %0, %9, %16, 0\n\t"
-        "v_fma_mixhi_f16 %1, %11, %16, 0\n\t"
-        "v_fma_mixhi_f16 %2, %13, %16, 0\n\t"
-        "v_fma_mixhi_f16 %3, %15, %16, 0\n\t"
-        "v_fma_mixlo_f16 %4, %8, %16, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %5, %10, %16, -%1 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %6, %12, %16, -%2 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %7, %14, %16, -%3 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %4, %9, %16, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %5, %11, %16, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %6, %13, %16, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %7, %15, %16, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(H.u[0]), "=&v"(H.u[1]), "=&v"(H.u[2]), "=&v"(H.u[3]), "=&v"(L.u[0]), "=&v"(L.u[1]), "=&v"(L.u[2]), "=&v"(L.u[3])
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "s"(s));
-  }
+  for (int p = 0; p < 4; ++p) H.u[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * p], x[2 * p + 1]));
+  asm volatile(
+      "v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(L.u[0]), "=&v"(L.u[1]), "=&v"(L.u[2]), "=&v"(L.u[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(H.u[0]), "v"(H.u[1]),
+        "v"(H.u[2]), "v"(H.u[3]));
   hi = H.v;
   lo = L.v;
 }
@@ -140,13 +119,12 @@ __device__ __forceinline__ void x3_fence() {
   __builtin_amdgcn_sched_barrier(0);
 }
 #else
-__device__ __forceinline__ void split8_f16(const float (&x)[8], float s, half8& hi, half8& lo) {
+__device__ __forceinline__ void split8_f16(const float (&x)[8], half8& hi, half8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float v = x[e] * s;
-    const half h = (half)v;
+    const half h = (half)x[e];
     hi[e] = h;
-    lo[e] = (half)(v - (float)h);
+    lo[e] = (half)(x[e] - (float)h);
   }
 }
 __device__ __forceinline__ void x3_fence() {}

@@ -192,27 +192,43 @@ static __global__ void __launch_bounds__(256) bn_finalize_fwd_kernel(const doubl
   }
 }
 
-// out = [relu]( y * scale[c] + shift[c] [+ res] ), one 16-byte piece per lane
+// out = [relu]( y * scale[c] + shift[c] [+ res] ), one 16-byte piece per lane.
+// A thread's channel piece is the same in every iteration of the grid-stride loop (the stride, gridDim.x * 256, is a
+// multiple of the C / VEC pieces of a row, a power of two <= 256), so its VEC coefficient sets live in REGISTERS.  They
+// get there through a per-workgroup LDS table laid out [e][piece]: the workgroup builds it cooperatively (a channel's
+// coefficients are loaded from memory once per workgroup) and every lane then fetches its own VEC entries with reads whose
+// addresses are consecutive across lanes -- no bank conflicts.
+// (Rounds 1-2 indexed LDS arrays [c0 + e] inside the loop: lanes 8 channels apart hit the same 4 banks, an up to 8-way
+// conflict on every one of 16 (forward) / 48 (backward) ds_read_b32 per piece.  A first round-3 form loaded the
+// coefficients straight from memory into registers: 40 loads per thread in front of 1-8 loop iterations -- the backward
+// apply went from 44 to 81 us.)
 template <typename T>
 static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ coef,
                                                         const T* __restrict__ res, T* __restrict__ out, long npieces,
                                                         int C, int relu) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  __shared__ float s_scale[512], s_shift[512];
+  const int cpr = C / VEC;
+  __shared__ floatx2 tab[512];  // [e][piece] -> (scale, shift)
   for (int c = threadIdx.x; c < C; c += 256) {
-    s_scale[c] = coef[c];
-    s_shift[c] = coef[C + c];
+    const floatx2 v = {coef[c], coef[C + c]};
+    tab[(c % VEC) * cpr + c / VEC] = v;
   }
   __syncthreads();
-  const int cpr = C / VEC;
+  const int cp = (int)(threadIdx.x % cpr);  // (blockIdx.x * 256 is a multiple of cpr)
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const floatx2 v = tab[e * cpr + cp];
+    sc[e] = v[0];
+    sh[e] = v[1];
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
-    int c0 = (int)(i % cpr) * VEC;
     PieceView<T> v, r, o;
     v.p = reinterpret_cast<const piece_t*>(y)[i];
     if (res) r.p = reinterpret_cast<const piece_t*>(res)[i];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float f = (float)v.e[e] * s_scale[c0 + e] + s_shift[c0 + e];
+      float f = (float)v.e[e] * sc[e] + sh[e];
       if (res) f += (float)r.e[e];
       if (relu) f = fmaxf(f, 0.f);
       o.e[e] = (T)f;
@@ -229,13 +245,23 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __
                                                                T* __restrict__ out, unsigned char* __restrict__ idx, int B,
                                                                int H, int W, int C, int Po, int Qo) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  __shared__ float s_scale[512], s_shift[512];
-  for (int c = threadIdx.x; c < C; c += 256) {
-    s_scale[c] = coef[c];
-    s_shift[c] = coef[C + c];
-  }
-  __syncthreads();
   const int cpr = C / VEC;
+  float s_scale[VEC], s_shift[VEC];  // this thread's channel piece is loop invariant (see bn_apply_kernel)
+  {
+    __shared__ floatx2 tab[512];  // [e][piece] -> (scale, shift)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const floatx2 v = {coef[c], coef[C + c]};
+      tab[(c % VEC) * cpr + c / VEC] = v;
+    }
+    __syncthreads();
+    const int cp = (int)(threadIdx.x % cpr);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const floatx2 v = tab[e * cpr + cp];
+      s_scale[e] = v[0];
+      s_shift[e] = v[1];
+    }
+  }
   const long total = (long)B * Po * Qo * cpr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cp = (int)(i % cpr);
@@ -244,7 +270,6 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __
     tmp /= Qo;
     const int po = (int)(tmp % Po);
     const int b = (int)(tmp / Po);
-    const int c0 = cp * VEC;
     float best[VEC];
     unsigned char arg[VEC];
 #pragma unroll
@@ -264,7 +289,7 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __
         v.p = reinterpret_cast<const piece_t*>(y)[((long)(b * H + h) * W + w) * cpr + cp];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          float f = fmaxf((float)v.e[e] * s_scale[c0 + e] + s_shift[c0 + e], 0.f);
+          float f = fmaxf((float)v.e[e] * s_scale[e] + s_shift[e], 0.f);
           f = (float)(T)f;
           if (f > best[e]) {  // strict: the first maximum wins
             best[e] = f;
@@ -409,23 +434,38 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
                                                             T* __restrict__ gy, long npieces, int C, int self_gate,
                                                             PoolGradSrc pg, int reverse) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  __shared__ float s_k1[512], s_mg[512], s_mgx[512], s_mean[512], s_is[512], s_sh[512];
   const bool sg_beta = self_gate != 0;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    s_k1[c] = coef[c];
-    s_mg[c] = coef[C + c];
-    s_mgx[c] = coef[2 * C + c];
-    s_sh[c] = sg_beta ? coef[3 * C + c] : 0.f;
-    s_mean[c] = mean[c];
-    s_is[c] = invstd[c];
-  }
-  __syncthreads();
   const int cpr = C / VEC;
+  // gy = k1 (gm - mg - xhat mgx), xhat = (y - mean) invstd, as  k1 gm + kb (y - mean) + kd  with per-channel coefficients
+  // in registers (this thread's channel piece is loop invariant, forward or reverse walk: see bn_apply_kernel)
+  float k1[VEC], kb[VEC], kd[VEC], mu[VEC], sh[VEC];
+  {
+    __shared__ floatx4 tab[512];  // [e][piece] -> (k1, kb, kd, mean)
+    __shared__ float tab_sh[512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float a = coef[c];
+      const floatx4 v = {a, -a * coef[2 * C + c] * invstd[c], -a * coef[C + c], mean[c]};
+      const int at = (c % VEC) * cpr + c / VEC;
+      tab[at] = v;
+      tab_sh[at] = sg_beta ? coef[3 * C + c] : 0.f;
+    }
+    __syncthreads();
+    const long first = reverse ? npieces - 1 - ((long)blockIdx.x * blockDim.x + threadIdx.x) : (long)threadIdx.x;
+    const int cp = (int)(((first % cpr) + cpr) % cpr);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const floatx4 v = tab[e * cpr + cp];
+      k1[e] = v[0];
+      kb[e] = v[1];
+      kd[e] = v[2];
+      mu[e] = v[3];
+      sh[e] = tab_sh[e * cpr + cp];
+    }
+  }
   // reverse: walk the tensor back to front -- the reduction pass that ran just before read g and y front to back, so
   // their tails are what the L2s / Infinity Cache still hold
   for (long i_ = (long)blockIdx.x * blockDim.x + threadIdx.x; i_ < npieces; i_ += (long)gridDim.x * blockDim.x) {
     const long i = reverse ? npieces - 1 - i_ : i_;
-    int c0 = (int)(i % cpr) * VEC;
     PieceView<T> vg, vy, vm, o;
     if constexpr (POOL) {
       float a[VEC];
@@ -443,12 +483,10 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
     if (gate) vm.p = reinterpret_cast<const piece_t*>(gate)[i];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      int c = c0 + e;
       float gv = (float)vg.e[e];
       if (gate && !((float)vm.e[e] > 0.f)) gv = 0.f;
-      if (sg_beta && !((float)vy.e[e] * s_k1[c] + s_sh[c] > 0.f)) gv = 0.f;  // self gate (see the reduce kernel)
-      float xh = ((float)vy.e[e] - s_mean[c]) * s_is[c];
-      o.e[e] = (T)(s_k1[c] * (gv - s_mg[c] - xh * s_mgx[c]));
+      if (sg_beta && !((float)vy.e[e] * k1[e] + sh[e] > 0.f)) gv = 0.f;  // self gate (see the reduce kernel)
+      o.e[e] = (T)(k1[e] * gv + (kb[e] * ((float)vy.e[e] - mu[e]) + kd[e]));
     }
     reinterpret_cast<piece_t*>(gy)[i] = o.p;
   }

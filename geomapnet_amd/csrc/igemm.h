@@ -129,10 +129,10 @@ struct X3Frag<MMA_BF16X3> {
   bf16x8 hi, lo;
 };
 template <int MM>
-__device__ __forceinline__ void x3_split(const PieceView<float>& p0, const PieceView<float>& p1, float s, X3Frag<MM>& f) {
+__device__ __forceinline__ void x3_split(const PieceView<float>& p0, const PieceView<float>& p1, X3Frag<MM>& f) {
   const float x[8] = {p0.e[0], p0.e[1], p0.e[2], p0.e[3], p1.e[0], p1.e[1], p1.e[2], p1.e[3]};
   if constexpr (MM == MMA_F16X3)
-    split8_f16(x, s, f.hi, f.lo);
+    split8_f16(x, f.hi, f.lo);
   else
     split8_bf16(x, f.hi, f.lo);
 }
@@ -208,7 +208,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // MM (fp32 tensors only): MMA_F16X3 / MMA_BF16X3 run the contraction on the f16 / bf16 matrix pipe with every operand split
 // into hi + lo halves after its LDS read, three MFMAs per product (common.h): the K-step's pieces are consumed in groups
 // of four (16 k: lanes 0-31 take pieces 4 kp, 4 kp + 1, lanes 32-63 pieces 4 kp + 2, 4 kp + 3 -- any k order is valid as
-// long as A and B agree).  In MMA_F16X3 the B operand (the weights) is pre-scaled by kX3WeightScale, divided out of alpha.
+// long as A and B agree).
 template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SK = false, bool SPL = false,
           int ABL = 0, int MM = MMA_NATIVE>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
@@ -471,9 +471,9 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
       for (int kp = 0; kp < NKP; ++kp) {
         X3Frag<MM> xa[TM], xb[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) x3_split<MM>(ra[i][0], ra[i][1], 1.f, xa[i]);
+        for (int i = 0; i < TM; ++i) x3_split<MM>(ra[i][0], ra[i][1], xa[i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) x3_split<MM>(rb[j][0], rb[j][1], kX3WeightScale, xb[j]);
+        for (int j = 0; j < TN; ++j) x3_split<MM>(rb[j][0], rb[j][1], xb[j]);
         if (kp + 1 < NKP) load_raw(kp + 1);  // the raw registers are free again: next group's reads fly under these MFMAs
         x3_fence();
 #pragma unroll
@@ -578,7 +578,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   const T* res = reinterpret_cast<const T*>(ep.res);
   const T* gate = reinterpret_cast<const T*>(ep.res_gate);
   const T* ogate = reinterpret_cast<const T*>(ep.out_gate);
-  const float alpha = MM == MMA_F16X3 ? ep.alpha * (1.f / kX3WeightScale) : ep.alpha;
+  const float alpha = ep.alpha;
   float* stage = reinterpret_cast<float*>(&smem[0]);  // [64][SC] fp32 sub-block
   constexpr int SC = BN < 128 ? BN : 128;             // columns staged per round
   constexpr int CPR = SC / VEC;                       // output pieces per staged row
@@ -737,7 +737,7 @@ inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const 
   RowDiv rd;
   rd.q = make_fastdiv(g.Q);
   rd.p = make_fastdiv(g.P);
-  if constexpr (sizeof(T) == 4 && NP % 4 == 0 && !ALLOW_SK && !SPL && ABL == 0 && TM * TN <= 4) {  // (launch_igemm_x3's configurations)
+  if constexpr (sizeof(T) == 4 && NP % 4 == 0 && !ALLOW_SK && !SPL && ABL == 0 && WM == 2 && WN == 2 && TN <= 2) {  // (launch_igemm_x3's configurations)
     if (g.mma == MMA_F16X3) {
       hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL, 0, MMA_F16X3>), dim3(gm * gn),
                          dim3(WM * WN * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
@@ -814,6 +814,13 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
     // x3 modes: 128-row tiles of 4 waves, two workgroups per CU (the split operands and the raw pieces need the 256
     // registers that occupancy leaves a wave)
     if (g.mma != MMA_NATIVE) {
+      // ... except where 128x128 tiles leave a few tiles over one round of the 512 resident workgroups (layer4 at 192
+      // images: 528 tiles): 256x128 tiles of 128x64 wave tiles put every tile in one round (367 -> 314 us forward,
+      // 364 -> 308 us data gradient).  Measured and not kept (round 3, tools/conv_bench.py fp32x3): 64-byte K-steps with a
+      // 4-deep ring (layer3 313 -> 354 us), the 256x128 tile everywhere (layer3 313 -> 369 us).
+      const long x3_tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+      if ((g.C / VEC) % 4 == 0 && g.N % 128 == 0 && x3_tiles128 > 512 && x3_tiles128 <= 640)
+        return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);
       if ((g.C / VEC) % 4 != 0) {
         if (g.N <= 64) return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);
         return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2, false>(g, A, Bw, ep, stream, zero_page);

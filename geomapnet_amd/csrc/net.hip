@@ -361,7 +361,8 @@ struct Plan : PlanBase {
   double* acc_region = nullptr;
   size_t acc_bytes = 0;
   int cur_training = 1;
-  double* sqnorm;
+  double* sqnorm;             // squared gradient norm: the first double of acc_region
+  bool sqnorm_clean = false;  // zeroed by this step's fill and not yet accumulated into
   static constexpr int kSqPartials = 8192;
   double* sq_partials = nullptr;  // MN_DETERMINISTIC: per-workgroup sums of the gradient norm
   unsigned char* frozen;
@@ -409,9 +410,12 @@ struct Plan : PlanBase {
       acc_doubles += (size_t)(blk.u1.rows_f + blk.u1.rows_b + blk.u2.rows_f + blk.u2.rows_b) * 2 * blk.u1.cp.cout;
       if (blk.down) acc_doubles += (size_t)(blk.ud.rows_f + blk.ud.rows_b) * 2 * blk.ud.cp.cout;
     }
-    acc_bytes = acc_doubles * 8;
+    // ... and the squared gradient norm rides at its head: ONE fill launch per step clears all of it (hipMemsetAsync's fill
+    // kernel took ~110 us per call for these 2 MB, on the main stream at the head of every step; round-3 profile)
+    acc_bytes = (acc_doubles + 2) * 8;
     acc_region = (double*)A(acc_bytes);
-    double* acc_cursor = acc_region;
+    sqnorm = acc_region;
+    double* acc_cursor = acc_region ? acc_region + 2 : nullptr;
     auto unit_bufs = [&](Unit& u) {
       int C = u.cp.cout;
       u.y = (T*)A((size_t)u.M * C * sizeof(T));
@@ -468,7 +472,6 @@ struct Plan : PlanBase {
     dpooled = (float*)A((size_t)B * 512 * 4);
     fcT = (float*)A((size_t)512 * F * 4);
     loss_dev = (float*)A(256);
-    sqnorm = (double*)A(256);
     sq_partials = (double*)A((size_t)kSqPartials * 8);
     frozen = (unsigned char*)A(256);
     stem_colmap = (int*)A(224 * 4);
@@ -710,7 +713,10 @@ struct Plan : PlanBase {
     if (dirty) repack_head(s);
     grads_zeroed = zero_grads;
     cur_training = training;
-    if (training) hipMemsetAsync(acc_region, 0, acc_bytes, s);  // forward statistics + backward reduction sums
+    if (training) {  // forward statistics + backward reduction sums + the squared gradient norm
+      launch_zero_fill(reinterpret_cast<float*>(acc_region), (long)(acc_bytes / 4), s);
+      sqnorm_clean = true;
+    }
     if (input_u8)
       hipLaunchKernelGGL((u8nhwc_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
                          (const unsigned char*)images, xpad, B, H, W, Hp, Wp, input_norm);
@@ -1053,7 +1059,8 @@ struct Plan : PlanBase {
                            sq_partials);
         hipLaunchKernelGGL(sqnorm_fold_kernel, dim3(1), dim3(256), 0, s, (const double*)sq_partials, nb, sqnorm);
       } else {
-        hipMemsetAsync(sqnorm, 0, sizeof(double), s);
+        if (!sqnorm_clean) hipMemsetAsync(sqnorm, 0, sizeof(double), s);  // (a second optimiser step on one forward pass)
+        sqnorm_clean = false;
         hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(nb), dim3(256), 0, s, (const float*)grads, (long)L.model_floats, sqnorm,
                            (double*)nullptr);
       }

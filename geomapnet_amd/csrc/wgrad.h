@@ -39,9 +39,7 @@ struct WgradArgs {
   long split_stride = 0;
 };
 
-// MM (fp32 tensors): MMA_BF16X3 contracts on the bf16 matrix pipe, both operands split into hi + lo halves in registers
-// (common.h; g.mma selects it): a fragment is then 8 consecutive m of one channel instead of 4.
-template <typename T, int BMO, int BNO, int MM = MMA_NATIVE>
+template <typename T, int BMO, int BNO>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int BKM = 32;              // m rows per step
@@ -145,41 +143,6 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   for (int mt = m_begin; mt < m_end; mt += BKM) {
     const bool more = mt + BKM < m_end;
     if (more) load_tile(mt + BKM);
-    if constexpr (MM != MMA_NATIVE) {
-      static_assert(sizeof(T) == 4, "x3 modes: fp32 tensors");
-#pragma unroll
-      for (int kp = 0; kp < BKM / 16; ++kp) {
-        X3Frag<MM> xa[TM], xb[TN];
-        const int kb = kp * 16 + (lane >> 5) * 8;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int col = wm * (BMO / 2) + i * 32 + (lane & 31);
-          PieceView<float> p0, p1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            p0.e[e] = ldsY[cur][kb + e][col];
-            p1.e[e] = ldsY[cur][kb + 4 + e][col];
-          }
-          x3_split<MM>(p0, p1, 1.f, xa[i]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = wn * (BNO / 2) + j * 32 + (lane & 31);
-          PieceView<float> p0, p1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            p0.e[e] = ldsX[cur][kb + e][col];
-            p1.e[e] = ldsX[cur][kb + 4 + e][col];
-          }
-          x3_split<MM>(p0, p1, 1.f, xb[j]);
-        }
-        x3_fence();
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) x3_mma<MM>(xa[i], xb[j], acc[i][j]);
-      }
-    } else {
 #pragma unroll
     for (int ks = 0; ks < BKM / (2 * VEC); ++ks) {
       PieceView<T> fa[TM], fb[TN];
@@ -201,7 +164,6 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) mma_piece<T>(fa[i], fb[j], acc[i][j]);
     }
-    }  // native / x3
     if (more) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -546,6 +508,190 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
     }
 }
 
+// ---- fp32 tensors on the bf16 matrix pipe (MMA_BF16X3, common.h): the weight gradient of the fp32x3 mode -----------------
+// wgrad_kernel's loader (any gather: stride, taps, column map; 16-byte pieces of 4 floats through registers) + the fp16
+// kernel's reader: every element is split into hi + lo bf16 halves ONCE, on its way from the staging registers into LDS
+// (two bf16 planes per operand, rows = m, 16-byte pieces XOR-swizzled with the row as above), and a fragment -- 8
+// consecutive m of one channel -- is two ds_read_b64_tr_b16 per plane.  dW += alpha (Yh Xh + Yh Xl + Yl Xh): three MFMAs
+// per product, 2^-16 relative per operand.  (The first x3 form converted after the LDS read, per fragment: every element
+// was converted by both waves that read it and fetched with eight 4-byte LDS reads -- 134-195 TF on MI355X, round 3.)
+union TrFragB {
+  v4s16 h[2];
+  bf16x8 v;
+};
+template <int BMO, int BNO>
+static __global__ void __launch_bounds__(256, 2) wgrad_x3_kernel(WgradArgs a) {
+  constexpr int BKM = 32;                       // m rows per step
+  constexpr int YCP = BMO / 4, XCP = BNO / 4;   // float pieces per row
+  constexpr int YPT = BKM * YCP / 256, XPT = BKM * XCP / 256;
+  constexpr int YRS = 256 / YCP, XRS = 256 / XCP;
+  constexpr int TM = BMO / 64, TN = BNO / 64;   // 2x2 waves, 32x32 MFMA tiles
+  constexpr int PY = BKM * BMO, PX = BKM * BNO; // elements of one plane
+  constexpr int BUF = 2 * PY + 2 * PX;          // [Y hi][Y lo][X hi][X lo]
+  __shared__ unsigned short smem[2 * BUF] __attribute__((aligned(16)));
+
+  const GatherGeom& g = a.g;
+  const float* dY = reinterpret_cast<const float*>(a.dY);
+  const float* X = reinterpret_cast<const float*>(a.X);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * BMO, k0 = blockIdx.y * BNO;
+  const int m_begin = blockIdx.z * a.rows_per_split;
+  const int m_end = min(g.M, m_begin + a.rows_per_split);
+
+  const int ycp = t % YCP, yrow = t / YCP;
+  const bool y_col_ok = n0 + ycp * 4 < g.N;
+  const int xcp = t % XCP, xrow = t / XCP;
+  const int kcol = k0 + xcp * 4;
+  const bool x_col_ok = kcol < g.K;
+  const int tap = x_col_ok ? kcol / g.C : 0;
+  const int c0 = x_col_ok ? kcol % g.C : 0;
+  const int dh = g.rsign * (tap / g.S), dw = g.ssign * (tap % g.S);
+  int xb[XPT], xp[XPT], xq[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int m = m_begin + xrow + i * XRS;
+    xq[i] = m % g.Q;
+    const int tmp = m / g.Q;
+    xp[i] = tmp % g.P;
+    xb[i] = tmp / g.P;
+  }
+  piece_t ry[YPT], rx[XPT];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < YPT; ++i) {
+      const int m = mt + yrow + i * YRS;
+      ry[i] = (y_col_ok && m < m_end) ? *reinterpret_cast<const piece_t*>(dY + (long)m * a.ldy + n0 + ycp * 4) : zero_piece();
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int m = mt + xrow + i * XRS;
+      int hn = xp[i] * g.mul_p + g.off_h + dh, wn_ = xq[i] * g.mul_q + g.off_w + dw;
+      bool ok = x_col_ok && m < m_end;
+      if (g.div == 2) {
+        ok = ok && ((hn | wn_) & 1) == 0;
+        hn >>= 1;
+        wn_ >>= 1;
+      }
+      ok = ok && (unsigned)hn < (unsigned)g.Hi && (unsigned)wn_ < (unsigned)g.Wi;
+      rx[i] = ok ? *reinterpret_cast<const piece_t*>(X + ((long)((xb[i] * g.Hi + hn) * g.Wi + wn_) * g.C + c0)) : zero_piece();
+      xq[i] += BKM;
+      while (xq[i] >= g.Q) {
+        xq[i] -= g.Q;
+        if (++xp[i] == g.P) {
+          xp[i] = 0;
+          ++xb[i];
+        }
+      }
+    }
+  };
+  // 4 floats -> 4 hi + 4 lo bf16 at (row, columns col .. col + 3) of a plane pair whose rows are W elements long
+  auto split_store = [&](piece_t raw, unsigned short* hi_plane, unsigned short* lo_plane, int row, int col, int W, int swz) {
+    PieceView<float> v;
+    v.p = raw;
+    union {
+      __bf16 b[4];
+      u32x2 u;
+    } h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h.b[e] = (__bf16)v.e[e];
+      l.b[e] = (__bf16)(v.e[e] - (float)h.b[e]);
+    }
+    const int at = row * W + (((col >> 3) ^ swz) * 8) + (col & 7);
+    *reinterpret_cast<u32x2*>(hi_plane + at) = h.u;
+    *reinterpret_cast<u32x2*>(lo_plane + at) = l.u;
+  };
+  auto store_tile = [&](int buf) {
+    unsigned short* base = &smem[buf * BUF];
+#pragma unroll
+    for (int i = 0; i < YPT; ++i) {
+      const int row = yrow + i * YRS;
+      split_store(ry[i], base, base + PY, row, ycp * 4, BMO, wg_swz<BMO / 8>(row));
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int row = xrow + i * XRS;
+      split_store(rx[i], base + 2 * PY, base + 2 * PY + PX, row, xcp * 4, BNO, wg_swz<BNO / 8>(row));
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transpose-read lane geometry (wgrad_dma_kernel)
+  const int gq = lane >> 4, i16 = lane & 15;
+  const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
+  const int kgrp = (gq >> 1) * 8;
+
+  if (m_begin < m_end) {
+    load_tile(m_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int mt = m_begin; mt < m_end; mt += BKM) {
+    const bool more = mt + BKM < m_end;
+    if (more) load_tile(mt + BKM);  // in flight under this step's reads and MFMAs
+    const unsigned short* yh = &smem[cur * BUF];
+    const unsigned short* yl = yh + PY;
+    const unsigned short* xh = yh + 2 * PY;
+    const unsigned short* xl = xh + PX;
+#pragma unroll
+    for (int ks = 0; ks < BKM / 16; ++ks) {
+      TrFragB ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const int row = ks * 16 + kgrp + hlf * 4 + src_row;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int col = wm * (BMO / 2) + i * 32 + src_chunk;
+          const int at = row * BMO + (((col >> 3) ^ wg_swz<BMO / 8>(row)) * 8) + (col & 7);
+          ah[i].h[hlf] = ds_read_tr16(yh + at);
+          al[i].h[hlf] = ds_read_tr16(yl + at);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * (BNO / 2) + j * 32 + src_chunk;
+          const int at = row * BNO + (((col >> 3) ^ wg_swz<BNO / 8>(row)) * 8) + (col & 7);
+          bh[j].h[hlf] = ds_read_tr16(xh + at);
+          bl[j].h[hlf] = ds_read_tr16(xl + at);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int kc = k0 + wn * (BNO / 2) + j * 32 + (lane & 31);
+      const int dst = kc < g.K ? (a.colmap ? a.colmap[kc] : kc) : -1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * (BMO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < g.N && dst >= 0)
+          unsafeAtomicAdd(a.dW + (long)blockIdx.z * a.split_stride + (long)n * a.ldw + dst, acc[i][j][r] * a.alpha);
+      }
+    }
+}
+
 template <typename T>
 struct WgradDma {
   static bool launch(const WgradArgs&, dim3, int, int, hipStream_t, const void*) { return false; }
@@ -666,13 +812,13 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
   if (sizeof(T) == 4 && g.mma == MMA_BF16X3) {
     if constexpr (sizeof(T) == 4) {
       if (bmo == 64 && bno == 64)
-        hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, MMA_BF16X3>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((wgrad_x3_kernel<64, 64>), grid, block, 0, stream, a);
       else if (bmo == 64)
-        hipLaunchKernelGGL((wgrad_kernel<T, 64, 128, MMA_BF16X3>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((wgrad_x3_kernel<64, 128>), grid, block, 0, stream, a);
       else if (bno == 64)
-        hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, MMA_BF16X3>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((wgrad_x3_kernel<128, 64>), grid, block, 0, stream, a);
       else
-        hipLaunchKernelGGL((wgrad_kernel<T, 128, 128, MMA_BF16X3>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((wgrad_x3_kernel<128, 128>), grid, block, 0, stream, a);
     }
   } else if (use_dma && WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) {
   } else if (bmo == 64 && bno == 64)

@@ -69,17 +69,9 @@ _PROTOS = {
     "mn_op_igemm": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_void, c_i, c_void, c_void,
                           c_f, c_void, c_void]),
     "mn_op_igemm_grid_m": (c_i, [c_i]),
-    "mn_op_igemm_streamk": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_void, c_i, c_void, c_void,
-                                  c_f, c_void, c_void, c_i, c_void]),
     "mn_op_wgrad": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_i, c_void, c_void, c_i, c_void, c_f, c_i, c_void, c_void]),
     "mn_op_wgrad_ws_floats": (c_i64, []),
     "mn_op_wgrad_ws": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_i, c_void, c_void, c_i, c_f, c_void, c_i64, c_void, c_void]),
-    "mn_op_conv_halo": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_void, c_i, c_void, c_void, c_void, c_f,
-                              c_void]),
-    "mn_op_conv_halo_grid_m": (c_i, [C.POINTER(GatherGeom)]),
-    "mn_op_igemm_rt": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_void, c_i, c_i, c_void, c_void, c_void,
-                             c_f, c_void]),
-    "mn_op_igemm_rt_grid_m": (c_i, [C.POINTER(GatherGeom)]),
     "mn_op_conv_halo_pp": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_i, c_i, c_void, c_void, c_void, c_f,
                                  c_i, c_void]),
     "mn_op_conv_dgrad": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_i,

@@ -12,19 +12,11 @@
 namespace mn {
 
 inline int ew_grid(long work_items) {
-  // grid-stride kernels: at most 16 workgroups per CU (MN_EW_WGS_PER_CU, tuning knob: fewer leave wave slots to the
-  // weight-gradient workgroups that run beside the HBM-bound passes)
-  static const int per_cu = getenv("MN_EW_WGS_PER_CU") ? atoi(getenv("MN_EW_WGS_PER_CU")) : 16;
-  // small tensors (layers 3-4: 1-2 M pieces): at one piece per thread a workgroup's prologue (coefficient tables into LDS)
-  // and its dispatch cost as much as its loads; MN_EW_MIN_ITERS pieces per thread (while that leaves >= 2 workgroups per CU)
-  static const int min_iters = getenv("MN_EW_MIN_ITERS") ? atoi(getenv("MN_EW_MIN_ITERS")) : 1;
+  // grid-stride kernels: at most 16 workgroups per CU.  (Measured and removed, same-box A/Bs of the whole step in
+  // profiles/r02/c25_*: fewer workgroups per CU -- to leave wave slots to the weight gradients running beside the
+  // HBM-bound passes -- and several pieces per thread for the small tensors of layers 3-4: no gain.)
   long b = (work_items + 255) / 256;
-  if (min_iters > 1) {
-    long fat = (work_items + 256L * min_iters - 1) / (256L * min_iters);
-    if (fat < 512) fat = b < 512 ? b : 512;
-    b = fat;
-  }
-  if (b > 256L * per_cu) b = 256L * per_cu;
+  if (b > 256L * 16) b = 256L * 16;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -341,7 +333,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
   }
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  // U rows per iteration, all loads issued before the arithmetic (memory-level parallelism; MN_BN_REDUCE_UNROLL = 4 | 8)
+  // U rows per iteration, all loads issued before the arithmetic (memory-level parallelism)
   for (long r = r0 + rl; r < r1; r += (long)U * rlanes) {
     PieceView<T> vg[U], vy[U], vm[U];
 #pragma unroll
@@ -432,12 +424,12 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ coef,
                                                             T* __restrict__ gy, long npieces, int C, int self_gate,
-                                                            PoolGradSrc pg, int reverse) {
+                                                            PoolGradSrc pg) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const bool sg_beta = self_gate != 0;
   const int cpr = C / VEC;
   // gy = k1 (gm - mg - xhat mgx), xhat = (y - mean) invstd, as  k1 gm + kb (y - mean) + kd  with per-channel coefficients
-  // in registers (this thread's channel piece is loop invariant, forward or reverse walk: see bn_apply_kernel)
+  // in registers (this thread's channel piece is loop invariant: see bn_apply_kernel)
   float k1[VEC], kb[VEC], kd[VEC], mu[VEC], sh[VEC];
   {
     __shared__ floatx4 tab[512];  // [e][piece] -> (k1, kb, kd, mean)
@@ -450,8 +442,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
       tab_sh[at] = sg_beta ? coef[3 * C + c] : 0.f;
     }
     __syncthreads();
-    const long first = reverse ? npieces - 1 - ((long)blockIdx.x * blockDim.x + threadIdx.x) : (long)threadIdx.x;
-    const int cp = (int)(((first % cpr) + cpr) % cpr);
+    const int cp = (int)(threadIdx.x % cpr);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const floatx4 v = tab[e * cpr + cp];
@@ -462,10 +453,9 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
       sh[e] = tab_sh[e * cpr + cp];
     }
   }
-  // reverse: walk the tensor back to front -- the reduction pass that ran just before read g and y front to back, so
-  // their tails are what the L2s / Infinity Cache still hold
-  for (long i_ = (long)blockIdx.x * blockDim.x + threadIdx.x; i_ < npieces; i_ += (long)gridDim.x * blockDim.x) {
-    const long i = reverse ? npieces - 1 - i_ : i_;
+  // (Walking the tensor back to front -- the reduction pass that ran just before read g and y front to back, so their
+  // tails are what the caches still hold -- was measured: no gain.)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
     PieceView<T> vg, vy, vm, o;
     if constexpr (POOL) {
       float a[VEC];
@@ -551,22 +541,18 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   if (self_gate_beta) gate = nullptr;
   // ~512 workgroups (2 per CU): the reduction is HBM-bound and needs the whole chip, but every workgroup ends with an LDS
   // reduction and 2 x C fp64 atomics -- at 4096 workgroups (round 1) layers 3-4 did ONE loop iteration per workgroup and
-  // that epilogue weighed as much as the loads (MN_BN_REDUCE_BLOCKS, same-box A/Bs of the whole step: 4096 17.77 ms,
+  // that epilogue weighed as much as the loads (same-box A/Bs of the whole step: 4096 workgroups 17.77 ms,
   // 1024 17.60, 512 17.42, 256 17.97)
-  static const long target = getenv("MN_BN_REDUCE_BLOCKS") && atol(getenv("MN_BN_REDUCE_BLOCKS")) > 0
-                                 ? atol(getenv("MN_BN_REDUCE_BLOCKS")) : 512;
+  constexpr long target = 512;
   const int rlanes = 256 / (C / VEC);
   long rows = (M + target - 1) / target;
   rows = ((rows + rlanes - 1) / rlanes) * rlanes;
   if (rows < 4L * rlanes) rows = 4L * rlanes;
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
-  static const int unroll = getenv("MN_BN_REDUCE_UNROLL") ? atoi(getenv("MN_BN_REDUCE_UNROLL")) : 4;
+  // (4 rows per thread per iteration in flight; 8 measured equal: 15.07 vs 14.99 ms per step)
   if (pg.idx)
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
-                       rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
-  else if (unroll == 8)
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false, 8>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   else
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
@@ -575,13 +561,12 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
                      invstd, dgamma, dbeta, grad_unscale, self_gate_beta, coef, C, accum_rows);
   if (!apply) return;
   long np = M * C / VEC;
-  static const int reverse = getenv("MN_BN_BWD_REVERSE") ? atoi(getenv("MN_BN_BWD_REVERSE")) : 0;
   if (pg.idx)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
-                       (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg, reverse);
+                       (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
-                       (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg, reverse);
+                       (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg);
 }
 
 // ---- global average pool --------------------------------------------------------------------------

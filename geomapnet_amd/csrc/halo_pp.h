@@ -1,12 +1,21 @@
-// 3x3 stride-1 convolution of 64 -> 64 channel fp16 tensors (ResNet layer1, forward and data gradient): persistent
-// "ping-pong" form of halo.h.
+// 3x3 stride-1 convolution of 64 -> 64 channel fp16 tensors (ResNet layer1, forward and data gradient) with the input tile
+// staged ONCE in LDS, as a persistent "ping-pong" kernel.
 //
-// halo.h runs one 16x16-pixel tile per 4-wave workgroup (this kernel: 8x32- or 16x16-pixel tiles, template parameter TW): halo DMA -> wait -> nine taps with a barrier each (the tap's
-// weight slice streams through a two-slot ring) -> epilogue through an LDS staging block.  Its ablations (profiles/r02)
-// show the three phases ADD: a CU holds two such workgroups and they drift into the same phase, so the matrix pipe
-// idles through the DMA waits, nine barrier bubbles per tile and the epilogue (123 us for a launch whose MFMA time is
-// 35 us and whose HBM floor -- 270 MB -- is ~55 us).  Here a workgroup is 8 waves in TWO groups of four, persistent over
-// the tiles of the launch (one workgroup per CU), and the groups alternate by construction:
+//   out[b, y, x, n] = sum_{r, s, c} in[b, y + rsign*r + off_h, x + ssign*s + off_w, c] * Bw[n][(r*3 + s)*64 + c]
+//
+// (GatherGeom conventions of igemm.h: forward rsign = +1, off = -pad; data gradient rsign = -1, off = +pad.)
+//
+// Why not igemm.h: the implicit-GEMM kernel fetches every tap of every K-step through the LDS-DMA path -- for C = N = 64
+// that is 221 KB per 128-pixel tile (nine shifted copies of the same 128 input rows + the 74 KB weight matrix) and the
+// launch runs at the ~20 B/clk/CU that path sustains (159 us for 270 MB of tensors, MFMA pipe 21 % busy).  A workgroup
+// that owns a 16x16-pixel output tile loads its 18x18-pixel input halo (41 KB) once and walks the nine taps as ADDRESS
+// OFFSETS into that LDS image.  The first form of this idea (rounds 1-2, "halo.h", removed in round 3) ran one tile per
+// 4-wave workgroup: halo DMA -> wait -> nine taps with a barrier each (the tap's weight slice streamed through a two-slot
+// ring) -> epilogue through an LDS staging block.  Its ablations (profiles/r02) showed the three phases ADD: a CU held two
+// such workgroups and they drifted into the same phase, so the matrix pipe idled through the DMA waits, nine barrier
+// bubbles per tile and the epilogue (123 us for a launch whose MFMA time is 35 us and whose HBM floor -- 270 MB -- is
+// ~55 us).  Here a workgroup is 8 waves in TWO groups of four, persistent over the tiles of the launch (one workgroup per
+// CU), and the groups alternate by construction:
 //
 //   phase p:   group p & 1        computes tile p          (144 MFMAs per wave, NO barrier inside: all nine weight
 //                                                           slices, 72 KB, are LDS-resident for the whole launch)
@@ -14,27 +23,37 @@
 //   one s_barrier per phase.
 //
 // So the matrix pipe of each SIMD always has one wave in its MFMA loop while the other wave of that SIMD does the
-// memory-side work of the neighbouring tiles.  LDS: weights 72 KB + two halo images 2 x 43 KB = 158 KB.
+// memory-side work of the neighbouring tiles.  LDS: weights 72 KB + two halo images 2 x 43 KB = 158 KB.  LDS image:
+// pixel-major, 8 pieces of 16 bytes per pixel, piece slot XOR-swizzled by (pixel >> 1) & 7 on the source side of the DMA
+// and in the fragment address.
 //
 // The epilogue uses NO LDS (a staging block would have to live in the halo buffer and delay the next halo's DMA behind
 // the stores): the MFMA operands are swapped -- weights as the A operand, pixels as B -- so that the accumulator of a
 // lane holds, for ONE pixel (lane & 31), channels 8q + 4(lane >> 5) + 0..3 of each 32-channel tile: four consecutive
 // channels = one 8-byte store, the two half-waves completing 16 bytes, eight such stores covering the pixel's 128-byte
 // line.  Residual / gate values are read in the same pattern.  BatchNorm column sums (forward) are per-lane partial
-// sums held in registers across all tiles of the workgroup, folded across lanes once at the end.
+// sums held in registers across all tiles of the workgroup, folded across lanes once at the end; out-of-image pixels of
+// ragged tiles (341 / 4 = 86 = 5*16 + 6 columns) are masked out of them.
 #pragma once
-#include "halo.h"
+#include "igemm.h"
 
 namespace mn {
 
+constexpr int kHaloTH = 16, kHaloTW = 16;  // output tile
+
+// the shapes the kernel family covers: fp16, 3x3, stride 1, 64 input channels, same-size output
+inline bool conv_halo_applies(const GatherGeom& g) {
+  return g.R == 3 && g.S == 3 && g.C == 64 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&
+         g.K == 9 * 64 && g.N % 8 == 0 && !g.bt_on && (g.rsign == 1 || g.rsign == -1) && g.rsign == g.ssign &&
+         (long)g.B * g.Hi * g.Wi * g.C * 2 < 0xfffffff0l;
+}
+
 constexpr int kPpWeightPieces = 9 * 512;  // nine 64 x 64 fp16 slices
-// Tile: 16 x 16 pixels (halo.h's) or 8 rows x 32 columns.  With 8 x 32 the 32 pixel lanes of an MFMA operand are 32
-// CONSECUTIVE pixels of one halo row = 32 consecutive LDS rows, the conflict-free ds_read_b128 pattern of igemm.h; with
+// Tile: 16 x 16 pixels (TW = 16).  The template also builds 8 rows x 32 columns (TW = 32): there the 32 pixel lanes of an
+// MFMA operand are 32 CONSECUTIVE pixels of one halo row, the conflict-free ds_read_b128 pattern of igemm.h, while with
 // 16 x 16 tiles lanes 16-31 sit one halo row (18 pixels) below lanes 0-15 and collide with lanes 2-17
-// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.31 vs 0, profiles/r02/c27_sq_counters_layer1.txt, c28_*).  Same number of
-// tiles for 64 x 86 maps (8 x 3 instead of 4 x 6), 340 instead of 324 halo pixels.  Measured EQUAL (c29_*): the default
-// stays 16 x 16.
-// TW = 32 (TH = 8) or 16 (TH = 16): template parameter, MN_HALO_PP_TILE selects (same-box A/B in profiles/r02/c29_*).
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.31 vs 0, profiles/r02/c27_sq_counters_layer1.txt, c28_*).  Measured EQUAL
+// per launch and per step (c29_*): the bank conflicts are not what bounds the MFMA loop; only 16 x 16 is instantiated.
 constexpr int pp_halo_passes(int TW) { return ((256 / TW + 2) * (TW + 2) * 8 + 63) / 64; }  // wave-wide DMAs per halo: 43 | 41
 
 // ABL (timing experiments only, ablation build, results are wrong): bit 0 = halo DMA only for each group's first tile,
@@ -328,10 +347,7 @@ inline bool conv_halo_pp_applies(const GatherGeom& g, const Epilogue& ep) {
 // wgs: persistent workgroups (0 = one per CU, or MN_HALO_PP_WGS)
 inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
                                 int wgs_arg = 0) {
-  // 16 (default): 16 x 16 tiles; 32: 8 x 32 tiles, whose fragment reads have no bank conflicts -- measured the same per
-  // launch and 0.3 % slower per step (15.27 vs 15.21 ms, same box): the conflicts are not what bounds the MFMA loop
-  static const int tw = getenv("MN_HALO_PP_TILE") && atoi(getenv("MN_HALO_PP_TILE")) == 32 ? 32 : 16;
-  const int tx = cdiv(g.Q, tw), ty = cdiv(g.P, 256 / tw);
+  const int tx = cdiv(g.Q, kHaloTW), ty = cdiv(g.P, kHaloTH);
   const int ntiles = g.B * tx * ty;
   static const int wgs_env = getenv("MN_HALO_PP_WGS") ? atoi(getenv("MN_HALO_PP_WGS")) : 256;  // one per CU
   const int wgs = wgs_arg > 0 ? wgs_arg : wgs_env;
@@ -368,13 +384,6 @@ inline void launch_conv_halo_pp(const GatherGeom& g, const half* A, const half* 
 #undef PP_CASE
 #undef PP_VAR
 #endif
-  if (tw == 32) {
-    if (ep.stats_accum)
-      hipLaunchKernelGGL((conv_halo_pp_kernel<true, 0, 0, 3, false, 32>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
-    else
-      hipLaunchKernelGGL((conv_halo_pp_kernel<false, 0, 0, 3, false, 32>), grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
-    return;
-  }
   if (ep.stats_accum)
     hipLaunchKernelGGL(conv_halo_pp_kernel<true>, grid, dim3(512), 0, stream, g, A, Bw, ep, tx, ty, ntiles);
   else

@@ -78,10 +78,6 @@ struct Epilogue {
   void* out;             // [M][ldc], element type T
   int ldc;
   float* stats;          // [grid_m][2][N] column partial sums (sum, sum of squares) or null
-  // stream-K (see igemm_kernel): fp32 slabs [blocks][2][BM*BN] (scratch) and arrival counters [blocks] (zero on
-  // entry, left zero on exit); null = every workgroup owns whole tiles
-  float* sk_ws = nullptr;
-  int* sk_counters = nullptr;
   double* stats_accum = nullptr;  // alternative: [stats_rows][2][N] fp64 accumulators, added to atomically (row =
   int stats_rows = 0;             // tile_m % stats_rows spreads the same-address contention); consumer sums the rows
   const float* bias;     // [N] or null
@@ -192,29 +188,33 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 //
-// SK (stream-K): the launch has a fixed number of workgroups (the resident slots of the chip) and the tile-major
-// iteration space tiles x K-steps is cut into equal contiguous ranges, so a grid of 528 or 1056 tiles costs 1.03 /
-// 2.06 rounds of work instead of 2 / 3.  A workgroup whose range covers only part of a tile adds its fp32
-// accumulators to its own workspace slab and bumps the tile's arrival counter; the second of the two workgroups
-// that share a tile adds the other's slab and runs the normal epilogue.  Nobody waits for anybody.
 // SPL: the NBUF-1-ahead tile's DMA instructions are not issued in one burst after the barrier but spread over the
 // K-step's MFMA sub-steps (behind each sub-step's MFMAs), so that the first fragment reads and MFMAs of a K-step do not
 // queue behind the burst.
 // ABL (timing experiments only, results are wrong; tools/conv_bench.py with MN_ABLATE): bit 0 = no DMA in the main
 // loop, bit 1 = fragments from registers instead of ds_reads, bit 2 = no barrier in the main loop.
-// (A "rotated" loop -- K-step boundary before the last MFMA sub-step, first fragments of the next tile read there so
-// that their LDS latency hides under the previous tile's MFMAs -- was implemented, emulator-verified and measured
-// neutral on the 288x256, 128x128 and 128x64 configurations; removed.)
+// (Measured and removed: a "rotated" loop -- K-step boundary before the last MFMA sub-step, first fragments of the next
+// tile read there -- neutral on the 288x256, 128x128 and 128x64 configurations; a stream-K schedule -- equal (tile,
+// K-step) ranges per resident workgroup with a two-party slab reduction -- 123 vs 120 us, 105 vs 103 us, 113 vs 118 us,
+// whole step 19.8 vs 19.65 ms: every extra segment pays a gather prologue and a pipeline fill; profiles/r01.)
 // MM (fp32 tensors only): MMA_F16X3 / MMA_BF16X3 run the contraction on the f16 / bf16 matrix pipe with every operand split
 // into hi + lo halves after its LDS read, three MFMAs per product (common.h): the K-step's pieces are consumed in groups
 // of four (16 k: lanes 0-31 take pieces 4 kp, 4 kp + 1, lanes 32-63 pieces 4 kp + 2, 4 kp + 3 -- any k order is valid as
 // long as A and B agree).
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SK = false, bool SPL = false,
-          int ABL = 0, int MM = MMA_NATIVE>
+// Main-loop ablation of the x3 form on MI355X (profiles/r03/c5_ablation_fp32x3_igemm_layer3.txt, layer3 forward, 346 us):
+// no DMA 279 us, no operand splits 252, no MFMAs 225, neither splits nor MFMAs 155, nothing but prologue + epilogue 35 --
+// MFMAs (~120 us), splits (~94) and DMA + fragment reads (~120) ADD almost linearly, as they did for the fp16 kernel in
+// round 1: a wave alternates VALU-only and MFMA-only segments and the two workgroups of a CU do not settle half a K-step
+// apart.  Forcing that alternation was tried and removed (round 3, c6_fp32x3_pingpong_experiment.txt): ONE 8-wave workgroup
+// of two wave groups with a tile and an LDS ring each, a K-step = a LOAD phase (reads + splits) and an MFMA phase (MFMAs +
+// DMA issue) separated by workgroup-wide barriers, group 1 one phase late -- parity-green and 2x SLOWER (layer3 306 -> 660
+// us, whole step 40.9 -> 64.9 ms): every phase then lasts as long as the slowest of eight waves' waits.  What is left to
+// try is software pipelining INSIDE a wave (the splits of group kp + 1 in the shadow of the MFMAs of group kp).
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI, bool SPL = false, int ABL = 0,
+          int MM = MMA_NATIVE>
 static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherGeom g, const T* __restrict__ A,
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
-                                                                         const T* __restrict__ zero_page, RowDiv rd,
-                                                                         int sk_tiles) {
+                                                                         const T* __restrict__ zero_page, RowDiv rd) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -240,24 +240,9 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform values stay in scalar registers
   const int wm = wave / WN, wn = wave % WN;
   const int KT = g.K / (NP * VEC);
-  // [it, it_end): this workgroup's range of the tile-major (tile, K-step) iteration space
-  long it, it_end;
-  long sk_total = 0;
-  if constexpr (SK) {
-    static_assert(UNI, "stream-K needs the uniform tap walk");
-    sk_total = (long)sk_tiles * KT;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    it = lb * sk_total / gridDim.x;
-    it_end = (lb + 1) * sk_total / gridDim.x;
-  } else {
-    it = (long)xcd_remap(blockIdx.x, gridDim.x) * KT;
-    it_end = it + KT;
-  }
-  while (it < it_end) {
-  const int tile = (int)(it / KT);
-  const int k0 = (int)(it - (long)tile * KT);
-  const int k1 = (int)(it_end - it < (long)(KT - k0) ? k0 + (it_end - it) : KT);
-  it += k1 - k0;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int k0 = 0;
+  const int k1 = KT;
   const int tile_m = tile / grid_n, tile_n = tile - tile_m * grid_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int pc = t % NP, lrow = t / NP;
@@ -340,13 +325,6 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   // running decomposition of the step's first piece (uniform walk) or of this lane's piece (per-lane walk)
   // into (tap = (tr, ts), channel piece cpi)
   int cpi = uni ? 0 : src_piece, tr = 0, ts = 0, tap = 0;
-  if (SK && k0 > 0) {  // the range starts inside the tile (uniform walk: plain scalar divisions)
-    const int piece0 = k0 * NP;
-    tap = piece0 / CP;
-    cpi = piece0 - tap * CP;
-    tr = tap / g.S;
-    ts = tap - tr * g.S;
-  }
   while (cpi >= CP) {
     cpi -= CP;
     ++tap;
@@ -356,7 +334,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     }
   }
   unsigned b_step = (unsigned)k0 * NP * 16;  // byte offset of the K-step inside a weight row (scalar)
-  const bool tapin = UNI && !SK && g.tap_inner != 0;
+  const bool tapin = UNI && g.tap_inner != 0;
   const unsigned lds_wave = wave * 64;  // this wave's 64 pieces of DMA pass 0 inside a tile
 
   // instructions [j0, j1) of the tile's IPT DMA instructions (A passes first, then B passes); the tap walk advances
@@ -421,6 +399,69 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   for (int j = 0; j < D; ++j)
     if (j < NK) issue_tile(j);
   int cur = 0, nxt = D % NBUF;
+  // x3, software-pipelined form (128-byte K-steps = two groups of 16 k, two buffers): the operand splits of a group run in
+  // the shadow of the MFMAs of the group before it -- after every MFMA triple (96 matrix-pipe cycles) one fragment of the
+  // NEXT group is split (12 VALU operations) -- and the K-step's barrier sits between its two groups, so that the first
+  // group of tile kt + 1 can be split under the MFMAs of the second group of tile kt:
+  //     [M(kt, 0) | C(kt, 1)]  wait + barrier  DMA(kt + 2)  [M(kt, 1) | C(kt + 1, 0)]
+  // (the form without this overlap: layer3 forward 313 us of which ~94 us are the splits, c5_ablation_fp32x3_*.txt)
+  constexpr bool X3_PIPE = MM != MMA_NATIVE && NP == 8 && NBUF == 2 && !SPL && ABL == 0;
+  if constexpr (X3_PIPE) {
+    constexpr int P = TM * TN, F = TM + TN;
+    X3Frag<MM> xa[2][TM], xb[2][TN];  // [group parity]
+    PieceView<float> ra[TM][2], rb[TN][2];
+    auto load_raw = [&](int buf, int kp) {
+      const piece_t* ta = &smem[buf * TILE_PIECES];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pxs = (kp * 4 + (lane >> 5) * 2 + h) ^ lds_swz<NP>(lane & 31);
+        const piece_t* pa = ta + (wm * WTM + (lane & 31)) * NP + pxs;
+        const piece_t* pb = ta + (BM + wn * WTN + (lane & 31)) * NP + pxs;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ra[i][h].p = pa[i * 32 * NP];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) rb[j][h].p = pb[j * 32 * NP];
+      }
+    };
+    auto split_frag = [&](int f, int dst) {  // fragment f of the raw registers -> group slot dst (f, dst: unrolled constants)
+      if (f < TM)
+        x3_split<MM>(ra[f][0], ra[f][1], xa[dst][f]);
+      else
+        x3_split<MM>(rb[f - TM][0], rb[f - TM][1], xb[dst][f - TM]);
+    };
+    // MFMAs of group slot `src`; with `split`, the raw registers are split into slot src ^ 1 along the way
+    auto mma_group = [&](int src, bool split) {
+#pragma unroll
+      for (int pth = 0; pth < P; ++pth) {
+        x3_mma<MM>(xa[src][pth / TN], xb[src][pth % TN], acc[pth / TN][pth % TN]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (split) {
+#pragma unroll
+          for (int f = pth * F / P; f < (pth + 1) * F / P; ++f) split_frag(f, src ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (split) x3_fence();
+    };
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // tile 0 visible
+    if (1 < NK) issue_tile(1);
+    load_raw(0, 0);
+#pragma unroll
+    for (int f = 0; f < F; ++f) split_frag(f, 0);
+    x3_fence();
+    for (int kt = 0; kt < NK; ++kt) {
+      const int cb = kt & 1;
+      load_raw(cb, 1);
+      mma_group(0, true);  // M(kt, 0) | C(kt, 1)
+      const bool next = kt + 1 < NK;
+      if (next) wait_vmcnt<0>();  // this wave's pieces of tile kt + 1, requested one K-step ago
+      __builtin_amdgcn_s_barrier();  // tile kt + 1 visible to all waves; every read of tile kt has been consumed
+      if (kt + 2 < NK) issue_tile(cb);
+      if (next) load_raw(cb ^ 1, 0);
+      mma_group(1, next);  // M(kt, 1) | C(kt + 1, 0)
+    }
+  } else
   for (int kt = 0; kt < NK; ++kt) {
     // tiles issued so far: min(NK, kt + D); tile kt must have landed
     const int ahead = min(NK, kt + D) - (kt + 1);
@@ -451,12 +492,21 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     const int ln = lane;
 #endif
     if constexpr (MM != MMA_NATIVE) {
-      static_assert(sizeof(T) == 4 && NP % 4 == 0 && ABL == 0 && !SK, "x3 modes: fp32 tensors, whole groups of four pieces");
+      static_assert(sizeof(T) == 4 && NP % 4 == 0, "x3 modes: fp32 tensors, whole groups of four pieces");
+      // (ABL, timing experiments: bits 0-2 as above; bit 3 = no operand splits, bit 4 = no MFMAs)
       constexpr int NKP = NP / 4;
       PieceView<float> ra[TM][2], rb[TN][2];
       auto load_raw = [&](int kp) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+          if constexpr ((ABL & 2) != 0) {
+            const piece_t fake = {(unsigned)ln, (unsigned)kt, (unsigned)kp, (unsigned)h};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ra[i][h].p = fake;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) rb[j][h].p = fake;
+            continue;
+          }
           const int pxs = (kp * 4 + (ln >> 5) * 2 + h) ^ lds_swz<NP>(ln & 31);
           const piece_t* pa = ta + (wm * WTM + (ln & 31)) * NP + pxs;
           const piece_t* pb = ta + (BM + wn * WTN + (ln & 31)) * NP + pxs;
@@ -470,16 +520,36 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #pragma unroll
       for (int kp = 0; kp < NKP; ++kp) {
         X3Frag<MM> xa[TM], xb[TN];
+        if constexpr ((ABL & 8) != 0) {  // raw bits stand in for the split operands
 #pragma unroll
-        for (int i = 0; i < TM; ++i) x3_split<MM>(ra[i][0], ra[i][1], xa[i]);
+          for (int i = 0; i < TM; ++i) {
+            __builtin_memcpy(&xa[i].hi, &ra[i][0].p, 16);
+            __builtin_memcpy(&xa[i].lo, &ra[i][1].p, 16);
+          }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) x3_split<MM>(rb[j][0], rb[j][1], xb[j]);
+          for (int j = 0; j < TN; ++j) {
+            __builtin_memcpy(&xb[j].hi, &rb[j][0].p, 16);
+            __builtin_memcpy(&xb[j].lo, &rb[j][1].p, 16);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) x3_split<MM>(ra[i][0], ra[i][1], xa[i]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) x3_split<MM>(rb[j][0], rb[j][1], xb[j]);
+        }
         if (kp + 1 < NKP) load_raw(kp + 1);  // the raw registers are free again: next group's reads fly under these MFMAs
         x3_fence();
+        if constexpr ((ABL & 16) != 0) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(xa[i].hi), "v"(xa[i].lo));
 #pragma unroll
-          for (int j = 0; j < TN; ++j) x3_mma<MM>(xa[i], xb[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(xb[j].hi), "v"(xb[j].lo));
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) x3_mma<MM>(xa[i], xb[j], acc[i][j]);
+        }
         if constexpr (SPL) {
           if (more) issue_part(nxt, kp * IPT / NKP, (kp + 1) * IPT / NKP);
         }
@@ -524,54 +594,6 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
     nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
   }
   __syncthreads();  // all fragment reads done before the ring is reused as epilogue staging
-
-  if constexpr (SK) {
-    if (k0 != 0 || k1 != KT) {
-      // Partial tile.  Ranges are at least one tile long (the launcher only uses stream-K when tiles > workgroups),
-      // so a tile is shared by exactly two workgroups: lb, which holds its head (k0 == 0), and lb + 1, which holds
-      // its tail.  Each writes its fp32 accumulators to its own slab (write-through stores, no atomics), publishes
-      // with one counter increment, and whoever arrives second adds the other's slab and runs the epilogue
-      // (cdna_hip_programming.md, in-launch split-K reduction).
-      const int lb = xcd_remap(blockIdx.x, gridDim.x);
-      const bool head = k0 == 0;
-      const int cidx = head ? lb : lb - 1;
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(ep.sk_ws, (long)gridDim.x * 2 * (BM * BN) * 4);
-      const unsigned mine = (unsigned)((lb * 2 + (head ? 1 : 0)) * (BM * BN) * 4);
-      const unsigned theirs = (unsigned)(((head ? lb + 1 : lb - 1) * 2 + (head ? 0 : 1)) * (BM * BN) * 4);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            u32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = f32_bits(acc[i][j][q * 4 + e]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + ((((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 16, 0,
-                                                   16 /* sc1: write-through */);
-          }
-      wait_vmcnt<0>();
-      __syncthreads();
-      int* flag = reinterpret_cast<int*>(red);
-      if (t == 0) flag[0] = atomicAdd(&ep.sk_counters[cidx], 1);
-      __syncthreads();
-      const bool last = flag[0] != 0;
-      __syncthreads();  // everyone has read the flag before `red` is reused
-      if (!last) continue;
-      if (t == 0) atomicExch(&ep.sk_counters[cidx], 0);  // leave the counter ready for the next launch
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                rs, theirs + ((((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 16, 0, 16 /* sc1: bypass this XCD's L2 */);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] += bits_f32(v[e]);
-          }
-    }
-  }
 
   // ---- epilogue ---------------------------------------------------------------------------------
   T* out = reinterpret_cast<T*>(ep.out);
@@ -692,20 +714,18 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
         }
       }
   }
-  if constexpr (SK) __syncthreads();  // `red` and the staging area are free before the next segment starts
-  }  // segments of this workgroup's range
 }
 
 // upper bound of the number of M-blocks a launch uses (sizes the BatchNorm partial buffer)
 inline int igemm_grid_m(int M) { return cdiv(M, 128); }
 
-// Tile configuration.  MN_IGEMM_CONFIG (tuning knob, read once) overrides the per-shape choice:
+// Tile configurations (per-shape choice in launch_igemm; MN_IGEMM_CONFIG=1|8|12 forces one -- the parity tests use it to
+// run the 12-wave tile on small ragged problems):
 //   1: 128x128 / 128x64 (N <= 64), 4 waves of 64x64 / 64x32, 128-byte K-steps, 2 buffers   (2 workgroups/CU)
-//   2: 256x128, 8 waves of 64x64, 64-byte K-steps, 2 buffers
 //   8: 256x128, 4 waves of 128x64, 64-byte K-steps, 3 buffers                              (2 workgroups/CU)
-//  10: 256x256, 4 waves of 128x128, 64-byte K-steps, 3 buffers                             (1 workgroup/CU)
+//  12: 288x256, 12 waves of 96x64, 128-byte K-steps, 2 buffers                             (1 workgroup/CU)
 // Measured alternatives that lost everywhere and were removed: 3-4 workgroups/CU (64-byte steps), deeper rings,
-// 256x64 tiles for N = 64, 8-wave 256x256.
+// 256x64 tiles for N = 64, 8-wave 256x128 and 256x256 tiles, 256x256 tiles of 128x128 wave tiles, 576x128 tiles.
 inline int igemm_config() {
   static int v = -1;
   if (v < 0) {
@@ -715,53 +735,44 @@ inline int igemm_config() {
   return v;
 }
 
-// number of workgroups a stream-K launch uses: two per CU (the occupancy of the 128x128 configuration)
-inline int igemm_sk_blocks() {
+inline int device_cus() {  // compute units of the current device (256 on MI355X)
   static int v = 0;
   if (v == 0) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
-    v = 2 * cus;
+    v = cus;
   }
   return v;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI = true, bool ALLOW_SK = false,
-          bool SPL = false, int ABL = 0>
+template <typename T, int WM, int WN, int TM, int TN, int NP, int NBUF, int MINW, bool UNI = true, bool SPL = false, int ABL = 0>
 inline int launch_igemm_cfg(const GatherGeom& g, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
-                            const T* zero_page, int sk_blocks = 0) {
+                            const T* zero_page) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int gm = cdiv(g.M, BM), gn = cdiv(g.N, BN);
   RowDiv rd;
   rd.q = make_fastdiv(g.Q);
   rd.p = make_fastdiv(g.P);
-  if constexpr (sizeof(T) == 4 && NP % 4 == 0 && !ALLOW_SK && !SPL && ABL == 0 && WM == 2 && WN == 2 && TN <= 2) {  // (launch_igemm_x3's configurations)
+  if constexpr (sizeof(T) == 4 && NP % 4 == 0 && !SPL && WM == 2 && WN == 2 && TN <= 2) {  // (the x3 configurations)
     if (g.mma == MMA_F16X3) {
-      hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL, 0, MMA_F16X3>), dim3(gm * gn),
-                         dim3(WM * WN * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
+      hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, SPL, ABL, MMA_F16X3>), dim3(gm * gn),
+                         dim3(WM * WN * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd);
       return gm;
     }
     if (g.mma == MMA_BF16X3) {
-      hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL, 0, MMA_BF16X3>), dim3(gm * gn),
-                         dim3(WM * WN * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
+      hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, SPL, ABL, MMA_BF16X3>), dim3(gm * gn),
+                         dim3(WM * WN * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd);
       return gm;
     }
   }
-  if constexpr (UNI && ALLOW_SK) {
-    if (sk_blocks > 0 && sk_blocks < gm * gn && ep.sk_ws && ep.sk_counters) {
-      hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, true>), dim3(sk_blocks), dim3(WM * WN * 64), 0,
-                         stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
-      return gm;
-    }
-  }
-  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, false, SPL, ABL>), dim3(gm * gn), dim3(WM * WN * 64), 0,
-                     stream, g, A, Bw, ep, gn, zero_page, rd, gm * gn);
+  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, NP, NBUF, MINW, UNI, SPL, ABL>), dim3(gm * gn), dim3(WM * WN * 64), 0,
+                     stream, g, A, Bw, ep, gn, zero_page, rd);
   return gm;
 }
 
-// igemm_halo.h (experimental, MN_IGEMM_HALO=1|2): 288-row tiles with the A operand staged once per 64-channel chunk
+// igemm_halo.h: 288-row tiles with the A operand staged once per 64-channel chunk (fp16 3x3 stride-1 convolutions)
 inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
                              int level, bool tile288_wanted);
 template <typename T>
@@ -772,42 +783,21 @@ template <>
 inline int maybe_launch_igemm_halo<half>(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep,
                                          hipStream_t stream, bool tile288_wanted) {
   // measured on MI355X (round 2, same-box A/B of the whole step): level 0 17.34 ms, 1 (256-column shape: layer3) 17.03,
-  // 2 (+ 128-column shape: layers 2 and 4) 16.79; per launch layer2 114 -> 104, layer3 93 -> 81, layer4 112 -> 87 us
+  // 2 (+ 128-column shape: layers 2 and 4) 16.79; per launch layer2 114 -> 104, layer3 93 -> 81, layer4 112 -> 87 us.
+  // MN_IGEMM_HALO=0|1 (parity tests: the generic kernel on the same shapes)
   static const int level = getenv("MN_IGEMM_HALO") ? atoi(getenv("MN_IGEMM_HALO")) : 2;
   return level > 0 ? launch_igemm_halo(g, A, Bw, ep, stream, level, tile288_wanted) : -1;
-}
-
-// igemm_rt.h (MN_IGEMM_RT=1; 2 = also launches that do not fill two workgroups per CU): 256x128 tiles, 128x64 register
-// tiles per wave, chunk-resident A image
-inline bool igemm_rt_applies(const GatherGeom& g, const Epilogue& ep);
-inline int launch_igemm_rt(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream);
-template <typename T>
-inline int maybe_launch_igemm_rt(const GatherGeom&, const T*, const T*, const Epilogue&, hipStream_t) {
-  return -1;
-}
-template <>
-inline int maybe_launch_igemm_rt<half>(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep,
-                                       hipStream_t stream) {
-  static const int level = getenv("MN_IGEMM_RT") ? atoi(getenv("MN_IGEMM_RT")) : 0;
-  if (level <= 0 || !igemm_rt_applies(g, ep)) return -1;
-  // the shape runs two workgroups per CU: layer2 (1032 tiles at 192 images) fills them, layer4 (264 tiles) does not
-  if (level < 2 && (long)cdiv(g.M, 256) * (g.N / 128) < 512) return -1;
-  return launch_igemm_rt(g, A, Bw, ep, stream);
 }
 
 // returns the number of M-blocks used (= rows of the stats partial buffer that were written)
 template <typename T>
 inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const Epilogue& ep, hipStream_t stream,
-                        const T* zero_page, int sk_blocks = 0) {
+                        const T* zero_page) {
   constexpr int VEC = ElemTraits<T>::VEC;
   GatherGeom g = g_in;
-  // taps-fastest K order: layer3 data gradient 98 -> 92 us, with residual 117 -> 107, layer2 120 -> 117; MN_TAP_INNER=0
-  // restores the stored order
-  static const int tap_inner = getenv("MN_TAP_INNER") ? atoi(getenv("MN_TAP_INNER")) : 1;
-  g.tap_inner = ((tap_inner && g.R * g.S > 1) || g.bt_on) ? 1 : 0;
-  // split DMA issue (SPL): bit 0 = the 288x256 configuration (on: dgrad 95.8 -> 90.1 us, with residual 111.7 -> 103.6),
-  // bit 1 = the 128x128 configuration (off: 114 -> 120 us); MN_SPLIT_DMA overrides
-  static const int spl = getenv("MN_SPLIT_DMA") ? atoi(getenv("MN_SPLIT_DMA")) : 1;
+  // taps-fastest K order (all R*S taps of one 128-byte channel chunk before the next chunk): layer3 data gradient
+  // 98 -> 92 us, with residual 117 -> 107, layer2 120 -> 117
+  g.tap_inner = (g.R * g.S > 1 || g.bt_on) ? 1 : 0;
   const bool wide_k = (g.C / VEC) % 8 == 0;  // 128-byte K-steps need taps that are a multiple of them
   int cfg = igemm_config();
   if constexpr (sizeof(T) == 4) {
@@ -829,6 +819,23 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
         if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 1, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
         return launch_igemm_cfg<T, 2, 2, 2, 1, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
       }
+#ifdef MN_ABLATION_BUILD
+      if (wide_k) {
+        static const int abl = getenv("MN_ABLATE") ? atoi(getenv("MN_ABLATE")) : 0;
+        switch (abl) {
+          case 1: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 1>(g, A, Bw, ep, stream, zero_page);
+          case 2: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 2>(g, A, Bw, ep, stream, zero_page);
+          case 3: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 3>(g, A, Bw, ep, stream, zero_page);
+          case 4: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 4>(g, A, Bw, ep, stream, zero_page);
+          case 7: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 7>(g, A, Bw, ep, stream, zero_page);
+          case 8: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 8>(g, A, Bw, ep, stream, zero_page);
+          case 16: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 16>(g, A, Bw, ep, stream, zero_page);
+          case 24: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 24>(g, A, Bw, ep, stream, zero_page);
+          case 31: return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, 31>(g, A, Bw, ep, stream, zero_page);
+          default: break;
+        }
+      }
+#endif
       if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
       return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
     }
@@ -841,33 +848,13 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   // per-shape default (tools/conv_bench.py on MI355X, B = 192): 128x128 tiles, two workgroups per CU (512 slots);
   // when that leaves a few tiles over one full round (layer4: 528 tiles), 256x128 tiles with 128-row wave tiles
   // put every tile in a single round instead (103 vs 121 us)
-  // With a stream-K workspace: grids of 1..6 rounds that do not fill their last round are cut into equal ranges
-  // instead (sk_blocks > 0 forces it, for tests).
-  // Measured on MI355X (tools/quant_probe.py, SK=1): 1056 tiles 123 vs 120 us, 528 tiles 105 vs 103 us (256x128
-  // tiles), 2064 tiles 113 vs 118 us, whole step 19.8 vs 19.65 ms -- every extra segment pays a gather prologue and
-  // a pipeline fill, which eats what the balanced ranges save.  Off unless MN_STREAMK=1 (or sk_blocks is forced).
-  static const bool allow_sk = getenv("MN_STREAMK") && atoi(getenv("MN_STREAMK")) != 0;
-  if (ep.sk_ws && ep.sk_counters && g.N >= 128 && (cfg == 0 || cfg == 1) && (allow_sk || sk_blocks > 0) && !g.bt_on) {
-    const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
-    const int G = sk_blocks > 0 ? sk_blocks : igemm_sk_blocks();
-    const bool want = sk_blocks > 0 || (tiles128 > G && tiles128 < 6L * G && (tiles128 % G) * 8 < 7L * G);
-    if (want && tiles128 > G) {
-      if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, true>(g, A, Bw, ep, stream, zero_page, G);
-      return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2, true, true>(g, A, Bw, ep, stream, zero_page, G);
-    }
-  }
   if (cfg == 0) {
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
     cfg = (g.N >= 128 && g.N % 128 == 0 && tiles128 > 512 && tiles128 <= 640) ? 8 : 1;
     // 288x256 tiles when they cover the problem in ONE round of one workgroup per CU (layer3 at B = 192: 235 tiles
     // instead of 1056 128x128 tiles = 2.06 rounds of 512; 92 vs 110-118 us)
     const long tiles288 = (long)cdiv(g.M, 288) * cdiv(g.N, 256);
-    if (wide_k && g.N % 256 == 0 && tiles128 > 512 && tiles288 > 192 && tiles288 <= igemm_sk_blocks() / 2 && g.R * g.S <= 10)
-      cfg = 12;
-  }
-  if (!(cfg == 12 && wide_k && g.N % 256 == 0)) {
-    const int gm_rt = maybe_launch_igemm_rt<T>(g, A, Bw, ep, stream);
-    if (gm_rt >= 0) return gm_rt;
+    if (wide_k && g.N % 256 == 0 && tiles128 > 512 && tiles288 > 192 && tiles288 <= device_cus() && g.R * g.S <= 10) cfg = 12;
   }
   {
     const int gm_halo = maybe_launch_igemm_halo<T>(g, A, Bw, ep, stream, cfg == 12 && wide_k && g.N % 256 == 0);
@@ -881,29 +868,23 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   }
   if (cfg == 8 && g.N % 64 == 0)  // 256x128, 4 waves of 128x64, 64-byte K-steps, 3 buffers
     return launch_igemm_cfg<T, 2, 2, 4, 2, 4, 3, 2>(g, A, Bw, ep, stream, zero_page);
-  if (cfg == 10 && g.N >= 256 && g.N % 128 == 0)  // 256x256, 4 waves of 128x128 (one wave per SIMD)
-    return launch_igemm_cfg<T, 2, 2, 4, 4, 4, 3, 1>(g, A, Bw, ep, stream, zero_page);
-  // (measured and removed: 576x128 tiles, 12 waves (6x2) of 96x64, 64-byte K-steps, 3 buffers for N = 128 -- layer2 in
-  // 1.8 rounds of one workgroup per CU: 121 / 120 us vs 117 / 122 us)
-  if (cfg == 2) return launch_igemm_cfg<T, 4, 2, 2, 2, 4, 2, 4>(g, A, Bw, ep, stream, zero_page);  // 256x128, 8 waves
   // 288x256, 12 waves of 96x64, 128-byte K-steps, 2 buffers, one workgroup per CU: M = B*P*Q of the 256x341 input at
-  // B = 192 is 132 * 2^k, and 288-row tiles put layer3 (67584 rows, N = 256) on 235 of the 256 CUs in ONE round
+  // B = 192 is 132 * 2^k, and 288-row tiles put layer3 (67584 rows, N = 256) on 235 of the 256 CUs in ONE round.  The
+  // next tile's DMA instructions are issued behind the MFMAs of each sub-step (SPL: data gradient 95.8 -> 90.1 us, with
+  // residual 111.7 -> 103.6; the same change costs the 128x128 configuration 5 %, so it is not used there).
   if (cfg == 12 && wide_k && g.N % 256 == 0 && g.R * g.S <= 10) {  // (packed tap masks: 10 bits per A pass)
-
 #ifdef MN_ABLATION_BUILD
     static const int abl = getenv("MN_ABLATE") ? atoi(getenv("MN_ABLATE")) : 0;
-    if (abl == 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 1>(g, A, Bw, ep, stream, zero_page);
-    if (abl == 2) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 2>(g, A, Bw, ep, stream, zero_page);
-    if (abl == 3) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 3>(g, A, Bw, ep, stream, zero_page);
-    if (abl == 4) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 4>(g, A, Bw, ep, stream, zero_page);
-    if (abl == 7) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true, 7>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, true, 1>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 2) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, true, 2>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 3) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, true, 3>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 4) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, true, 4>(g, A, Bw, ep, stream, zero_page);
+    if (abl == 7) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, true, 7>(g, A, Bw, ep, stream, zero_page);
 #endif
-    if (spl & 1) return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, false, true>(g, A, Bw, ep, stream, zero_page);
-    return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3>(g, A, Bw, ep, stream, zero_page);
+    return launch_igemm_cfg<T, 3, 4, 3, 2, 8, 2, 3, true, true>(g, A, Bw, ep, stream, zero_page);
   }
   // (measured and removed: the same tile with 64-byte K-steps and FOUR buffers, i.e. three tiles in flight -- 99 vs 93 us
   // on layer3, so the ring depth is not what limits it; 288x128 tiles of 6 waves, two workgroups per CU -- 131 us)
-  if (wide_k && (spl & 2)) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2, true, false, true>(g, A, Bw, ep, stream, zero_page);
   if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
   return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
 }
@@ -911,4 +892,3 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
 }  // namespace mn
 
 #include "igemm_halo.h"
-#include "igemm_rt.h"

@@ -22,20 +22,17 @@ namespace mn {
 
 // Two shapes: <256, 352> (N in 256-column tiles, W <= 31: layer3) and <128, 384> (128-column tiles, W <= 47, 131 KB of
 // LDS: layer2 with its 43-pixel rows, and layer4, whose 16 896 rows give 59 x 4 = 236 tiles = one round of the chip).
-// NBS: slots of the B ring.  With 2 slots every K-step waits for the slice it requested one K-step earlier; with 3 slots
-// the slice of step kt+2 is requested at step kt and the waits are counted (two slices of DMA instructions stay in
-// flight).  Measured on MI355X for the 128-column shape (round 2): 3 slots are SLOWER -- layer2 109.8 vs 105.1 us, layer4
-// 92.0 vs 85.8 us, whole step 15.36 vs 15.27 ms -- so the request latency is not what bounds these launches; 2 is the default
-// (MN_IGEMM_HALO_NBS=3 selects the deeper ring).
-template <int BN, int kAH, int NBS = 2>
+// The B ring has TWO slots: every K-step waits for the slice it requested one K-step earlier.  (Measured and removed: three
+// slots with counted waits -- two slices of DMA instructions in flight -- are SLOWER for the 128-column shape, layer2 109.8
+// vs 105.1 us, layer4 92.0 vs 85.8 us, whole step 15.36 vs 15.27 ms: request latency is not what bounds these launches.)
+template <int BN, int kAH>
 static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
   constexpr int VEC = 8, NP = 8, WM = 3, WN = 4, TM = 3, TN = BN / 128, NT = 768;
   constexpr int BM = 288, WTM = 96, WTN = BN / WN, RPP = NT / NP;  // 96 rows per DMA pass
   static_assert(BN == 128 || BN == 256, "wave tiles of 96 x 32 or 96 x 64");
-  static_assert(NBS == 2 || NBS == 3, "B ring depth");
-  constexpr int A_IMG = kAH * NP, B_SLOT = BN * NP, RING = 2 * A_IMG + NBS * B_SLOT;  // pieces
+  constexpr int NBS = 2, A_IMG = kAH * NP, B_SLOT = BN * NP, RING = 2 * A_IMG + NBS * B_SLOT;  // pieces
   static_assert((RING + 1 + WM * BN / 2) * 16 <= 160 * 1024, "LDS");
   static_assert(RING * 16 >= 96 * 128 * 4, "epilogue staging (the ring is free by then)");
   constexpr int A_PASSES = (kAH + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;   // 4, 3
@@ -87,13 +84,6 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
       if (wave * (64 / NP) + j * RPP < BN)
         dma16(rsrc_b, b_off[j], soff, &smem[2 * A_IMG + (kt % NBS) * B_SLOT + j * RPP * NP + wave * 64]);
   };
-  // DMA instructions THIS wave issues per B slice / per image pass (the skips above are wave-uniform): what the counted
-  // waits of the 3-slot ring leave in flight
-  int nb_wave = 0;
-#pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) nb_wave += (wave * (64 / NP) + j * RPP < BN) ? 1 : 0;
-  auto a_count = [&](int chunk, int p) { return (p < A_PASSES && chunk + 1 < NCH && wave * (64 / NP) + p * RPP < kAH) ? 1 : 0; };
-
   // Fragment rows of this lane: tile-local row, its validity mask (bit tap set = outside the image, 9 bits per row tile)
   const int l31 = lane & 31, hi = lane >> 5;
   unsigned inv_mask = 0;  // [i] at bits 9i .. 9i+8
@@ -133,31 +123,11 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
     if (j < KT) issue_b(j);
 
   int chunk = 0, tap = 0, tr = 0, ts = 0;
-  int a_prev = 0;  // image-pass instructions this wave issued in the previous K-step (behind that step's B slice)
   for (int kt = 0; kt < KT; ++kt) {
-    if (NBS == 3 && kt + 1 < KT) {
-      // issued after slice kt: [image pass of step kt-2,] slice kt+1 [, image pass of step kt-1] -- slice kt (and the
-      // image of this chunk, requested during the previous chunk) has landed once at most those are outstanding.
-      // Counting the image pass of step kt-2 as well would be exact; leaving it out only waits for one instruction more.
-      const int n = nb_wave + a_prev;
-      if (n >= 3)
-        wait_vmcnt<3>();
-      else if (n == 2)
-        wait_vmcnt<2>();
-      else if (n == 1)
-        wait_vmcnt<1>();
-      else
-        wait_vmcnt<0>();
-    } else {
-      wait_vmcnt<0>();
-    }
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // this step's B slice (and any image pass in flight) landed; last step's reads are done
     if (kt + NBS - 1 < KT) issue_b(kt + NBS - 1);
-    a_prev = 0;
-    if (tap < A_PASSES && chunk + 1 < NCH) {
-      issue_a(chunk + 1, tap);
-      a_prev = a_count(chunk, tap);
-    }
+    if (tap < A_PASSES && chunk + 1 < NCH) issue_a(chunk + 1, tap);
     const piece_t* img = &smem[(chunk & 1) * A_IMG];
     const piece_t* tb = &smem[2 * A_IMG + (kt % NBS) * B_SLOT];
     const int shift = halo + (g.off_h + g.rsign * tr) * W + g.off_w + g.ssign * ts;  // scalar
@@ -332,11 +302,7 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
     return gm;
   }
   if (level >= 2 && igemm_halo_applies(g, ep, 128, 384)) {
-    static const int nbs = getenv("MN_IGEMM_HALO_NBS") ? atoi(getenv("MN_IGEMM_HALO_NBS")) : 2;  // B ring depth (2 | 3)
-    if (nbs != 3)
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 2>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
-    else
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 3>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
+    hipLaunchKernelGGL((igemm_halo_kernel<128, 384>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
     return gm;
   }
   return -1;

@@ -16,7 +16,6 @@
 #include "head.h"
 #include "igemm.h"
 #include "dgrad.h"
-#include "halo.h"
 #include "halo_pp.h"
 #include "layout.h"
 #include "optim.h"
@@ -104,30 +103,17 @@ struct KernelTimer {
   }
 };
 
-// One captured hipGraph per API segment (whole training step, or forward / backward stage / optimiser
-// when the host interleaves all-reduces).  The graph is keyed by everything the enqueued work bakes in
-// (data pointers, hyper-parameters); a key change re-captures, repeated changes fall back to eager launches.
-struct GraphSeg {
-  hipGraphExec_t exec = nullptr;
-  unsigned long long key = 0;
-  int captures = 0;
-};
-
 struct PlanBase {
   virtual ~PlanBase() {
-    // ROCm 7.2 workaround: graph execs that contain a fork/join are NOT destroyed, and the side stream is
-    // process-wide and never destroyed.  Destroying such an exec leaves the runtime with dangling references to
-    // the forked capture stream: a LATER graph launch (of another plan) then crashes in
-    // hip::Graph::UpdateStreams (reproduced: two plans trained and freed, a third one captured and launched;
-    // leaking either the execs or the stream avoids it).  The leak is a few hundred graph nodes per plan.
     for (hipEvent_t e : fork_events) hipEventDestroy(e);
     if (overflow_host) hipHostFree(overflow_host);
   }
+  // (one process-wide side stream per device, never destroyed: plans come and go, the stream is reused)
   static hipStream_t shared_side_stream() {
     static hipStream_t streams[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    // (a side stream of lower or higher priority was measured: no gain with direct launches, +1.5 ms inside a graph)
+    // (a side stream of lower or higher priority was measured: no gain)
     if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
       streams[dev] = nullptr;
       (void)hipGetLastError();
@@ -137,7 +123,7 @@ struct PlanBase {
   // Weight-gradient launches do not feed the data-gradient chain, so they run on a second stream: their
   // workgroups fill the CUs the tail of each data-gradient launch leaves idle (layers 3-4 at B = 192 have
   // 1056 / 528 tiles for 512 resident slots).  fork: wstream waits for everything enqueued on s so far;
-  // join: s waits for wstream.  Inside a stream capture the same calls become graph edges.
+  // join: s waits for wstream.
   hipStream_t wstream = nullptr;
   std::vector<hipEvent_t> fork_events;
   size_t fork_next = 0;
@@ -178,7 +164,7 @@ struct PlanBase {
   hipEvent_t loss_event = nullptr;
   bool loss_pending = false;
   void post_loss(const float* loss_dev_ptr, hipStream_t s) {
-    if (!loss_host || graphs_ok || s == nullptr) return;  // not inside a stream capture
+    if (!loss_host || s == nullptr) return;
     if (!loss_event && hipEventCreateWithFlags(&loss_event, hipEventDisableTiming) != hipSuccess) {
       loss_event = nullptr;
       (void)hipGetLastError();
@@ -188,54 +174,11 @@ struct PlanBase {
     hipEventRecord(loss_event, s);
     loss_pending = true;
   }
-  GraphSeg segs[8];
-  // hipGraph replay of the step is opt-in (MN_GRAPHS=1).  Measured on MI355X / ROCm 7.2 (tools/ab.sh): replaying the
-  // captured step is 2 % SLOWER than enqueueing its ~250 launches directly (19.57 vs 19.17 ms; the host enqueues a
-  // step in ~1.5 ms and stays a full step ahead of the device), forked branches overlap less inside a graph (early
-  // weight-gradient forks: +0.3 % in a graph, -2.4 % eager) and a side stream with a non-default priority costs a
-  // graph +1.5 ms.
-  bool graphs_ok = getenv("MN_GRAPHS") && atoi(getenv("MN_GRAPHS")) != 0;
-  unsigned long long fwd_key = 0;  // identity of the buffers the last training forward was issued on
-  unsigned long long hyper_version = 1;
-  template <typename F>
-  int run_segment(int seg, unsigned long long key, hipStream_t s, F&& body) {
-    // the legacy (null) stream cannot be captured; event-pair profiling needs eager launches
-    if (!graphs_ok || s == nullptr || timer.enabled) return body();
-    GraphSeg& gs = segs[seg];
-    key = key * 1099511628211ull + hyper_version;
-    if (gs.exec && gs.key == key) {
-      if (hipGraphLaunch(gs.exec, s) != hipSuccess) return fail("hipGraphLaunch failed");
-      return 0;
-    }
-    if (gs.captures >= 8) return body();  // arguments keep changing: stay eager
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
-      graphs_ok = false;
-      (void)hipGetLastError();
-      return body();
-    }
-    int rc = body();
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipStreamEndCapture(s, &graph);
-    if (rc != 0 || e != hipSuccess || !graph) {
-      if (graph) hipGraphDestroy(graph);
-      graphs_ok = false;
-      (void)hipGetLastError();
-      return rc != 0 ? rc : body();
-    }
-    gs.exec = nullptr;  // a superseded exec is leaked, see ~PlanBase
-    e = hipGraphInstantiate(&gs.exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    if (e != hipSuccess) {
-      gs.exec = nullptr;
-      graphs_ok = false;
-      (void)hipGetLastError();
-      return body();
-    }
-    gs.key = key;
-    gs.captures++;
-    if (hipGraphLaunch(gs.exec, s) != hipSuccess) return fail("hipGraphLaunch failed");
-    return 0;
-  }
+  // The step is enqueued DIRECTLY (~250 launches on two streams; the host needs ~1.5 ms per step and stays a full step
+  // ahead of the device).  Capturing it into a hipGraph and replaying it was implemented and measured in rounds 1-2 and
+  // removed in round 3: on ROCm 7.2 the replay was 2 % SLOWER than direct launches (19.57 vs 19.17 ms), forked branches
+  // overlapped less inside a graph (early weight-gradient forks: +0.3 % in a graph, -2.4 % eager), and destroying a graph
+  // exec that contains a fork/join crashed later graph launches in hip::Graph::UpdateStreams.
   virtual void after_optim_host() = 0;
   virtual int sync_step_to_device(hipStream_t s) = 0;
   virtual int64_t applied_steps() = 0;  // the device's count of optimiser steps that were applied (waits for the device)
@@ -275,7 +218,6 @@ struct PlanBase {
         if (cur_scale > 1.f) {
           cur_scale *= 0.5f;
           scale_set_at = attempts;
-          hyper_version++;
         } else {
           stuck_skips += seen - skipped_seen;  // non-finite values that no loss scale can fix (inputs, forward pass)
         }
@@ -287,7 +229,6 @@ struct PlanBase {
       if (cur_scale < 65536.f) {
         cur_scale *= 2.f;
         scale_set_at = attempts;
-        hyper_version++;
       }
     }
   }
@@ -351,13 +292,12 @@ struct Plan : PlanBase {
   // BatchNorm sums are accumulated with fp64 atomics straight from the producing kernels (conv epilogue, backward
   // reduction) into ACC_ROWS rows per unit (row = producer block % ACC_ROWS, to spread same-address contention);
   // the consuming apply kernels add the rows in their prologue.  No separate partial-reduction launches.
-  // (MN_ACC_ROWS: 8 by default)
   // MN_DETERMINISTIC=1: bit-reproducible training steps -- every floating-point sum the step takes is added in an order
   // that does not depend on scheduling: BatchNorm sums through one accumulator row per producing workgroup (below),
   // weight gradients through per-split workspace slices and an ordered reduction (conv_wgrad), the gradient norm through
   // per-workgroup partial sums (optim.h).  Costs ~x ms per step.
   const bool deterministic = getenv("MN_DETERMINISTIC") && atoi(getenv("MN_DETERMINISTIC")) != 0;
-  const int ACC_ROWS = getenv("MN_ACC_ROWS") && atoi(getenv("MN_ACC_ROWS")) > 0 ? atoi(getenv("MN_ACC_ROWS")) : 8;
+  static constexpr int ACC_ROWS = 8;  // (32 rows measured equal: 14.73 vs 14.69 ms per step)
   double* acc_region = nullptr;
   size_t acc_bytes = 0;
   int cur_training = 1;
@@ -373,8 +313,6 @@ struct Plan : PlanBase {
   unsigned char* pool_idx;  // winning tap of every max-pool window
   float* wgf_ws = nullptr;  // partial tiles of the fused weight gradient (wgrad_fused.h), shared by its launches (one stream)
   long wgf_ws_floats = 0;
-  float* sk_ws = nullptr;   // stream-K slabs [igemm_sk_blocks()][2][128*128] and
-  int* sk_counters = nullptr;  // arrival counters; zero between launches (igemm.h)
   void* zero_page;          // 256 zero bytes: source of out-of-image taps for the DMA conv pipeline
   long long* overflow_dev;  // {this step skipped, skipped steps in total} (adam_prep_kernel)
   long long* step_dev;      // device-resident Adam step counter
@@ -392,7 +330,7 @@ struct Plan : PlanBase {
       if (!deterministic) return;
       // one row per producing workgroup: every (row, channel) slot then receives exactly ONE atomic add onto zero, and the
       // finalize kernels add the rows in a fixed order.  Forward producers: the stem kernel's persistent workgroups, the
-      // 16x16-pixel tiles of the layer1 kernels (halo.h; halo_pp.h's <= 256 workgroups), M-tiles of >= 128 rows elsewhere.
+      // layer1 kernel's persistent workgroups (halo_pp.h: at most one per 16x16-pixel tile), M-tiles of >= 128 rows elsewhere.
       if (is_stem)
         u.rows_f = use_stem_kernel && DT == MN_F16 ? 1024 : cdiv((int)u.M, 128);
       else if (halo_path(u.gf))
@@ -480,8 +418,6 @@ struct Plan : PlanBase {
     wgf_ws_floats = DT == MN_F16 ? wgrad_fused_ws_floats(WGF_BLOCKS) : 0;
     if (deterministic && wgf_ws_floats < (16L << 20)) wgf_ws_floats = 16L << 20;  // split slices of the plain weight gradients
     wgf_ws = wgf_ws_floats ? (float*)A((size_t)wgf_ws_floats * 4) : nullptr;
-    sk_ws = (float*)A((size_t)igemm_sk_blocks() * 2 * 128 * 128 * 4);
-    sk_counters = (int*)A((size_t)igemm_sk_blocks() * 4);
     step_dev = (long long*)A(256);
     bc_dev = (float*)A(256);
     overflow_dev = (long long*)A(256);
@@ -673,23 +609,18 @@ struct Plan : PlanBase {
       ep.stats_accum = u.accum_f;
       ep.stats_rows = u.rows_f;
     }
-    ep.sk_ws = sk_ws;
-    ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
     if (&u == &stem && DT == MN_F16 && use_stem_kernel)  // weights in registers, input pairs read straight from LDS (stem.h)
       launch_stem_conv((const half*)x, (const half*)u.wf, (half*)u.y, training ? u.accum_f : nullptr, u.rows_f, B, H, W, Wp, s);
-    else if (halo_path(u.gf) && use_halo_pp && conv_halo_pp_applies(u.gf, ep))
+    else if (halo_path(u.gf) && conv_halo_pp_applies(u.gf, ep))
       launch_conv_halo_pp(u.gf, (const half*)x, (const half*)u.wf, ep, s);
-    else if (halo_path(u.gf))
-      launch_conv_halo(u.gf, (const half*)x, (const half*)u.wf, ep, s);
     else
       launch_igemm<T>(u.gf, x, u.wf, ep, s, (const T*)zero_page);
     timer.end(tp, s);
   }
-  // layer1's 64-channel 3x3 convolutions (forward and data gradient) run from an LDS-resident input halo (halo.h)
+  // layer1's 64-channel 3x3 convolutions (forward and data gradient) run from an LDS-resident input halo in the
+  // persistent two-group kernel of halo_pp.h (MN_HALO=0: the implicit-GEMM kernel, for A/B measurements)
   bool use_halo = DT == MN_F16 && !(getenv("MN_HALO") && atoi(getenv("MN_HALO")) == 0);
-  // ... in the persistent two-group form (halo_pp.h; MN_HALO_PP=0: one tile per workgroup, halo.h): 14.83 vs 15.08 ms / step
-  bool use_halo_pp = !(getenv("MN_HALO_PP") && atoi(getenv("MN_HALO_PP")) == 0);
   bool use_stem_kernel = !(getenv("MN_STEM_KERNEL") && atoi(getenv("MN_STEM_KERNEL")) == 0);
   bool halo_path(const GatherGeom& g) const { return use_halo && conv_halo_applies(g); }
   void bn_finalize(Unit& u, hipStream_t s) {  // statistics -> (scale, shift), mean / invstd, running statistics
@@ -796,17 +727,15 @@ struct Plan : PlanBase {
   void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s, bool self_gate = false) {
     launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
                      grads + u.bp.beta, u.gy, u.accum_b, u.coef_b, 1.f / cur_scale, s,
-                     (self_gate && self_gate_ok) ? params + u.bp.beta : nullptr, PoolGradSrc(), u.rows_b);
+                     self_gate ? params + u.bp.beta : nullptr, PoolGradSrc(), u.rows_b);
   }
   // bit 0: BatchNorm+ReLU+max-pool in one forward pass (-0.15 ms/step); bit 1: max-pool gradient gathered inside the
   // BatchNorm backward passes instead of a maxpool_bwd launch (measured +0.05 ms/step: the gather runs twice) -- off
   int fuse_stem_mask = getenv("MN_FUSE_STEM") ? atoi(getenv("MN_FUSE_STEM")) : 1;
   bool fuse_stem = (fuse_stem_mask & 1) != 0;
   bool fuse_stem_bwd = (fuse_stem_mask & 2) != 0;
-  bool self_gate_ok = !(getenv("MN_SELF_GATE") && atoi(getenv("MN_SELF_GATE")) == 0);
   bool early_fork = !(getenv("MN_EARLY_FORK") && atoi(getenv("MN_EARLY_FORK")) == 0);
-  bool pregate = !(getenv("MN_PREGATE") && atoi(getenv("MN_PREGATE")) == 0);
-  bool parity_dgrad = !(getenv("MN_PARITY_DGRAD") && atoi(getenv("MN_PARITY_DGRAD")) == 0);
+  static constexpr bool parity_dgrad = true;  // stride-2 data gradients by parity class (dgrad.h: -1.6 % step time)
   // `ws`: the stream the launch goes to (the side stream after a fork, or the main stream)
   void conv_wgrad(Unit& u, const T* x, hipStream_t ws) {
     WgradArgs a;
@@ -827,13 +756,9 @@ struct Plan : PlanBase {
     ep.out = gx; ep.ldc = u.cp.cin; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = res; ep.res_gate = gate;
     ep.out_gate = out_gate;
     ep.alpha = 1.f;
-    ep.sk_ws = sk_ws;
-    ep.sk_counters = sk_counters;
     auto* tp = timer.begin(0, s);
-    if (halo_path(u.dg.full) && use_halo_pp && conv_halo_pp_applies(u.dg.full, ep))
+    if (halo_path(u.dg.full) && conv_halo_pp_applies(u.dg.full, ep))
       launch_conv_halo_pp(u.dg.full, (const half*)u.gy, (const half*)u.wd, ep, s);
-    else if (halo_path(u.dg.full))
-      launch_conv_halo(u.dg.full, (const half*)u.gy, (const half*)u.wd, ep, s);
     else
       launch_conv_dgrad<T>(u.dg, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page, parity_dgrad);
     timer.end(tp, s);
@@ -863,8 +788,8 @@ struct Plan : PlanBase {
   // path of this block use `gout` as it is and never read `out`.
   void block_backward(Block& blk, hipStream_t s) {
     // the gate of the block below = ReLU that produced this block's input (none below layer1.0: its input is the max-pool)
-    const T* below = (!pregate || &blk == &blocks.front()) ? nullptr : blk.x;
-    const T* og = pregate ? nullptr : blk.out;  // MN_PREGATE=0: the consumers read the gate themselves
+    const T* below = &blk == &blocks.front() ? nullptr : blk.x;
+    const T* og = nullptr;  // (bn2 / the projection / the identity path take `gout` as stored: already gated)
     if (wgrad_sched == 2) {
       flush_wgrads(s);
       bn_bwd(blk.u2, blk.gout, og, s);
@@ -930,7 +855,7 @@ struct Plan : PlanBase {
     launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s, (const float*)zero_page);
     Block& last = blocks.back();
     hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
-                       (const float*)dpooled, last.gout, B, Hl * Wl, 512, pregate ? (const T*)last.out : (const T*)nullptr);
+                       (const float*)dpooled, last.gout, B, Hl * Wl, 512, (const T*)last.out);
   }
   // (MN_DETERMINISTIC: the stem's backward goes through bn_bwd + the split-slice weight gradient instead)
   bool use_stem_bwd = DT == MN_F16 && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
@@ -1033,7 +958,7 @@ struct Plan : PlanBase {
   }
 
   // ---- optimiser -----------------------------------------------------------------------------------
-  // host-side effects of an optimiser step (also applied when the step was replayed from a graph)
+  // host-side effects of an optimiser step
   void after_optim_host() override {
     step += 1;
     weights_dirty = true;
@@ -1162,16 +1087,12 @@ extern "C" int mn_set_learn_flags(mn_handle* h, int learn_beta, int learn_gamma)
 extern "C" int mn_set_optim(mn_handle* h, float lr, float weight_decay, float beta1, float beta2, float eps,
                             float max_grad_norm) {
   MN_H(h);
-  if (P.lr != lr || P.wd != weight_decay || P.beta1 != beta1 || P.beta2 != beta2 || P.eps != eps ||
-      P.max_grad_norm != max_grad_norm)
-    P.hyper_version++;  // captured graphs bake these in
   P.lr = lr; P.wd = weight_decay; P.beta1 = beta1; P.beta2 = beta2; P.eps = eps; P.max_grad_norm = max_grad_norm;
   return 0;
 }
 extern "C" int mn_set_optim_method(mn_handle* h, int method, int nesterov) {
   MN_H(h);
   if (method < 0 || method > 2) return fail("set_optim_method: method must be 0 (adam), 1 (sgd) or 2 (rmsprop)");
-  if (P.optim_method != method || P.nesterov != nesterov) P.hyper_version++;
   P.optim_method = method;
   P.nesterov = nesterov ? 1 : 0;
   return 0;
@@ -1191,7 +1112,7 @@ extern "C" int mn_set_loss_host(mn_handle* h, float* pinned_host) {
 extern "C" int mn_wait_loss(mn_handle* h) {
   if (!h || !h->plan) return -1;
   PlanBase& P = *h->plan;
-  if (!P.loss_pending) return 1;  // nothing was posted (graph replay, default stream): read the device scalar instead
+  if (!P.loss_pending) return 1;  // nothing was posted (default stream): read the device scalar instead
   P.loss_pending = false;
   if (hipEventSynchronize(P.loss_event) != hipSuccess) {
     (void)hipGetLastError();
@@ -1215,7 +1136,6 @@ extern "C" int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval)
   MN_H(h);
   if (!(scale > 0.f)) return fail("mn_set_loss_scale: scale must be positive");
   if (P.cfg.dtype != MN_DTYPE_F16 && scale != 1.f) return fail("mn_set_loss_scale: fp32 plans do not scale the loss");
-  if (P.cur_scale != scale) P.hyper_version++;
   P.cur_scale = scale;
   P.scale_set_at = P.attempts;
   P.scale_growth_interval = growth_interval;
@@ -1235,8 +1155,6 @@ extern "C" int mn_set_input_u8(mn_handle* h, int enable, const float* mean, cons
       P.input_norm.scale[c] = 1.f / (255.f * std[c]);
       P.input_norm.shift[c] = -mean[c] / std[c];
     }
-  if (P.input_u8 != (enable != 0)) P.hyper_version++;  // captured graphs bake the conversion kernel in
-  P.hyper_version += enable ? 1 : 0;                     // ... and its constants
   P.input_u8 = enable != 0;
   return 0;
 }
@@ -1253,18 +1171,15 @@ extern "C" int mn_train_forward_loss(mn_handle* h, const void* images, const flo
   MN_H(h);
   P.timer.reset();
   hipStream_t s = (hipStream_t)stream;
-  unsigned long long key = (unsigned long long)(uintptr_t)images * 31 + (unsigned long long)(uintptr_t)targets * 17 +
-                           (unsigned long long)(uintptr_t)loss_out * 13 + (unsigned long long)(uintptr_t)poses_out;
   P.weights_dirty = true;  // a training forward always follows an optimiser step or a parameter load
   P.poll_overflow();
-  P.fwd_key = key;
-  return P.run_segment(1, key, s, [&] { return P.forward_loss(images, targets, loss_out, poses_out, s); });
+  return P.forward_loss(images, targets, loss_out, poses_out, s);
 }
 extern "C" int mn_train_backward_stage(mn_handle* h, int stage, void* stream) {
   MN_H(h);
   if (stage < 0 || stage > 3) return fail("backward_stage: stage must be 0..3");
   hipStream_t s = (hipStream_t)stream;
-  return P.run_segment(2 + stage, P.fwd_key, s, [&] { return P.backward_stage(stage, s); });
+  return P.backward_stage(stage, s);
 }
 extern "C" int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t* count) {
   MN_H(h);
@@ -1276,9 +1191,7 @@ extern "C" int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t*
 extern "C" int mn_optim_step(mn_handle* h, float grad_mul, void* stream) {
   MN_H(h);
   hipStream_t s = (hipStream_t)stream;
-  unsigned key;
-  memcpy(&key, &grad_mul, sizeof(key));
-  int rc = P.run_segment(6, key, s, [&] { return P.optim_step(grad_mul, s); });
+  int rc = P.optim_step(grad_mul, s);
   if (rc == 0) P.after_optim_host();
   return rc;
 }
@@ -1287,19 +1200,13 @@ extern "C" int mn_train_step(mn_handle* h, const void* images, const float* targ
   MN_H(h);
   hipStream_t s = (hipStream_t)stream;
   P.timer.reset();
-  unsigned long long key = (unsigned long long)(uintptr_t)images * 31 + (unsigned long long)(uintptr_t)targets * 17 +
-                           (unsigned long long)(uintptr_t)loss_out * 13 + (unsigned long long)(uintptr_t)poses_out;
   P.weights_dirty = true;  // a training step always follows an optimiser step or a parameter load
   P.poll_overflow();
-  int rc = P.run_segment(0, key, s, [&]() -> int {
-    auto* tp = P.timer.begin(3, s);
-    if (int e = P.forward_loss(images, targets, loss_out, poses_out, s)) return e;
-    for (int st = 3; st >= 0; --st)
-      if (int e = P.backward_stage(st, s)) return e;
-    int r = P.optim_step(1.f, s);
-    P.timer.end(tp, s);
-    return r;
-  });
+  auto* tp = P.timer.begin(3, s);
+  int rc = P.forward_loss(images, targets, loss_out, poses_out, s);
+  for (int st = 3; st >= 0 && rc == 0; --st) rc = P.backward_stage(st, s);
+  if (rc == 0) rc = P.optim_step(1.f, s);
+  P.timer.end(tp, s);
   if (rc == 0) P.after_optim_host();
   return rc;
 }

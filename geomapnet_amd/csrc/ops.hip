@@ -9,7 +9,6 @@
 #include "head.h"
 #include "igemm.h"
 #include "dgrad.h"
-#include "halo.h"
 #include "halo_pp.h"
 #include "optim.h"
 #include "pgo.h"
@@ -78,38 +77,6 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   return check_launch("igemm");
 }
 
-extern "C" int mn_op_conv_halo(const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc, float* stats,
-                              const float* bias, int relu, const void* res, const void* res_gate, const void* out_gate,
-                              float alpha, void* stream) {
-  begin_call();
-  GatherGeom g = to_geom(gg);
-  if (int e = check_geom(g, MN_F16)) return e;
-  if (!conv_halo_applies(g)) return fail("conv_halo: fp16 3x3 stride-1 same-size convolutions of 64 input channels only");
-  Epilogue ep;
-  ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
-  ep.out_gate = out_gate; ep.alpha = alpha;
-  launch_conv_halo(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream);
-  return check_launch("conv_halo");
-}
-extern "C" int mn_op_conv_halo_grid_m(const mn_gather_geom* gg) { return conv_halo_grid_m(to_geom(gg)); }
-
-extern "C" int mn_op_igemm_rt(const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc, float* stats,
-                             double* stats_accum, int stats_rows, int relu, const void* res, const void* res_gate,
-                             const void* out_gate, float alpha, void* stream) {
-  begin_call();
-  GatherGeom g = to_geom(gg);
-  if (int e = check_geom(g, MN_F16)) return e;
-  Epilogue ep;
-  ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = nullptr; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
-  ep.out_gate = out_gate; ep.alpha = alpha; ep.stats_accum = stats_accum; ep.stats_rows = stats_rows;
-  if (!igemm_rt_applies(g, ep))
-    return fail("igemm_rt: fp16 3x3 stride-1 same-size convolutions, C % 64 == 0, N % 128 == 0, image width <= 47, at most one gate, "
-                "no residual / gates together with statistics");
-  launch_igemm_rt(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream);
-  return check_launch("igemm_rt");
-}
-extern "C" int mn_op_igemm_rt_grid_m(const mn_gather_geom* gg) { return cdiv(to_geom(gg).M, 256); }
-
 extern "C" int mn_op_conv_halo_pp(const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc, double* stats_accum,
                                  int stats_rows, int relu, const void* res, const void* res_gate, const void* out_gate,
                                  float alpha, int wgs, void* stream) {
@@ -123,25 +90,6 @@ extern "C" int mn_op_conv_halo_pp(const mn_gather_geom* gg, const void* A, const
     return fail("conv_halo_pp: fp16 3x3 stride-1 same-size convolutions of 64 -> 64 channels only (stats_rows > 0 with stats_accum)");
   launch_conv_halo_pp(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, wgs);
   return check_launch("conv_halo_pp");
-}
-
-extern "C" int mn_op_igemm_streamk(int dtype, const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc,
-                                   float* stats, const float* bias, int relu, const void* res, const void* res_gate,
-                                   float alpha, float* ws, int* counters, int blocks, void* stream) {
-  begin_call();
-  GatherGeom g = to_geom(gg);
-  if (int e = check_geom(g, dtype)) return e;
-  if (!ws || !counters || blocks < 1) return fail("igemm_streamk: workspace, counters and blocks >= 1 are required");
-  const int VEC = dtype == MN_DTYPE_F16 ? 8 : 4;
-  if (g.N < 128 || (g.C / VEC) % 4 != 0) return fail("igemm_streamk: needs N >= 128 and C a multiple of the K-step");
-  Epilogue ep;
-  ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
-  ep.alpha = alpha; ep.sk_ws = ws; ep.sk_counters = counters;
-  if (dtype == MN_F16)
-    launch_igemm<half>(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, (const half*)nullptr, blocks);
-  else
-    launch_igemm<float>(g, (const float*)A, (const float*)Bw, ep, (hipStream_t)stream, (const float*)nullptr, blocks);
-  return check_launch("igemm_streamk");
 }
 
 static int op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,

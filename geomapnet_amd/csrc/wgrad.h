@@ -702,35 +702,20 @@ struct WgradDma<half> {
   static void go(const WgradArgs& a, dim3 grid, int bmo, int bno, hipStream_t stream, const half* zp) {
     dim3 block(256);
     const GatherGeom& g = a.g;
-    static const bool allow_fast = !(getenv("MN_WGRAD_FAST") && atoi(getenv("MN_WGRAD_FAST")) == 0);
-    const bool fast = allow_fast && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&
-                      g.R * g.S <= 16 && g.P * g.Q <= WG_TBL && g.P * g.Q >= BKM && g.C % 8 == 0 &&
-                      (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l;
-    // transpose reads from inline assembly with hand-placed waits (ASMRD above); measured on MI355X (round 2): layer1
-    // 189 -> 155 us, layer2 140 -> 122, layer3 144 -> 124, layer4 129 -> 117; MN_WGRAD_TR_ASM=0 restores the builtin reads
-    static const bool tr_asm = !(getenv("MN_WGRAD_TR_ASM") && atoi(getenv("MN_WGRAD_TR_ASM")) == 0);
-    {
-      if (fast && tr_asm) {
-        if (bmo == 64 && bno == 64)
-          hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
-        else if (bmo == 64)
-          hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
-        else if (bno == 64)
-          hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
-        else
-          hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
-        return;
-      }
-    }
+    const bool fast = g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi && g.R * g.S <= 16 &&
+                      g.P * g.Q <= WG_TBL && g.P * g.Q >= BKM && g.C % 8 == 0 && (long)g.M * a.ldy * 2 < 0xfffffff0l &&
+                      (long)g.M * g.C * 2 < 0xfffffff0l;
+    // fast form: transpose reads from inline assembly with hand-placed waits (ASMRD above); measured on MI355X (round 2):
+    // layer1 189 -> 155 us, layer2 140 -> 122, layer3 144 -> 124, layer4 129 -> 117 against the builtin reads
     if (fast) {
       if (bmo == 64 && bno == 64)
-        hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW, true>), grid, block, 0, stream, a, zp);
+        hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
       else if (bmo == 64)
-        hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW, true>), grid, block, 0, stream, a, zp);
+        hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
       else if (bno == 64)
-        hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW, true>), grid, block, 0, stream, a, zp);
+        hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
       else
-        hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW, true>), grid, block, 0, stream, a, zp);
+        hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
       return;
     }
     if (bmo == 64 && bno == 64)
@@ -746,13 +731,9 @@ struct WgradDma<half> {
     const half* zp = reinterpret_cast<const half*>(zero_page);
     if (!zp || (a.rows_per_split % 64) != 0) return false;
     dim3 grid(grid3.x * grid3.y * grid3.z);  // 1-D: the kernel derives (cout tile, k tile, split) itself
-    // measured on MI355X (tools/conv_bench.py): 32-row steps with registers capped for 4 blocks/CU beat
-    // 64-row steps at 2 blocks/CU on every 3x3 layer; MN_WGRAD_VARIANT=0 selects the latter (tuning knob)
-    static const int variant = getenv("MN_WGRAD_VARIANT") ? atoi(getenv("MN_WGRAD_VARIANT")) : 1;
-    if (variant == 0)
-      go<64, 2>(a, grid, bmo, bno, stream, zp);
-    else
-      go<32, 4>(a, grid, bmo, bno, stream, zp);
+    // measured on MI355X (tools/conv_bench.py): 32-row steps with registers capped for 4 blocks/CU beat 64-row steps at
+    // 2 blocks/CU on every 3x3 layer
+    go<32, 4>(a, grid, bmo, bno, stream, zp);
     return true;
   }
 };
@@ -786,8 +767,6 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
   const bool narrow_n = g.N <= 64, narrow_k = g.K <= 64 || (g.K % 128 != 0 && g.K < 256);
   int bmo = narrow_n ? 64 : 128, bno = narrow_k ? 64 : 128;
   int tiles = cdiv(g.N, bmo) * cdiv(g.K, bno);
-  static const int env_blocks = getenv("MN_WGRAD_BLOCKS") ? atoi(getenv("MN_WGRAD_BLOCKS")) : 0;  // tuning knob
-  if (env_blocks > 0) target_blocks = env_blocks;
   int splits = cdiv(target_blocks, tiles);
   int max_splits = cdiv(g.M, 512);  // at least 8 steps of 64 rows per block
   if (splits > max_splits) splits = max_splits;
@@ -808,7 +787,6 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
     a.split_stride = slice;
   }
   dim3 grid(cdiv(g.N, bmo), cdiv(g.K, bno), splits), block(256);
-  static const bool use_dma = !(getenv("MN_WGRAD_DMA") && atoi(getenv("MN_WGRAD_DMA")) == 0);
   if (sizeof(T) == 4 && g.mma == MMA_BF16X3) {
     if constexpr (sizeof(T) == 4) {
       if (bmo == 64 && bno == 64)
@@ -820,7 +798,7 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
       else
         hipLaunchKernelGGL((wgrad_x3_kernel<128, 128>), grid, block, 0, stream, a);
     }
-  } else if (use_dma && WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) {
+  } else if (WgradDma<T>::launch(a, grid, bmo, bno, stream, zero_page)) {
   } else if (bmo == 64 && bno == 64)
     hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, block, 0, stream, a);
   else if (bmo == 64)

@@ -341,14 +341,9 @@ inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
 inline long wgrad_fused_ws_floats(int blocks) { return (long)blocks * 64 * 9 * 64; }
 constexpr int WGF_BLOCKS = 512;  // workgroups per launch: two per CU (the register budget), i.e. one round of the chip
 
-inline int wgrad_fused_waves() {  // 8 (default): one 512-thread workgroup per CU with in-workgroup split-K; 4: two 256-thread ones
-  static const int nw = getenv("MN_WGF_WAVES") ? atoi(getenv("MN_WGF_WAVES")) : 8;
-  return nw == 4 ? 4 : 8;
-}
-
 inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream) {
   const GatherGeom& g = w.g;
-  const int NW = wgrad_fused_waves(), BKM = 8 * NW;
+  constexpr int NW = 8, BKM = 8 * NW;  // (the 4-wave form -- two 256-thread workgroups per CU, twice the partial tiles -- is not launched)
   WgradFusedArgs a;
   a.dY = reinterpret_cast<const half*>(w.dY);
   a.X = reinterpret_cast<const half*>(w.X);
@@ -372,16 +367,14 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   // pixel ranges: one round of resident workgroups (two 4-wave or one 8-wave workgroup per CU), each range at least 8
   // halos long (the ring prologue fetches 2 Gpad + D steps of rows that belong to the neighbouring ranges)
   const int pairs = a.tiles_n * a.tiles_c;
-  static const int env_blocks = getenv("MN_WGF_BLOCKS") ? atoi(getenv("MN_WGF_BLOCKS")) : 0;  // tuning knob
   (void)target_blocks;  // the plain-GEMM form's split count; this kernel wants exactly one round of resident workgroups
-  int chunks = cdiv(env_blocks > 0 ? env_blocks : (NW == 8 ? WGF_BLOCKS / 2 : WGF_BLOCKS), pairs);
+  int chunks = cdiv(NW == 8 ? WGF_BLOCKS / 2 : WGF_BLOCKS, pairs);
   const int min_chunk = 16 * a.Gpad;
   if ((long)chunks * min_chunk > a.J) chunks = (int)(a.J / min_chunk);
   if (chunks < 1) chunks = 1;
   a.chunk = cdiv(cdiv(a.J, chunks), BKM) * BKM;
   a.nchunks = cdiv(a.J, a.chunk);
-  static const bool use_ws = !(getenv("MN_WGF_WS") && atoi(getenv("MN_WGF_WS")) == 0);
-  if (use_ws && w.ws && (long)a.nchunks * a.N * 9 * a.C <= w.ws_floats) a.ws = w.ws;
+  if (w.ws && (long)a.nchunks * a.N * 9 * a.C <= w.ws_floats) a.ws = w.ws;
   static const bool trace = getenv("MN_TRACE_DISPATCH") != nullptr;
   if (trace)
     fprintf(stderr, "wgrad_fused<%d waves>: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows, ws %d\n", NW,
@@ -389,7 +382,7 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   const dim3 grid(a.nchunks * pairs), block(NW * 64);
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
-  if (NW == 8) {
+  {
     switch (abl) {
       case 1: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 1>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
       case 2: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 2>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
@@ -400,15 +393,8 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
     }
   }
 #endif
-  static const int pd = getenv("MN_WGF_PD") ? atoi(getenv("MN_WGF_PD")) : 4;  // B fragments requested ahead (tuning knob)
-  if (NW == 4)
-    hipLaunchKernelGGL((wgrad_fused_kernel<4, D>), grid, block, 0, stream, a);
-  else if (pd == 2)
-    hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 0, 2>), grid, block, 0, stream, a);
-  else if (pd >= 6)
-    hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 0, 6>), grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL((wgrad_fused_kernel<8, D>), grid, block, 0, stream, a);
+  // (B-fragment read-ahead PD = 2 / 4 / 6 and DMA depth 1-3 measured equal once the item is four instructions; PD = 4, D = 3)
+  hipLaunchKernelGGL((wgrad_fused_kernel<8, D>), grid, block, 0, stream, a);
   wgrad_fused_reduce(a, stream);
 }
 

@@ -53,7 +53,7 @@ def train_step(engine, plan, images, targets):
     if "poses" not in plan:
         plan["poses"] = torch.empty(plan["images"], 6, dtype=torch.float32, device=engine.device)
     side = engine.step_stream()
-    if side is not None:  # side stream: lets the library capture each stage into a hipGraph
+    if side is not None:  # the step runs on the engine's own stream (ordered after the caller's)
         cur = torch.cuda.current_stream(engine.device)
         side.wait_stream(cur)
         ctx = torch.cuda.stream(side)
@@ -70,8 +70,6 @@ def train_step(engine, plan, images, targets):
 
 def _staged_step(engine, plan, images, targets, lib, h, s):
     import ctypes as C
-    if s is not None:
-        images, targets = engine.stable_inputs(plan, images, targets)
     poses = plan["poses"]
     lib.check(lib.train_forward_loss(h, ptr(images), ptr(targets), ptr(plan["loss"]), ptr(poses), s))
     grads = engine.grads()

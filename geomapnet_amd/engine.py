@@ -260,34 +260,15 @@ class Engine:
             self.lib.check(self.lib.set_learn_flags(h, int(flags[0]), int(flags[1])))
             p["flags"] = flags
 
-    # -- training steps run on a side stream with persistent I/O buffers so the library can capture the
-    #    whole step into a hipGraph (the legacy default stream cannot be captured; a graph bakes pointers in)
+    # -- training steps run on a stream of the engine's own, ordered after the caller's current stream and joined back
+    #    into it: the library forks weight-gradient work onto a second (non-blocking) stream, which the legacy default
+    #    stream's implicit synchronisation would serialise
     def step_stream(self):
         if not self.params.is_cuda:
             return None
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
-
-    def stable_inputs(self, p, images, targets):
-        """the caller's tensors when they are the same storage as last step, else persistent copies"""
-        out = []
-        for name, t in (("images", images), ("targets", targets)):
-            last = p.get("last_" + name)
-            if last is not None and last.data_ptr() == t.data_ptr() and last.shape == t.shape:
-                out.append(t)
-                continue
-            if p.get("seen_" + name):  # second distinct tensor: switch to the persistent staging buffer
-                buf = p.get("buf_" + name)
-                if buf is None or buf.shape != t.shape:
-                    buf = p["buf_" + name] = torch.empty_like(t)
-                buf.copy_(t, non_blocking=True)
-                out.append(buf)
-            else:
-                p["seen_" + name] = True
-                p["last_" + name] = t
-                out.append(t)
-        return out
 
     def train_step(self, p, images, targets):
         if "poses" not in p:
@@ -303,7 +284,6 @@ class Engine:
         cur = torch.cuda.current_stream(self.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            images, targets = self.stable_inputs(p, images, targets)
             self.lib.check(self.lib.train_step(p["handle"], ptr(images), ptr(targets), ptr(p["loss"]), ptr(p["poses"]),
                                                C.c_void_p(side.cuda_stream)))
             poses = p["poses"].clone()

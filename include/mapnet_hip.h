@@ -200,12 +200,6 @@ int mn_op_igemm(int dtype, const mn_gather_geom* g, const void* A, const void* B
                 const float* bias, int relu, const void* res, const void* res_gate, float alpha, const void* zero_page,
                 void* stream);
 int mn_op_igemm_grid_m(int M);
-/* The same operator with the stream-K schedule (igemm.h): `blocks` workgroups share the (tile, K-step) iteration
- * space in equal ranges; ws: fp32 scratch [blocks][2][128*128]; counters: int32 [blocks], zero on entry and zero
- * again on return.  Requires N >= 128 and C a multiple of the K-step; falls back to whole tiles when blocks >= tiles. */
-int mn_op_igemm_streamk(int dtype, const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
-                        const float* bias, int relu, const void* res, const void* res_gate, float alpha, float* ws,
-                        int32_t* counters, int blocks, void* stream);
 /* dW[n][colmap(k)] += alpha * sum_m dY[m][n] * gather(X)[m][k]  (fp32 atomics into dW) */
 int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw,
                 const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream);
@@ -216,27 +210,13 @@ int mn_op_wgrad(int dtype, const mn_gather_geom* g, const void* dY, int ldy, con
 int64_t mn_op_wgrad_ws_floats(void);
 int mn_op_wgrad_ws(int dtype, const mn_gather_geom* g, const void* dY, int ldy, const void* X, float* dW, int ldw, float alpha,
                    float* ws, int64_t ws_floats, const void* zero_page, void* stream);
-/* fp16 3x3 stride-1 same-size convolution of 64 input channels (ResNet layer1 forward, and -- with the mirrored
- * geometry rsign = ssign = -1 -- its data gradient) with the 18x18-pixel input halo of a 16x16-pixel output tile staged
- * once in LDS and the taps walked as address offsets (csrc/halo.h); same operands and epilogue as mn_op_igemm plus
- * out_gate (result zeroed where out_gate <= 0).  stats: [mn_op_conv_halo_grid_m(g)][2][N] partial column sums or NULL. */
-int mn_op_conv_halo(const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
-                    const float* bias, int relu, const void* res, const void* res_gate, const void* out_gate, float alpha,
-                    void* stream);
-int mn_op_conv_halo_grid_m(const mn_gather_geom* g);
-/* fp16 3x3 stride-1 same-size convolution (forward or, with the mirrored geometry, data gradient) of C % 64 == 0 input
- * and N % 128 == 0 output channels on maps at most 47 pixels wide, with 256 x 128 tiles and 128 x 64 register tiles per wave
- * (csrc/igemm_rt.h: ResNet layer2).  Operands and epilogue as mn_op_conv_halo (no bias; at most one gate; statistics --
- * stats: [mn_op_igemm_rt_grid_m(g)][2][N] partial column sums, or stats_accum: [stats_rows][2][N] fp64 sums added to
- * atomically -- only without residual / gates). */
-int mn_op_igemm_rt(const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
-                   double* stats_accum, int stats_rows, int relu, const void* res, const void* res_gate,
-                   const void* out_gate, float alpha, void* stream);
-int mn_op_igemm_rt_grid_m(const mn_gather_geom* g);
-/* The same convolution for exactly 64 output channels in the persistent form (csrc/halo_pp.h): one 8-wave workgroup per
- * CU, two wave groups alternating between the MFMA loop of one tile and the epilogue + next halo fetch of another, all
- * nine weight slices LDS-resident.  stats_accum: [stats_rows][2][64] fp64 column sums (sum, sum of squares), ADDED to
- * atomically, or NULL.  wgs: number of persistent workgroups, 0 = one per CU. */
+/* fp16 3x3 stride-1 same-size convolution of 64 -> 64 channels (ResNet layer1 forward, and -- with the mirrored geometry
+ * rsign = ssign = -1 -- its data gradient) from an LDS-resident 18x18-pixel input halo per 16x16-pixel output tile, as a
+ * persistent kernel (csrc/halo_pp.h): one 8-wave workgroup per CU, two wave groups alternating between the MFMA loop of one
+ * tile and the epilogue + next halo fetch of another, all nine weight slices LDS-resident.  Operands and epilogue as
+ * mn_op_igemm plus out_gate (result zeroed where out_gate <= 0; at most one of res_gate / out_gate).  stats_accum:
+ * [stats_rows][2][64] fp64 column sums (sum, sum of squares), ADDED to atomically, or NULL (only without residual / gates).
+ * wgs: number of persistent workgroups, 0 = one per CU. */
 int mn_op_conv_halo_pp(const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, double* stats_accum,
                        int stats_rows, int relu, const void* res, const void* res_gate, const void* out_gate, float alpha,
                        int wgs, void* stream);

@@ -24,17 +24,6 @@ def test_conv_forward(lib, dtype, shape):
     checks.check_conv_fwd(lib, DEV, dtype, *shape)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("shape,blocks", [
-    ((4, 16, 16, 64, 128, 3), 3),     # 8 tiles x 9..18 K-steps over 3 workgroups: cuts inside tiles
-    ((5, 16, 16, 128, 256, 3), 7),    # 20 tiles over 7 workgroups
-    ((3, 12, 11, 64, 128, 1), 2),     # ragged M (396 rows), one K-step per tile at fp16: cuts only at tile borders
-    ((2, 16, 16, 64, 128, 3), 9),     # more workgroups than tiles: whole-tile schedule
-])
-def test_conv_stream_k(lib, dtype, shape, blocks):
-    checks.check_conv_streamk(lib, DEV, dtype, *shape, blocks=blocks)
-
-
 @pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1),
@@ -127,47 +116,6 @@ def test_pose_graph_properties(lib):
 @pytest.mark.parametrize("parity", [1, 0])
 def test_conv_data_gradient_op(lib, dtype, shape, mode, parity):
     checks.check_conv_dgrad_op(lib, DEV, dtype, *shape, parity=parity, mode=mode)
-
-
-@pytest.mark.parametrize("case", [
-    (2, 16, 16, 64, False, "plain"),     # one full tile per image
-    (1, 20, 22, 64, False, "plain"),     # ragged in both directions: 2 x 2 tiles, masks in the statistics
-    (2, 9, 11, 128, False, "plain"),     # smaller than a tile, two N tiles
-    (1, 20, 22, 64, True, "res_gate"),   # data gradient with the gated identity path
-    (2, 17, 16, 64, True, "out_gate"),
-    (1, 16, 35, 72, True, "plain"),      # N not a multiple of 64
-])
-def test_conv_halo(lib, case):
-    B, H, W, Cout, dgrad, mode = case
-    checks.check_conv_halo(lib, DEV, B, H, W, Cout=Cout, dgrad=dgrad, mode=mode)
-
-
-@pytest.mark.parametrize("case", [
-    (2, 16, 16, False, "plain", 0),      # one tile per workgroup: phases 0 and 1 only
-    (1, 20, 22, False, "plain", 1),      # four ragged tiles walked by ONE workgroup (both groups, five phases)
-    (2, 33, 20, False, "plain", 3),      # 12 tiles over 3 workgroups, statistics across tiles
-    (1, 20, 22, True, "res_gate", 1),
-    (2, 17, 35, True, "out_gate", 2),    # 12 tiles over 2 workgroups
-    (1, 9, 11, True, "plain", 0),        # smaller than a tile
-])
-def test_conv_halo_pp(lib, case):
-    """persistent two-group form of the layer1 convolution (csrc/halo_pp.h)"""
-    B, H, W, dgrad, mode, wgs = case
-    checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=dgrad, mode=mode, pp_wgs=wgs)
-
-
-@pytest.mark.parametrize("case", [
-    (1, 9, 13, 64, 128, False, "plain", "rows"),      # one ragged tile, one chunk
-    (2, 12, 23, 128, 128, False, "plain", "accum"),   # three M tiles (552 rows), two chunks: image reload
-    (1, 20, 43, 64, 256, False, "plain", "none"),     # layer2's row width, two N tiles
-    (2, 12, 23, 128, 128, True, "out_gate", "none"),
-    (1, 17, 47, 64, 128, True, "res_gate", "none"),   # widest supported rows
-    (1, 12, 23, 192, 128, True, "plain", "none"),     # three chunks
-])
-def test_igemm_rt(lib, case):
-    """256 x 128 tiles with 128 x 64 register tiles per wave (csrc/igemm_rt.h)"""
-    B, H, W, Cin, Cout, dgrad, mode, stats = case
-    checks.check_igemm_rt(lib, DEV, B, H, W, Cin, Cout, dgrad=dgrad, mode=mode, stats=stats)
 
 
 def _random_cases(seed, n):

@@ -43,46 +43,6 @@ def test_conv_data_gradient(lib, dtype, shape):
     checks.check_conv_dgrad(lib, DEV, dtype, *shape)
 
 
-@pytest.mark.parametrize("case", [
-    (2, 16, 16, 64, False, "plain"), (1, 20, 22, 64, False, "plain"), (2, 9, 11, 128, False, "plain"),
-    (1, 20, 22, 64, True, "res_gate"), (2, 17, 16, 64, True, "out_gate"), (1, 16, 35, 72, True, "plain"),
-    (6, 64, 86, 64, False, "plain"),     # layer1 geometry at 256x341
-    (6, 64, 86, 64, True, "out_gate"),
-    (6, 64, 86, 64, True, "res_gate"),
-])
-def test_conv_halo(lib, case):
-    B, H, W, Cout, dgrad, mode = case
-    checks.check_conv_halo(lib, DEV, B, H, W, Cout=Cout, dgrad=dgrad, mode=mode)
-
-
-@pytest.mark.parametrize("case", [
-    (2, 16, 16, False, "plain", 0), (1, 20, 22, False, "plain", 1), (2, 33, 20, False, "plain", 3),
-    (1, 20, 22, True, "res_gate", 1), (2, 17, 35, True, "out_gate", 2), (1, 9, 11, True, "plain", 0),
-    (6, 64, 86, False, "plain", 0),      # layer1 geometry at 256x341: 144 tiles
-    (6, 64, 86, False, "plain", 7),      # ... 20-21 tiles per workgroup
-    (6, 64, 86, True, "out_gate", 16),
-    (6, 64, 86, True, "res_gate", 5),
-])
-def test_conv_halo_pp(lib, case):
-    """persistent two-group form of the layer1 convolution (csrc/halo_pp.h)"""
-    B, H, W, dgrad, mode, wgs = case
-    checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=dgrad, mode=mode, pp_wgs=wgs)
-
-
-@pytest.mark.parametrize("case", [
-    (1, 9, 13, 64, 128, False, "plain", "rows"), (2, 12, 23, 128, 128, False, "plain", "accum"),
-    (1, 20, 43, 64, 256, False, "plain", "none"), (2, 12, 23, 128, 128, True, "out_gate", "none"),
-    (1, 17, 47, 64, 128, True, "res_gate", "none"), (1, 12, 23, 192, 128, True, "plain", "none"),
-    (12, 32, 43, 128, 128, False, "plain", "accum"),   # layer2 geometry at 256x341: 65 M tiles
-    (12, 32, 43, 128, 128, True, "out_gate", "none"),
-    (16, 8, 11, 512, 512, True, "res_gate", "none"),   # layer4 geometry: eight chunks, four N tiles
-])
-def test_igemm_rt(lib, case):
-    """256 x 128 tiles with 128 x 64 register tiles per wave (csrc/igemm_rt.h)"""
-    B, H, W, Cin, Cout, dgrad, mode, stats = case
-    checks.check_igemm_rt(lib, DEV, B, H, W, Cin, Cout, dgrad=dgrad, mode=mode, stats=stats)
-
-
 @pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape,mode", [
     ((2, 8, 11, 64, 128, 3, 2, 1), "plain"), ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"), ((1, 8, 12, 64, 128, 3, 2, 1), "res_gate"),
@@ -95,15 +55,6 @@ def test_igemm_rt(lib, case):
 @pytest.mark.parametrize("parity", [1, 0])
 def test_conv_data_gradient_op(lib, dtype, shape, mode, parity):
     checks.check_conv_dgrad_op(lib, DEV, dtype, *shape, parity=parity, mode=mode)
-
-
-@pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("shape,blocks", [
-    ((4, 16, 16, 64, 128, 3), 3), ((5, 16, 16, 128, 256, 3), 7), ((3, 12, 11, 64, 128, 1), 2), ((2, 16, 16, 64, 128, 3), 9),
-    ((33, 16, 22, 256, 256, 3), 64),   # 182 tiles over 64 workgroups
-])
-def test_conv_stream_k(lib, dtype, shape, blocks):
-    checks.check_conv_streamk(lib, DEV, dtype, *shape, blocks=blocks)
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
@@ -176,11 +127,8 @@ def test_mapnet_train_step_fp32_parity_stem_variants(lib, monkeypatch, mask):
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=1, loss_rtol=1e-4, pose_atol=2e-3)
 
 
-def test_mapnet_train_step_fp32_parity_graph_replay(lib, monkeypatch):
-    """MN_GRAPHS=1: the step captured into a hipGraph (first step) and replayed (second step) -- opt-in; also with one
-    weight-gradient fork per block"""
-    monkeypatch.setenv("MN_GRAPHS", "1")
-    checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+def test_mapnet_train_step_fp32_parity_one_weight_gradient_fork_per_block(lib, monkeypatch):
+    """MN_EARLY_FORK=0: one weight-gradient fork per block instead of the deferred schedule"""
     monkeypatch.setenv("MN_EARLY_FORK", "0")
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
 

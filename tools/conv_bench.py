@@ -56,10 +56,6 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
         t_ws = timeit(lambda: lib.op_wgrad_ws(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, one, ptr(WS), WS.numel(), ptr(checks.zero_page("cuda")), None))
         print("%-22s wgrad through the workspace %7.1f us %6.0f TF" % (name, t_ws, flops / t_ws / 1e6), flush=True)
     if dtype == 1 and Ci == 64 and k == 3 and stride == 1:
-        th_f = timeit(lambda: lib.op_conv_halo(C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, None, 0, None, None, None, one, None))
-        th_d = timeit(lambda: lib.op_conv_halo(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, None, one, None)) if Co == 64 else float("nan")
-        th_r = timeit(lambda: lib.op_conv_halo(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), None, ptr(gate), one, None)) if Co == 64 else float("nan")
-        print("%-22s halo kernel: fwd %7.1f us %6.0f TF | dgrad %7.1f us | +res+out_gate %7.1f us" % (name, th_f, flops / th_f / 1e6, th_d, th_r), flush=True)
         if Co == 64:  # persistent two-group form (halo_pp.h); CB_PP_WGS = workgroup counts to try
             acc = torch.zeros(8, 2, 64, dtype=torch.double, device="cuda")
             for wgs in [int(v) for v in os.environ.get("CB_PP_WGS", "0").split(",")]:
@@ -68,13 +64,6 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
                 tp_r = timeit(lambda: lib.op_conv_halo_pp(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, 0, 0, ptr(res), None, ptr(gate), one, wgs, None))
                 print("%-22s halo_pp wgs=%d: fwd+stats %7.1f us %6.0f TF | dgrad %7.1f us | +res+out_gate %7.1f us"
                       % (name, wgs, tp_f, flops / tp_f / 1e6, tp_d, tp_r), flush=True)
-    if dtype == 1 and k == 3 and stride == 1 and Ci % 64 == 0 and Co % 128 == 0 and W <= 47:  # 128x64 register tiles (igemm_rt.h)
-        acc = torch.zeros(8, 2, Co, dtype=torch.double, device="cuda")
-        tr_f = timeit(lambda: lib.op_igemm_rt(C.byref(g), ptr(x), ptr(w), ptr(y), Co, None, ptr(acc), 8, 0, None, None, None, one, None))
-        tr_d = timeit(lambda: lib.op_igemm_rt(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, 0, None, None, None, one, None))
-        tr_r = timeit(lambda: lib.op_igemm_rt(C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, 0, ptr(res), None, ptr(gate), one, None))
-        print("%-22s igemm_rt: fwd+stats %7.1f us %6.0f TF | dgrad %7.1f us %6.0f TF | +res+out_gate %7.1f us"
-              % (name, tr_f, flops / tr_f / 1e6, tr_d, flops / tr_d / 1e6, tr_r), flush=True)
     io = (x.numel() + y.numel()) * x.element_size()
     print("%-22s M=%8d N=%4d K=%5d  fwd %7.1f us %6.0f TF (io %5.2f TB/s) | dgrad %7.1f us %6.0f TF | +res %7.1f us | wgrad %7.1f us %6.0f TF"
           % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, io / t_f / 1e6, t_d, flops / t_d / 1e6, t_r, t_w, flops / t_w / 1e6), flush=True)

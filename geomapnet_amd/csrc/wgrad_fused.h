@@ -53,38 +53,41 @@ struct WgradFusedArgs {
 
 // LDS rows of the X ring: (D+1) steps + 2 Gpad; bounds the image width (Gpad <= 96 -> Q <= 94, i.e. inputs up to 376
 // pixels wide at layer1).  4-wave form: 32-row steps; 8-wave form: 64-row steps.
-constexpr int WGF_RING_MAX4 = 320, WGF_RING_MAX8 = 448;
+constexpr int WGF_RING_MAX8 = 448;
 
-// NW = 4: 256 threads, 32-pixel steps, two workgroups per CU.
-// NW = 8: 512 threads, 64-pixel steps, one workgroup per CU; waves 0-3 and 4-7 hold the SAME 64 x 9 x 64 output tile and
-//         split every step's pixels between them (rows 0-31 / 32-63) -- split-K inside the workgroup.  At the end the two
-//         halves are added through LDS, so a CU flushes ONE partial tile instead of two: the partial-tile volume of a
-//         launch (what the reduce launch has to read back) is the number of resident accumulator tiles x 147 KB,
-//         75 MB at two workgroups per CU, 38 MB here.
+// 8 waves = 512 threads, 64-pixel steps, one workgroup per CU.  Wave roles: 32-column block of the 64 input channels (wc),
+// pixel half of every step (grp: rows 0-31 / 32-63 -- split-K inside the workgroup: at the end the two halves are added
+// through LDS, so a CU flushes ONE partial tile; the partial-tile volume of a launch, what the reduce launch has to read
+// back, is the number of resident accumulator tiles x 147 KB = 38 MB) and tap half (tset: taps 0-4 or 5-8).  A wave owns
+// BOTH 32-row blocks of the 64 output channels for its taps, so a B fragment (X rows at the tap's shift) feeds TWO MFMAs:
+// 1.4 fragment-read instructions per MFMA and one address add + one counted wait per two MFMAs.  Waves w and w + 4 (one
+// SIMD) hold the 5-tap and the 4-tap half: 18 MFMAs per SIMD per K sub-step.
+// (Round 2's form gave a wave one output-channel block for all nine taps -- a B fragment per MFMA, 2.2 read instructions
+// per MFMA.  Same time per launch in isolation, 101-109 us at every layer, so the loop is NOT issue-bound as round 2
+// concluded; the whole step runs 0.8 % faster with this form beside the other stream's kernels, 14.45 vs 14.60 ms,
+// profiles/r03/c8_*.  A 4-wave form -- two 256-thread workgroups per CU, twice the partial tiles -- was slower and is gone.)
 // ABL (timing experiments only, MN_WGF_ABLATE in the ablation build; results are wrong): bit 0 = no DMA after the prologue,
 // bit 1 = no B-fragment reads, bit 2 = no MFMA, bit 3 = no stores / atomics.
-// PD: B fragments requested ahead of the MFMA that consumes them.
-// The K loop is issue-bound, not MFMA- or LDS-bound (round-2 ablations: removing the MFMAs changed nothing): one item is
-// ONE vector add (scalar ring base + per-lane tap offset), two transpose reads, one counted wait and one MFMA.  No item
-// ever wraps around the ring: the 32/64 rows behind the ring mirror its first block (the DMA that fills block 0 is issued
-// twice), so a tap window that starts near the end simply runs on into the mirror.
-template <int NW, int D, int ABL = 0, int PD = 4>
-static __global__ void __launch_bounds__(NW * 64, 2) wgrad_fused_kernel(WgradFusedArgs a) {
-  static_assert(NW == 4 || NW == 8, "one or two wave groups");
+// PD: B fragments requested ahead of the MFMAs that consume them.
+// No item ever wraps around the ring: the 64 rows behind the ring mirror its first block (the DMA that fills block 0 is
+// issued twice), so a tap window that starts near the end simply runs on into the mirror.
+template <int D, int ABL = 0, int PD = 3>
+static __global__ void __launch_bounds__(512, 2) wgrad_fused_kernel(WgradFusedArgs a) {
+  constexpr int NW = 8;
   static_assert(D >= 1 && D <= 3, "steps in flight");
   constexpr int BKM = 8 * NW;              // pixels per step = one DMA pass of all threads per operand
   constexpr int ROWH = 64;                 // halves per LDS row (64 channels / 64 output channels)
   constexpr int TILE_Y = BKM * ROWH;       // halves
   constexpr int NY = D + 1;                // dY tiles
-  constexpr int RING_MAX = NW == 4 ? WGF_RING_MAX4 : WGF_RING_MAX8;
+  constexpr int RING_MAX = WGF_RING_MAX8;
   // ONE LDS object: [NY dY tiles][X ring (RING rows used)][mirror of ring rows 0 .. BKM-1, right behind row RING-1]
   __shared__ half smem[NY * TILE_Y + (RING_MAX + BKM) * ROWH] __attribute__((aligned(16)));
   half* ring = &smem[NY * TILE_Y];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2, wg = wave & 3;  // pixel half of every step; role inside the group
-  const int wn = wg >> 1, wc = wg & 1;       // 32-row block of the 64 output channels, 32-column block of the 64 inputs
+  const int wc = wave & 1, grp = (wave >> 1) & 1, tset = wave >> 2;  // 32-column block of the 64 inputs; pixel half; tap half
+  const int tap0 = tset * 5, ntap = tset == 0 ? 5 : 4;
   // logical id = (chunk, pair): the pairs of one pixel range are adjacent, i.e. on one XCD, and share its L2 lines
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int pairs = a.tiles_n * a.tiles_c;
@@ -127,11 +130,13 @@ static __global__ void __launch_bounds__(NW * 64, 2) wgrad_fused_kernel(WgradFus
     if (rr == 0) dma16(rsrc_x, off, 0u, ring + RING * ROWH + wave * 64 * 8);
   };
 
-  floatx16 acc[9];
+  floatx16 acc[2][5];  // [32-row block of the output channels][tap slot: tap = tap0 + slot]
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
+  for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][i][r] = 0.f;
 
   // transpose-read lane geometry (wgrad.h): 16-lane group gq -> column block (gq & 1) * 16, k half (gq >> 1) * 8; as a
   // SOURCE lane this lane addresses row lrow = kgrp + (lane & 15) / 4 and the 8-byte chunk (lane & 3) of its column block
@@ -139,21 +144,26 @@ static __global__ void __launch_bounds__(NW * 64, 2) wgrad_fused_kernel(WgradFus
   const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
   const int lrow = grp * 32 + (gq >> 1) * 8 + src_row;  // + this wave group's half of the step
   const unsigned lds0 = lds_addr_of(smem);
-  // A operand (dY tile): row lrow, column wn*32 + src_chunk; the swizzle sees row & 3 = src_row
-  const int colA = wn * 32 + src_chunk;
-  const unsigned aA = lds0 + (unsigned)((lrow * ROWH + (((colA >> 3) ^ wg_swz<8>(src_row)) * 8) + (colA & 7)) * 2);
+  // A operand (dY tile): row lrow, column nb*32 + src_chunk; the swizzle sees row & 3 = src_row
+  unsigned aA[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int colA = nb * 32 + src_chunk;
+    aA[nb] = lds0 + (unsigned)((lrow * ROWH + (((colA >> 3) ^ wg_swz<8>(src_row)) * 8) + (colA & 7)) * 2);
+  }
   // B operand (X ring), tap tp: byte address = ring + rbB[tp] (scalar: first row of the tap's window, advanced per step)
   // + xoffB[tp] (lane: row lrow, column with the swizzle of (window start + src_row) & 3 -- window starts move in
   // multiples of 4, so the key is loop invariant per tap) + an immediate for the K sub-step
   const int colB = wc * 32 + src_chunk;
-  unsigned xoffB[9];
-  int rbB[9];
+  unsigned xoffB[5];
+  int rbB[5];
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
+  for (int sl = 0; sl < 5; ++sl) {
+    const int tp = tap0 + (sl < ntap ? sl : ntap - 1);  // (the 4-tap half re-reads its last tap in slot 4: no MFMA follows)
     const int sh = Gpad + (tp / 3 - 1) * a.Qp + (tp % 3 - 1);  // in [0, 2 Gpad] < RING
     const int key = (sh + src_row) & 3;
-    xoffB[tp] = lds0 + (unsigned)((NY * TILE_Y + lrow * ROWH + ((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
-    rbB[tp] = sh * (ROWH * 2);
+    xoffB[sl] = lds0 + (unsigned)((NY * TILE_Y + lrow * ROWH + ((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
+    rbB[sl] = sh * (ROWH * 2);
   }
   const int ring_bytes = RING * ROWH * 2;
 
@@ -181,107 +191,117 @@ static __global__ void __launch_bounds__(NW * 64, 2) wgrad_fused_kernel(WgradFus
       issue_y(s + D);
       issue_x(2 * Gpad + BKM * (s + D));
     }
-    const unsigned tyA = aA + (unsigned)((s % NY) * TILE_Y * 2);
-    // One step = 18 (K sub-step, tap) items per wave, each one MFMA fed by the A fragment of that sub-step and a B
-    // fragment read at the tap's row shift.  B fragments travel through a ring of PD + 1 register buffers: item i + PD is
-    // requested right before the MFMA of item i (its buffer was last used by item i - 1, whose MFMA has been issued).
-    constexpr int NKS = 2, ITEMS = NKS * 9, NB = PD + 1;
-    static_assert(2 * PD <= 15, "lgkmcnt field");
-    TrFrag fa[NKS], fb[NB];
+    const unsigned tyoff = (unsigned)((s % NY) * TILE_Y * 2);
+    // One step = 10 (K sub-step, tap slot) items per wave, each TWO MFMAs (both output-channel blocks) fed by the A
+    // fragments of that sub-step and ONE B fragment read at the tap's row shift.  B fragments travel through a ring of
+    // PD + 1 register buffers: item i + PD is requested right before the MFMAs of item i.
+    constexpr int NKS = 2, ITEMS = NKS * 5, NB = PD + 1;
+    static_assert(2 * PD + 4 <= 15, "lgkmcnt field");
+    TrFrag fa[NKS][2], fb[NB];
     __builtin_amdgcn_sched_barrier(0);
     static_for<NKS>([&](auto KS) {
       constexpr int ks = decltype(KS)::value;
-      fa[ks].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, tyA);
-      fa[ks].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, tyA);
+      static_for<2>([&](auto NBk) {
+        constexpr int nb = decltype(NBk)::value;
+        fa[ks][nb].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, aA[nb] + tyoff);
+        fa[ks][nb].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, aA[nb] + tyoff);
+      });
     });
     auto read_b = [&](auto I, TrFrag& f) {
-      constexpr int it = decltype(I)::value, ks = it / 9, tp = it % 9;
+      constexpr int it = decltype(I)::value, ks = it / 5, sl = it % 5;
       if constexpr ((ABL & 2) != 0) {
-        f.h[0] = fa[ks].h[1];
-        f.h[1] = fa[ks].h[0];
+        f.h[0] = fa[ks][0].h[1];
+        f.h[1] = fa[ks][0].h[0];
         return;
       }
-      const unsigned ad = xoffB[tp] + (unsigned)rbB[tp];
+      const unsigned ad = xoffB[sl] + (unsigned)rbB[sl];
       f.h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, ad);
       f.h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, ad);
     };
     static_for<(PD < ITEMS ? PD : ITEMS)>([&](auto I) { read_b(I, fb[decltype(I)::value % NB]); });
     static_for<ITEMS>([&](auto I) {
-      constexpr int it = decltype(I)::value, ks = it / 9, tp = it % 9;
+      constexpr int it = decltype(I)::value, ks = it / 5, sl = it % 5;
       if constexpr (it + PD < ITEMS) read_b(StaticIndex<it + PD>{}, fb[(it + PD) % NB]);
       // LDS reads return in order: once at most the requests issued AFTER item `it` are outstanding (two per item), its
       // fragment -- and the A fragments, requested before every B fragment -- are in their registers
       constexpr int later = (ITEMS - 1 - it) < PD ? (ITEMS - 1 - it) : PD;
       wait_lgkmcnt_for<2 * later>(fb[it % NB]);
-      if constexpr (tp == 0) wait_lgkmcnt_for<2 * later>(fa[ks]);
+      if constexpr (sl == 0) {
+        wait_lgkmcnt_for<2 * later>(fa[ks][0]);
+        wait_lgkmcnt_for<2 * later>(fa[ks][1]);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr ((ABL & 4) == 0)
-        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks].v, fb[it % NB].v, acc[tp], 0, 0, 0);
-      else
-        asm volatile("" ::"v"(fa[ks].v), "v"(fb[it % NB].v));
+      if (sl < 4 || tset == 0) {  // wave-uniform: slot 4 of the 4-tap half carries no MFMA
+        if constexpr ((ABL & 4) == 0) {
+          acc[0][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][0].v, fb[it % NB].v, acc[0][sl], 0, 0, 0);
+          acc[1][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][1].v, fb[it % NB].v, acc[1][sl], 0, 0, 0);
+        } else {
+          asm volatile("" ::"v"(fa[ks][0].v), "v"(fa[ks][1].v), "v"(fb[it % NB].v));
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     // the tap windows move on by one step (scalar)
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      rbB[tp] += BKM * ROWH * 2;
-      rbB[tp] -= rbB[tp] >= ring_bytes ? ring_bytes : 0;
+    for (int sl = 0; sl < 5; ++sl) {
+      rbB[sl] += BKM * ROWH * 2;
+      rbB[sl] -= rbB[sl] >= ring_bytes ? ring_bytes : 0;
     }
   }
 
-  int tp_lo = 0, tp_hi = 9;  // taps this wave flushes
-  if constexpr (NW == 8) {
-    // the two wave groups hold partial sums of the same tile: group 1 hands taps 0-4 to group 0, group 0 hands taps 5-8
-    // to group 1 (through LDS, lane-contiguous), then each flushes its share
+  // the two pixel groups hold partial sums of the same tiles: group 1 hands its block-0 tiles to group 0, group 0 hands its
+  // block-1 tiles to group 1 (through LDS, lane-contiguous), then each flushes the block it collected
+  {
     float* xch = reinterpret_cast<float*>(smem);
     static_assert((NY * TILE_Y + (RING_MAX + BKM) * ROWH) * 2 >= 4 * 5 * 16 * 64 * 4, "exchange buffer");
+    const int pr = wc + 2 * tset;  // the (column block, tap half) pair this wave shares with its partner of the other group
     __syncthreads();  // every fragment read of the K loop is done
     if (grp == 1) {
 #pragma unroll
-      for (int tp = 0; tp < 5; ++tp)
+      for (int sl = 0; sl < 5; ++sl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xch[((wg * 5 + tp) * 16 + r) * 64 + lane] = acc[tp][r];
+        for (int r = 0; r < 16; ++r) xch[((pr * 5 + sl) * 16 + r) * 64 + lane] = acc[0][sl][r];
     }
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
-      for (int tp = 0; tp < 5; ++tp)
+      for (int sl = 0; sl < 5; ++sl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tp][r] += xch[((wg * 5 + tp) * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[0][sl][r] += xch[((pr * 5 + sl) * 16 + r) * 64 + lane];
     }
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
-      for (int tp = 5; tp < 9; ++tp)
+      for (int sl = 0; sl < 5; ++sl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xch[((wg * 4 + tp - 5) * 16 + r) * 64 + lane] = acc[tp][r];
+        for (int r = 0; r < 16; ++r) xch[((pr * 5 + sl) * 16 + r) * 64 + lane] = acc[1][sl][r];
     }
     __syncthreads();
     if (grp == 1) {
 #pragma unroll
-      for (int tp = 5; tp < 9; ++tp)
+      for (int sl = 0; sl < 5; ++sl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tp][r] += xch[((wg * 4 + tp - 5) * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[1][sl][r] += xch[((pr * 5 + sl) * 16 + r) * 64 + lane];
     }
-    tp_lo = grp == 0 ? 0 : 5;
-    tp_hi = grp == 0 ? 5 : 9;
   }
 
   // partial tile -> workspace slab of this pixel range (plain stores, summed in chunk order by the reduce kernel), or
   // fp32 atomics straight into dW[n][tap*C + c]
   const int K9 = 9 * a.C;
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
-    if (tp < tp_lo || tp >= tp_hi) continue;  // wave-uniform
+  for (int sl = 0; sl < 5; ++sl) {
+    if (sl >= ntap) continue;  // wave-uniform
+    const int tp = tap0 + sl;
     const int c = c0 + wc * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int n = n0 + grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float v = grp == 0 ? acc[0][sl][r] : acc[1][sl][r];
       if (n < a.N && c < a.C && (ABL & 8) == 0) {
         if (a.ws)
-          a.ws[((long)ci * a.N + n) * K9 + tp * a.C + c] = acc[tp][r];
+          a.ws[((long)ci * a.N + n) * K9 + tp * a.C + c] = v;
         else
-          unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[tp][r] * a.alpha);
+          unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, v * a.alpha);
       }
     }
   }
@@ -357,7 +377,7 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   a.tiles_n = cdiv(g.N, 64);
   a.tiles_c = cdiv(g.C, 64);
   a.Gpad = ((g.Q + 2 + 15) / 16) * 16;
-  if (NW == 8) a.Gpad = ((a.Gpad + 31) / 32) * 32;  // 2 Gpad must be a multiple of the 64-row DMA block
+  a.Gpad = ((a.Gpad + 31) / 32) * 32;  // 2 Gpad must be a multiple of the 64-row DMA block
   constexpr int D = 3;  // DMA steps in flight
   a.ring = (D + 1) * BKM + 2 * a.Gpad;
   a.dq = make_fastdiv(a.Qp);
@@ -368,7 +388,7 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   // halos long (the ring prologue fetches 2 Gpad + D steps of rows that belong to the neighbouring ranges)
   const int pairs = a.tiles_n * a.tiles_c;
   (void)target_blocks;  // the plain-GEMM form's split count; this kernel wants exactly one round of resident workgroups
-  int chunks = cdiv(NW == 8 ? WGF_BLOCKS / 2 : WGF_BLOCKS, pairs);
+  int chunks = cdiv(WGF_BLOCKS / 2, pairs);  // one 512-thread workgroup per CU
   const int min_chunk = 16 * a.Gpad;
   if ((long)chunks * min_chunk > a.J) chunks = (int)(a.J / min_chunk);
   if (chunks < 1) chunks = 1;
@@ -384,17 +404,17 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   static const int abl = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
   {
     switch (abl) {
-      case 1: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 1>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
-      case 2: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 2>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
-      case 4: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 4>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
-      case 8: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 8>), grid, block, 0, stream, a); return;
-      case 9: hipLaunchKernelGGL((wgrad_fused_kernel<8, D, 9>), grid, block, 0, stream, a); return;
+      case 1: hipLaunchKernelGGL((wgrad_fused_kernel<D, 1>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
+      case 2: hipLaunchKernelGGL((wgrad_fused_kernel<D, 2>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
+      case 4: hipLaunchKernelGGL((wgrad_fused_kernel<D, 4>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return;
+      case 8: hipLaunchKernelGGL((wgrad_fused_kernel<D, 8>), grid, block, 0, stream, a); return;
+      case 9: hipLaunchKernelGGL((wgrad_fused_kernel<D, 9>), grid, block, 0, stream, a); return;
       default: break;
     }
   }
 #endif
-  // (B-fragment read-ahead PD = 2 / 4 / 6 and DMA depth 1-3 measured equal once the item is four instructions; PD = 4, D = 3)
-  hipLaunchKernelGGL((wgrad_fused_kernel<8, D>), grid, block, 0, stream, a);
+  // (B-fragment read-ahead PD = 2 / 4 / 6 and DMA depth 1-3 measured equal in round 2; PD = 3, D = 3)
+  hipLaunchKernelGGL((wgrad_fused_kernel<D>), grid, block, 0, stream, a);
   wgrad_fused_reduce(a, stream);
 }
 

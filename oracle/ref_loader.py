@@ -58,7 +58,21 @@ def _load_pgo(all_lines, pose_utils, pose_utils_np):
         Rz = _np.array([[ck, -sk, 0], [sk, ck, 0], [0, 0, 1]])
         return Rz @ Ry @ Rx
 
-    from geomapnet_amd.data import mat2quat as _mat2quat
+    def _mat2quat(M):
+        """transforms3d.quaternions.mat2quat (dependency absent from /root/reference, version unpinned), restated from
+        its published definition (Bar-Itzhack 2000): the eigenvector of the largest eigenvalue of the symmetric 4x4 matrix
+        K built from the rotation matrix, reordered to (w, x, y, z), w >= 0.  Test infrastructure: deliberately NOT the
+        product's geomapnet_amd.data.mat2quat, so that the pin of the pose-graph oracle does not lean on the product."""
+        Qxx, Qyx, Qzx, Qxy, Qyy, Qzy, Qxz, Qyz, Qzz = _np.asarray(M, dtype=_np.float64).flat
+        K = _np.array([[Qxx - Qyy - Qzz, 0, 0, 0],
+                       [Qyx + Qxy, Qyy - Qxx - Qzz, 0, 0],
+                       [Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, 0],
+                       [Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz]]) / 3.0
+        vals, vecs = _np.linalg.eigh(K)
+        q = vecs[[3, 0, 1, 2], _np.argmax(vals)]
+        if q[0] < 0:
+            q *= -1
+        return q
 
     class _txq(_opgo.txq):
         mat2quat = staticmethod(_mat2quat)

@@ -1267,10 +1267,49 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
     return rec
 
 
+def check_loss_trajectory(lib, dev, N=8, H=256, W=341, steps=50, lr=1e-4, envelope=0.25):
+    """Does the fp16 build TRAIN like the parity mode?  Two HIP models (fp16 and fp32x3), identical initial weights and one
+    fixed batch, `steps` Adam steps each on the same device; the loss curves are compared point by point, relative to
+    the total descent of the fp32x3 curve.  (Single steps are pinned against the oracle elsewhere; steps after the first
+    can only be compared loosely -- Adam's first updates are sign-like and the random-init network amplifies any
+    difference ~30x per step, DESIGN.md section 6 -- so this is an envelope on the whole trajectory.)
+    Returns (fp16 losses, fp32x3 losses, largest pointwise gap / descent)."""
+    _fresh()
+    import geomapnet_amd as G
+    torch.manual_seed(7)
+    onet = oracle.MapNet(oracle.PoseNet(oracle.resnet34(), droprate=0.0, pretrained=False))
+    sd0 = {k: v.clone() for k, v in onet.state_dict().items()}
+    del onet
+    x, t = oracle.make_batch("mapnet", N, H, W, seed=7)
+    x, t = x.to(dev), t.to(dev)
+    curves = {}
+    for dtype_name in ("fp16", "fp32x3"):
+        G.set_compute_dtype(dtype_name)
+        net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, _binding=lib))
+        net.load_state_dict(sd0)
+        if torch.device(dev).type == "cuda":
+            net.cuda()
+        c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+        opt = G.Optimizer([{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}], "adam",
+                          base_lr=lr, weight_decay=5e-4)
+        net.train()
+        curves[dtype_name] = [G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)[0] for _ in range(steps)]
+        del net, c, opt
+    a, b = np.array(curves["fp16"]), np.array(curves["fp32x3"])
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    descent = b[0] - b.min()
+    assert descent > 0.5 * abs(b[0]), (b[0], b.min())  # the fixed batch is being fitted
+    gap = float(np.abs(a - b).max() / descent)
+    assert gap <= envelope, (gap, curves)
+    return curves["fp16"], curves["fp32x3"], gap
+
+
 def check_stem_bwd(lib, dev, B, H, W, seed=5):
     """stem backward in two launches (csrc/stem_bwd.h: BatchNorm sums with the max-pool gradient gathered on the fly, then the
-    weight gradient with d(conv output) computed in LDS) against the four-launch chain of the operators it replaces
-    (maxpool_bwd -> bn_bwd -> wgrad) on identical fp16 tensors: same arithmetic, same roundings"""
+    weight gradient with d(conv output) computed in LDS), two ways: (1) SELF-CONSISTENCY against the four-launch chain of
+    the operators it replaces (maxpool_bwd -> bn_bwd -> wgrad) on identical fp16 tensors -- same arithmetic, same
+    roundings, tight tolerance; (2) DIRECTLY against torch autograd in fp64 through maxpool(relu(batchnorm(y))) and the
+    convolution's weight gradient (d(weight), d(gamma), d(beta)) at the tolerance of the fp16 tensors involved"""
     _fresh()
     td = torch.float16
     gen = torch.Generator().manual_seed(seed)
@@ -1327,3 +1366,20 @@ def check_stem_bwd(lib, dev, B, H, W, seed=5):
     assert (dW - dW_ref).abs().max().item() <= 2e-4 * scale, ((dW - dW_ref).abs().max().item(), scale)
     np.testing.assert_allclose(dg.cpu().numpy(), dg_ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dg_ref.abs().max()))
     np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(db_ref.abs().max()))
+    # (2) torch fp64 on the same (fp16-representable) inputs: y is a leaf standing for the conv output
+    y64 = y.cpu().double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    g64 = gamma.cpu().double().requires_grad_(True)
+    b64 = beta.cpu().double().requires_grad_(True)
+    a64 = F.relu(F.batch_norm(y64, None, None, g64, b64, True, 0.0, 1e-5))
+    # the kernel's max-pool routes through the fp16-rounded activation (first maximum wins): pool the rounded values'
+    # argmax by using them for the comparison only -- ties between distinct fp64 values that round to one fp16 value are
+    # rare at this size and would show up as isolated outliers well above the tolerance below
+    p64 = F.max_pool2d(a64, 3, 2, 1)
+    p64.backward(gp.cpu().double().permute(0, 3, 1, 2).contiguous())
+    gy64 = y64.grad  # d(conv output)
+    dW64 = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), gy64, stride=2, padding=3) * alpha
+    dW_t = dW.cpu().double().reshape(64, 7, 7, 3).permute(0, 3, 1, 2)  # [64][r][s][c] -> OIHW
+    s64 = dW64.abs().max().item()
+    assert (dW_t - dW64).abs().max().item() <= 4e-3 * s64, ((dW_t - dW64).abs().max().item(), s64)
+    np.testing.assert_allclose(dg.cpu().double().numpy(), (g64.grad * alpha).numpy(), rtol=0, atol=4e-3 * float(g64.grad.abs().max() * alpha))
+    np.testing.assert_allclose(db.cpu().double().numpy(), (b64.grad * alpha).numpy(), rtol=0, atol=4e-3 * float(b64.grad.abs().max() * alpha))

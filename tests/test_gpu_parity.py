@@ -156,6 +156,19 @@ def test_mapnet_online_train_step_fp32x3_parity_clip_and_nan_filter(lib):
                             filter_nans=True, grad_l2_rtol=None)
 
 
+def test_fp16_loss_trajectory_tracks_the_parity_mode(lib):
+    """50 Adam steps on one fixed full-resolution batch (8 windows x T=3, 256x341), fp16 against fp32x3, both on the GPU:
+    the two loss curves stay within 25 % of the curve's total descent of each other at every step"""
+    l16, l32, gap = checks.check_loss_trajectory(lib, DEV, N=8, H=256, W=341, steps=50)
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "loss_trajectory_fp16_vs_fp32x3.json"), "w") as f:
+            json.dump({"fp16": l16, "fp32x3": l32, "max_gap_over_descent": gap}, f)
+    print("trajectory gap / descent:", gap)
+
+
 def test_posenet_train_step_fp32_parity(lib):
     checks.check_train_step(lib, DEV, "fp32", mode="posenet", N=5, H=96, W=128, steps=1)
 

@@ -69,6 +69,9 @@ constexpr int WGF_RING_MAX8 = 448;
 // ABL (timing experiments only, MN_WGF_ABLATE in the ablation build; results are wrong): bit 0 = no DMA after the prologue,
 // bit 1 = no B-fragment reads, bit 2 = no MFMA, bit 3 = no stores / atomics.
 // PD: B fragments requested ahead of the MFMAs that consume them.
+// (Measured and removed, round 3, profiles/r03/c9_*: a ROTATED loop -- the A fragments and the first PD B fragments of step
+// s + 1 requested at the end of step s, in flight across the barrier, for which step s + 1 has to be visible one barrier
+// early, i.e. one DMA step fewer in flight -- 101-109 -> 106-115 us per launch, step 14.49 -> 14.59 ms.)
 // No item ever wraps around the ring: the 64 rows behind the ring mirror its first block (the DMA that fills block 0 is
 // issued twice), so a tap window that starts near the end simply runs on into the mirror.
 template <int D, int ABL = 0, int PD = 3>

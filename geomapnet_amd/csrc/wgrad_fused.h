@@ -416,7 +416,8 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
     }
   }
 #endif
-  // (B-fragment read-ahead PD = 2 / 4 / 6 and DMA depth 1-3 measured equal in round 2; PD = 3, D = 3)
+  // (B-fragment read-ahead PD = 2 / 4 / 6 and DMA depth 1-3 measured equal in round 2; depth 4 measured slower in round 3:
+  //  104-112 vs 101-110 us per launch, profiles/r03/c10_wgf_depth.txt; PD = 3, D = 3)
   hipLaunchKernelGGL((wgrad_fused_kernel<D>), grid, block, 0, stream, a);
   wgrad_fused_reduce(a, stream);
 }

@@ -25,9 +25,15 @@ namespace mn {
 // The B ring has TWO slots: every K-step waits for the slice it requested one K-step earlier.  (Measured and removed: three
 // slots with counted waits -- two slices of DMA instructions in flight -- are SLOWER for the 128-column shape, layer2 109.8
 // vs 105.1 us, layer4 92.0 vs 85.8 us, whole step 15.36 vs 15.27 ms: request latency is not what bounds these launches.)
+// The epilogue stages the accumulators through LDS for 16-byte stores.  (Measured and removed in round 3: a register epilogue
+// -- MFMA operands swapped so that a lane holds 4 consecutive channels of one pixel, 8-byte buffer stores, residual / gate
+// loads in the same pattern, no staging and no barriers, as halo_pp.h does -- is SLOWER: layer2 forward 131 vs 103 us,
+// +residual 150 vs 120, layer3 89 vs 80, whole step 15.1 vs 14.6 ms; a store instruction then touches 32 pixel rows x 16
+// bytes instead of 4 rows x 256 bytes.  profiles/r03/c11_igemm_halo_register_epilogue.txt.  What the staged epilogue
+// costs: profiles/r03/c10_igemm_halo_prologue_kloop_epilogue.txt -- 18 of 103 us at layer2, 12 of 80 at layer3.)
 // ABL (timing experiments only, ablation build, MN_HALO_ABLATE; results are wrong): bit 0 = no epilogue (no staging, stores,
 // residual / gate loads, statistics), bit 1 = K loop cut to its first K-step.
-template <int BN, int kAH, int ABL = 0, bool REGEPI = false>
+template <int BN, int kAH, int ABL = 0>
 static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
@@ -162,13 +168,7 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          // REGEPI: operands swapped -- the accumulator holds the TRANSPOSED tile: lane = pixel, registers = channels
-          if constexpr (REGEPI)
-            mma_piece<half>(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);
-          else
-            mma_piece<half>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
-        }
+        for (int j = 0; j < TN; ++j) mma_piece<half>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (++ts == 3) {
@@ -188,110 +188,6 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
 #pragma unroll
       for (int j = 0; j < TN; ++j) keep += acc[i][j][0] + acc[i][j][15];
     if (keep == 12345.678f) reinterpret_cast<half*>(ep.out)[0] = (half)keep;  // keeps the accumulators live
-    return;
-  }
-
-  if constexpr (REGEPI) {
-    // ---- register epilogue (no LDS staging): with the operands swapped a lane holds, for pixel l31 of row tile i, the
-    //      channels j*32 + 8q + 4*hi + {0..3} (q = r >> 2): 8-byte stores, residual / gate loads in the same pattern;
-    //      BatchNorm sums per lane over the row tiles, folded over the 32 pixel lanes by shuffles ----------------------
-    constexpr unsigned kOob = 0x80000000u;
-    const long obytes = (long)g.M * ep.ldc * 2L;
-    const __amdgpu_buffer_rsrc_t rsrc_out = make_rsrc(ep.out, obytes);
-    const __amdgpu_buffer_rsrc_t rsrc_res = make_rsrc(ep.res ? ep.res : ep.out, obytes);
-    const __amdgpu_buffer_rsrc_t rsrc_rg = make_rsrc(ep.res_gate ? ep.res_gate : ep.out, obytes);
-    const __amdgpu_buffer_rsrc_t rsrc_og = make_rsrc(ep.out_gate ? ep.out_gate : ep.out, obytes);
-    const bool has_res = ep.res != nullptr, has_rg = ep.res_gate != nullptr, has_og = ep.out_gate != nullptr;
-    const bool want_stats = ep.stats || ep.stats_accum;
-    unsigned voff[TM];
-    bool okp[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * WTM + i * 32 + l31;
-      okp[i] = m < g.M;
-      voff[i] = okp[i] ? (unsigned)m * (unsigned)(ep.ldc * 2) + (unsigned)(hi * 8) : kOob;
-    }
-    const int cb = (n0 + wn * WTN) * 2;  // byte column of this wave's first channel
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float st1[16], st2[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st1[r] = st2[r] = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        Half4View rv[4], gv[4], ov[4];
-        if (has_res) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            rv[q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_res, (int)voff[i], cb + j * 64 + q * 16, 0);
-            if (has_rg) gv[q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_rg, (int)voff[i], cb + j * 64 + q * 16, 0);
-          }
-        }
-        if (has_og) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            ov[q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_og, (int)voff[i], cb + j * 64 + q * 16, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          Half4View o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = q * 4 + e;
-            float v = acc[i][j][r] * ep.alpha;
-            if (ep.relu & 1) v = fmaxf(v, 0.f);
-            if (want_stats) {
-              const float vs = okp[i] ? v : 0.f;  // (rows past M are zero anyway: zero A rows, no bias)
-              st1[r] += vs;
-              st2[r] += vs * vs;
-            }
-            if (has_res) {
-              float xr = (float)rv[q].e[e];
-              if (has_rg && !((float)gv[q].e[e] > 0.f)) xr = 0.f;
-              v += xr;
-            }
-            if (has_og && !((float)ov[q].e[e] > 0.f)) v = 0.f;
-            o.e[e] = (half)v;
-          }
-          __builtin_amdgcn_raw_buffer_store_b64(o.p, rsrc_out, (int)voff[i], cb + j * 64 + q * 16, 0);
-        }
-      }
-      if (want_stats) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float a = st1[r], b = st2[r];
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            a += __shfl_xor(a, o);
-            b += __shfl_xor(b, o);
-          }
-          if (l31 == 0) {
-            const int lc = wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            red[(wm * BN + lc) * 2 + 0] = a;
-            red[(wm * BN + lc) * 2 + 1] = b;
-          }
-        }
-      }
-    }
-    if (want_stats) {
-      __syncthreads();
-      for (int c = t; c < BN; c += NT) {
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          a += red[(w * BN + c) * 2 + 0];
-          b += red[(w * BN + c) * 2 + 1];
-        }
-        if (ep.stats_accum) {
-          double* row = ep.stats_accum + (long)(tile_m % ep.stats_rows) * 2 * g.N;
-          atomicAdd(row + n0 + c, (double)a);
-          atomicAdd(row + g.N + n0 + c, (double)b);
-        } else {
-          ep.stats[((long)tile_m * 2 + 0) * g.N + n0 + c] = a;
-          ep.stats[((long)tile_m * 2 + 1) * g.N + n0 + c] = b;
-        }
-      }
-    }
     return;
   }
 
@@ -418,9 +314,6 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
   RowDiv rd;
   rd.q = make_fastdiv(g.Q);
   rd.p = make_fastdiv(g.P);
-  // (experiment) MN_HALO_EPI=1: register epilogue
-  static const int epi = getenv("MN_HALO_EPI") ? atoi(getenv("MN_HALO_EPI")) : 0;
-  const bool regepi = epi == 1 && !ep.bias && (long)g.M * ep.ldc * 2L < 0x7ffffff0l;
   if (level >= 1 && tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) {
 #ifdef MN_ABLATION_BUILD
     static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
@@ -428,10 +321,7 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
     if (abl == 2) { hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 2>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd); return gm; }
     if (abl == 3) { hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 3>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd); return gm; }
 #endif
-    if (regepi)
-      hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, true>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
-    else
-      hipLaunchKernelGGL((igemm_halo_kernel<256, 352>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
+    hipLaunchKernelGGL((igemm_halo_kernel<256, 352>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
     return gm;
   }
   if (level >= 2 && igemm_halo_applies(g, ep, 128, 384)) {
@@ -441,10 +331,7 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
     if (abl2 == 2) { hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 2>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd); return gm; }
     if (abl2 == 3) { hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 3>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd); return gm; }
 #endif
-    if (regepi)
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, true>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
-    else
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 384>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
+    hipLaunchKernelGGL((igemm_halo_kernel<128, 384>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
     return gm;
   }
   return -1;

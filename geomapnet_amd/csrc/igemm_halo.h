@@ -12,8 +12,8 @@
 // LDS (158 of 160 KiB for the 256-column shape): two A images of kAH rows (the next chunk's image is fetched, one DMA pass per
 // K-step, while the current one is read), a two-slot B ring of 256 rows, the zero slot, BatchNorm scratch.
 // kAH >= 288 + 2 (W + 1) bounds the image width W.
-// Synchronisation is igemm.h's: one `s_waitcnt vmcnt(0)` + raw barrier per K-step; every DMA is issued right after a
-// barrier and waited for at the next one, so image pass p of chunk c+1 (issued in K-step p of chunk c) has landed eight
+// Synchronisation is igemm.h's: one `s_waitcnt vmcnt(0)` + raw barrier per K-step; every DMA is issued after a
+// barrier (behind the K-step's first MFMA group, see DP) and waited for at the next one, so image pass p of chunk c+1 (issued in K-step p of chunk c) has landed eight
 // barriers before it is read, and the image it overwrites was last read in chunk c-1.
 #pragma once
 #include "igemm.h"
@@ -31,9 +31,14 @@ namespace mn {
 // +residual 150 vs 120, layer3 89 vs 80, whole step 15.1 vs 14.6 ms; a store instruction then touches 32 pixel rows x 16
 // bytes instead of 4 rows x 256 bytes.  profiles/r03/c11_igemm_halo_register_epilogue.txt.  What the staged epilogue
 // costs: profiles/r03/c10_igemm_halo_prologue_kloop_epilogue.txt -- 18 of 103 us at layer2, 12 of 80 at layer3.)
+// DP: where in a K-step the LDS-DMA instructions of the next step are issued: 0 = right after the barrier (rounds 1-2), 1 / 2 =
+// after the first / second of the four MFMA groups.  Measured (profiles/r03/c13_igemm_halo_dma_position.txt, two repeats):
+// layer2 105.7 / 100.6 / 104.0 us, layer3 83.1 / 81.8 / 83.5, layer4 88.3 / 85.5 / 90.0 -- right after the barrier the requests
+// compete with every wave's first fragment reads; DP = 1 is what ships.
 // ABL (timing experiments only, ablation build, MN_HALO_ABLATE; results are wrong): bit 0 = no epilogue (no staging, stores,
-// residual / gate loads, statistics), bit 1 = K loop cut to its first K-step.
-template <int BN, int kAH, int ABL = 0>
+// residual / gate loads, statistics), bit 1 = K loop cut to its first K-step, bit 2 = no DMA in the K loop, bit 3 = fragment
+// reads only in the first K-step, bit 4 = no MFMAs.
+template <int BN, int kAH, int ABL = 0, int DP = 1>
 static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
@@ -134,8 +139,13 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
   for (int kt = 0; kt < KT; ++kt) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // this step's B slice (and any image pass in flight) landed; last step's reads are done
-    if (kt + NBS - 1 < KT) issue_b(kt + NBS - 1);
-    if (tap < A_PASSES && chunk + 1 < NCH) issue_a(chunk + 1, tap);
+    auto issue_step = [&]() {
+      if constexpr ((ABL & 4) == 0) {
+        if (kt + NBS - 1 < KT) issue_b(kt + NBS - 1);
+        if (tap < A_PASSES && chunk + 1 < NCH) issue_a(chunk + 1, tap);
+      }
+    };
+    if constexpr (DP == 0) issue_step();
     const piece_t* img = &smem[(chunk & 1) * A_IMG];
     const piece_t* tb = &smem[2 * A_IMG + (kt % NBS) * B_SLOT];
     const int shift = halo + (g.off_h + g.rsign * tr) * W + g.off_w + g.ssign * ts;  // scalar
@@ -160,16 +170,28 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[slot][j].p = tb[(brow + j * 32) * NP + (piece ^ bswz)];
     };
-    load_frags(0, 0);
+    if ((ABL & 8) == 0 || kt == 0) load_frags(0, 0);
 #pragma unroll
     for (int ks = 0; ks < NP / 2; ++ks) {
-      if (ks + 1 < NP / 2) load_frags(ks + 1, (ks + 1) & 1);
+      if (ks + 1 < NP / 2 && ((ABL & 8) == 0 || kt == 0)) load_frags(ks + 1, (ks + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((ABL & 16) == 0) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma_piece<half>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) mma_piece<half>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[ks & 1][i].p));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[ks & 1][j].p));
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DP > 0)
+        if (ks + 1 == DP) {
+          issue_step();
+          __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (++ts == 3) {
       ts = 0;
@@ -314,22 +336,30 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
   RowDiv rd;
   rd.q = make_fastdiv(g.Q);
   rd.p = make_fastdiv(g.P);
+#ifdef MN_ABLATION_BUILD
+  static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
+#endif
   if (level >= 1 && tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) {
 #ifdef MN_ABLATION_BUILD
-    static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
-    if (abl == 1) { hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 1>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd); return gm; }
-    if (abl == 2) { hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 2>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd); return gm; }
-    if (abl == 3) { hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 3>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd); return gm; }
+#define MN_HALO_ABL(BN_, AH_, V_)                                                                                          \
+  if (abl == V_) {                                                                                                         \
+    hipLaunchKernelGGL((igemm_halo_kernel<BN_, AH_, V_>), dim3(gm * (g.N / BN_)), dim3(768), 0, stream, g, A, Bw, ep,      \
+                       g.N / BN_, rd);                                                                                     \
+    return gm;                                                                                                             \
+  }
+    MN_HALO_ABL(256, 352, 1) MN_HALO_ABL(256, 352, 2) MN_HALO_ABL(256, 352, 3) MN_HALO_ABL(256, 352, 4)
+    MN_HALO_ABL(256, 352, 8) MN_HALO_ABL(256, 352, 16) MN_HALO_ABL(256, 352, 12) MN_HALO_ABL(256, 352, 20)
+    MN_HALO_ABL(256, 352, 24) MN_HALO_ABL(256, 352, 28)
 #endif
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
     return gm;
   }
   if (level >= 2 && igemm_halo_applies(g, ep, 128, 384)) {
 #ifdef MN_ABLATION_BUILD
-    static const int abl2 = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
-    if (abl2 == 1) { hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 1>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd); return gm; }
-    if (abl2 == 2) { hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 2>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd); return gm; }
-    if (abl2 == 3) { hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 3>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd); return gm; }
+    MN_HALO_ABL(128, 384, 1) MN_HALO_ABL(128, 384, 2) MN_HALO_ABL(128, 384, 3) MN_HALO_ABL(128, 384, 4)
+    MN_HALO_ABL(128, 384, 8) MN_HALO_ABL(128, 384, 16) MN_HALO_ABL(128, 384, 12) MN_HALO_ABL(128, 384, 20)
+    MN_HALO_ABL(128, 384, 24) MN_HALO_ABL(128, 384, 28)
+#undef MN_HALO_ABL
 #endif
     hipLaunchKernelGGL((igemm_halo_kernel<128, 384>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
     return gm;

@@ -175,8 +175,9 @@ def test_shipped_k_loops_have_no_scratch_access_and_asm_reads_skip_the_dma_wait(
     hot = audit.signatures(r"igemm_kernelIDF16_Li3ELi4ELi3ELi2ELi8ELi2ELi3ELb1ELb1ELi0ELi0E|"
                            r"igemm_kernelIDF16_Li2ELi2ELi2ELi2ELi8ELi2ELi2ELb1ELb0ELi0ELi0E|"
                            r"igemm_kernelIDF16_Li2ELi2ELi4ELi2ELi4ELi3ELi2ELb1ELb0ELi0ELi0E|"
-                           r"wgrad_dma_kernelILi\d+ELi\d+ELi32ELi\dELb1ELb1E")
-    assert len(hot) == 7, sorted(hot)
+                           r"wgrad_dma_kernelILi\d+ELi\d+ELi32ELi\dELb1ELb1E|"
+                           r"igemm_halo_kernelILi\d+ELi\d+ELi0ELi1E")  # igemm_halo_kernel<BN, kAH, ABL = 0, DP = 1>: two shapes
+    assert len(hot) == 9, sorted(hot)
     for name, (_, _, sig) in hot.items():
         assert "S!" not in sig, (name, sig)
     asm = {n: s for n, (_, _, s) in hot.items() if "wgrad_dma" in n and n.split("ELb1ELb")[1].startswith("1")}

@@ -473,6 +473,9 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
       wait_vmcnt<0>();
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; everyone is done reading buffer `nxt`
     const bool more = (ABL & 1) ? false : kt + D < NK;
+    // (Issuing behind the K-step's first MFMA group instead, which gains 2-5 % in igemm_halo.h and wgrad_fused.h, measured
+    // neutral here and in the x3 pipelined loop: layer2 fp16 98.9 vs 98.8 us, whole step 14.28-14.37 vs 14.36-14.39 ms,
+    // profiles/r03/c15_*.)
     if (!SPL && more) issue_tile(nxt);  // tiles are issued strictly in K order
     const piece_t* ta = &smem[cur * TILE_PIECES];
     // fragments are register double-buffered: the ds_reads of sub-step ks+1 are issued before the MFMAs

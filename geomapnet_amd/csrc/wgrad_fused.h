@@ -69,12 +69,17 @@ constexpr int WGF_RING_MAX8 = 448;
 // ABL (timing experiments only, MN_WGF_ABLATE in the ablation build; results are wrong): bit 0 = no DMA after the prologue,
 // bit 1 = no B-fragment reads, bit 2 = no MFMA, bit 3 = no stores / atomics.
 // PD: B fragments requested ahead of the MFMAs that consume them.
+// DPI: the LDS-DMA of step s + D is issued behind the MFMAs of item DPI of step s (-1: right after the barrier, rounds 1-2).
+// Measured per launch at layers 1-4 (profiles/r03/c14_*, c15_*): -1: 112 / 105 / 101 / 109 us, 1: 111 / 101 / 98 / 106,
+// 4: 111 / 103 / 99 / 108, 7: 108 / 101 / 97 / 105, 8: 110 / 109 / 102 / 109, 9: 116 / 112 / 106 / 114; whole step 13.94 (-1) vs
+// 13.85 ms (7) on one box -- right after the barrier the requests (and the address arithmetic of their pixels) compete with
+// every wave's first fragment reads.
 // (Measured and removed, round 3, profiles/r03/c9_*: a ROTATED loop -- the A fragments and the first PD B fragments of step
 // s + 1 requested at the end of step s, in flight across the barrier, for which step s + 1 has to be visible one barrier
 // early, i.e. one DMA step fewer in flight -- 101-109 -> 106-115 us per launch, step 14.49 -> 14.59 ms.)
 // No item ever wraps around the ring: the 64 rows behind the ring mirror its first block (the DMA that fills block 0 is
 // issued twice), so a tap window that starts near the end simply runs on into the mirror.
-template <int D, int ABL = 0, int PD = 3>
+template <int D, int ABL = 0, int PD = 3, int DPI = 7>
 static __global__ void __launch_bounds__(512, 2) wgrad_fused_kernel(WgradFusedArgs a) {
   constexpr int NW = 8;
   static_assert(D >= 1 && D <= 3, "steps in flight");
@@ -190,10 +195,13 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_kernel(WgradFusedAr
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // step s visible to everyone; everyone is done with step s-1's reads
-    if (s + D < nsteps && (ABL & 1) == 0) {  // into dY tile (s - 1) % NY and the ring rows behind the live + in-flight window
-      issue_y(s + D);
-      issue_x(2 * Gpad + BKM * (s + D));
-    }
+    auto issue_step = [&]() {
+      if (s + D < nsteps && (ABL & 1) == 0) {  // into dY tile (s - 1) % NY and the ring rows behind the live + in-flight window
+        issue_y(s + D);
+        issue_x(2 * Gpad + BKM * (s + D));
+      }
+    };
+    if constexpr (DPI < 0) issue_step();
     const unsigned tyoff = (unsigned)((s % NY) * TILE_Y * 2);
     // One step = 10 (K sub-step, tap slot) items per wave, each TWO MFMAs (both output-channel blocks) fed by the A
     // fragments of that sub-step and ONE B fragment read at the tap's row shift.  B fragments travel through a ring of
@@ -243,6 +251,10 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_kernel(WgradFusedAr
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (it == DPI) {
+        issue_step();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     });
     // the tap windows move on by one step (scalar)
 #pragma unroll

@@ -93,6 +93,11 @@ struct Epilogue {
   int om_on = 0, om_P = 0, om_Q = 0, om_H = 0, om_W = 0, om_a = 0, om_b = 0;
   FastDiv om_dq{0, 0}, om_dp{0, 0};
   float alpha;           // scale applied to the accumulator
+  // (Measured and removed in round 3: BatchNorm-BACKWARD sums (sum g, sum g * y of the BatchNorm that consumes the stored
+  // gradient next) taken in the row-wise store passes of this epilogue and igemm_halo.h's, to drop the reduction launches
+  // that read the gradient back.  The extra 16-byte load of y per stored piece sits, latency exposed, in each of the 6-12
+  // store passes of a tile: layer3 data gradients +29 us per launch against 19.9 us of reduction saved, layer2 +36 against
+  // 34.9, whole step 14.94 vs 14.63 ms.  profiles/r03/c16_bn_backward_sums_in_dgrad_epilogue.txt.)
 };
 
 struct RowDiv {

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: convolution parity cases run in a process of their own with a tile configuration forced
-through MN_IGEMM_CONFIG / MN_WGRAD_TR_ASM / MN_WGRAD_FUSED (the library reads such knobs once).  `python forced_config_cases.py emu|hip`.
+through MN_IGEMM_CONFIG / MN_IGEMM_HALO / MN_WGRAD_FUSED (the library reads such knobs once).  `python forced_config_cases.py emu|hip`.
 Configuration 12 = the 12-wave 288x256 tile, which the dispatcher picks by itself only for grids that fill most of
 the chip (layer3 at 192 images); here it runs on small ragged problems against torch fp64."""
 import os
@@ -17,7 +17,7 @@ def main(backend):
     else:
         from geomapnet_amd import _binding
         lib, dev = _binding.hip(), "cuda"
-    if os.environ.get("MN_WGRAD_CASES") == "1":  # (with MN_WGRAD_VARIANT=0: the 64-row-step kernels; MN_WGRAD_FUSED=0/1)
+    if os.environ.get("MN_WGRAD_CASES") == "1":  # (MN_WGRAD_FUSED=0/1)
         # fp16 weight gradients of stride-1 "same" convolutions with the transpose reads issued from inline assembly
         # (wgrad_dma_kernel<..., ASMRD>): all four tile shapes, several splits, ragged last split
         for shape, blocks in (((2, 9, 11, 64, 64, 3, 1, 1), 8), ((3, 7, 9, 128, 128, 3, 1, 1), 40),

@@ -170,16 +170,15 @@ def test_forced_288x256_configuration():
 
 
 def test_weight_gradient_with_assembly_transpose_reads():
-    """wgrad_dma_kernel<..., ASMRD> (the plain-GEMM weight gradient with assembly transpose reads; since round 2 the
+    """wgrad_dma_kernel (the plain-GEMM fp16 weight gradient, transpose reads issued from inline assembly; since round 2 the
     3x3 stride-1 layers go to wgrad_fused.h, so MN_WGRAD_FUSED=0 routes the cases here): the emulator executes the
-    variant's address arithmetic (lane base + immediate offsets).  MN_WGRAD_TR_ASM=0: the builtin-read form."""
+    kernel's address arithmetic (lane base + immediate offsets)"""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    for variant, asm in (("1", "1"), ("0", "1"), ("1", "0")):  # 32-row steps (default) and 64-row steps; builtin reads
-        env = dict(os.environ, MN_WGRAD_TR_ASM=asm, MN_WGRAD_CASES="1", MN_WGRAD_VARIANT=variant, MN_WGRAD_FUSED="0")
-        subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
+    env = dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_FUSED="0")
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
 
 
 @pytest.mark.parametrize("mode,N,T", [("mapnet", 1, 2), ("mapnet", 3, 5), ("mapnet", 2, 7), ("online", 1, 2), ("online", 3, 4),

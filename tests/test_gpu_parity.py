@@ -187,7 +187,10 @@ def test_mapnet_gps_train_step_fp32(lib):
 
 
 def test_mapnet_train_step_fp16_close(lib):
-    checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=2e-2, pose_atol=5e-2,
+    """fp16 build, two windows (6 images) at full resolution: BatchNorm statistics over so few samples make the storage
+    rounding weigh more than at 64 windows (FP16_ENVELOPE).  Measured on MI355X (profiles/r03/c17_fp16_step_small_batches.txt):
+    loss 8.6e-4 relative, pose 9.8e-3 max abs; N=4: 3.3e-3 / 1.05e-2 -- asserted at ~3x the larger of the two."""
+    checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-2, pose_atol=3e-2,
                             grad_l2_rtol=None)
 
 
@@ -424,9 +427,8 @@ def _run_forced(env, default_path):
 def test_weight_gradient_with_assembly_transpose_reads():
     """the plain-GEMM fp16 weight-gradient kernel (MN_WGRAD_FUSED=0 routes the 3x3 layers to it) with its transpose reads
     issued from inline assembly and hand-placed waits, against torch fp64 at small and layer-sized shapes, repeated."""
-    # 32-row steps: what the stride-2 / 1x1 layers run by default; 64-row steps: an off-by-default variant
-    _run_forced(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT="1", MN_WGRAD_FUSED="0"), True)
-    _run_forced(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_TR_ASM="1", MN_WGRAD_VARIANT="0", MN_WGRAD_FUSED="0"), False)
+    # (the kernel the stride-2 / 1x1 layers run by default)
+    _run_forced(dict(os.environ, MN_WGRAD_CASES="1", MN_WGRAD_FUSED="0"), True)
 
 
 def test_fused_weight_gradient_race_screen():

@@ -714,8 +714,8 @@ struct WgradDma<half> {
         hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
       else if (bno == 64)
         hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
-      else
-        hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, MINW, true, true>), grid, block, 0, stream, a, zp);
+      else  // (the 128x128 tile needs more than the 128 registers of 4 waves per SIMD: 3 requested = what it runs at)
+        hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, BKM, (MINW > 3 ? 3 : MINW), true, true>), grid, block, 0, stream, a, zp);
       return;
     }
     if (bmo == 64 && bno == 64)

@@ -415,7 +415,7 @@ struct Plan : PlanBase {
     stem_colmap = (int*)A(224 * 4);
     repack_jobs = (RepackJob*)A(64 * sizeof(RepackJob));
     zero_page = (void*)A(256);
-    wgf_ws_floats = DT == MN_F16 ? wgrad_fused_ws_floats(WGF_BLOCKS) : 0;
+    wgf_ws_floats = (DT == MN_F16 || mma_bwd == MMA_BF16X3) ? wgrad_fused_ws_floats(WGF_BLOCKS) : 0;  // (both fused forms)
     if (deterministic && wgf_ws_floats < (16L << 20)) wgf_ws_floats = 16L << 20;  // split slices of the plain weight gradients
     wgf_ws = wgf_ws_floats ? (float*)A((size_t)wgf_ws_floats * 4) : nullptr;
     step_dev = (long long*)A(256);

@@ -509,6 +509,8 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
 }
 
 // ---- fp32 tensors on the bf16 matrix pipe (MMA_BF16X3, common.h): the weight gradient of the fp32x3 mode -----------------
+// (The 3x3 stride-1 layers -- 29 of 37 launches -- go to wgrad_fused.h's wgrad_fused_x3_kernel, which reads the pixels once for
+// all nine taps: 232-260 us per launch against this kernel's 336-530; this one keeps the stride-2 / 1x1 / stem shapes.)
 // wgrad_kernel's loader (any gather: stride, taps, column map; 16-byte pieces of 4 floats through registers) + the fp16
 // kernel's reader: every element is split into hi + lo bf16 halves ONCE, on its way from the staging registers into LDS
 // (two bf16 planes per operand, rows = m, 16-byte pieces XOR-swizzled with the row as above), and a fragment -- 8
@@ -741,7 +743,8 @@ struct WgradDma<half> {
 // wgrad_fused.h: 3x3 stride-1 fp16 layers with the nine taps of a channel tile accumulated from one LDS-resident pass
 // over the pixels (MN_WGRAD_FUSED=0 restores the plain GEMM form below for them)
 inline bool wgrad_fused_applies(const WgradArgs& a);
-inline void launch_wgrad_fused(const WgradArgs& a, int target_blocks, hipStream_t stream);
+inline bool wgrad_fused_x3_applies(const WgradArgs& a);
+inline void launch_wgrad_fused(const WgradArgs& a, int target_blocks, hipStream_t stream, bool x3);
 
 // dW[i] += sum over the split slices, in split order (the slices already carry alpha)
 static __global__ void __launch_bounds__(256) wgrad_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
@@ -757,10 +760,15 @@ inline void launch_zero_fill(float* p, long n, hipStream_t s);  // optim.h
 template <typename T>
 inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, const void* zero_page = nullptr) {
   const GatherGeom& g = a.g;
+  static const bool fused = !(getenv("MN_WGRAD_FUSED") && atoi(getenv("MN_WGRAD_FUSED")) == 0);
   if constexpr (ElemTraits<T>::DTYPE == MN_F16) {
-    static const bool fused = !(getenv("MN_WGRAD_FUSED") && atoi(getenv("MN_WGRAD_FUSED")) == 0);
     if (fused && wgrad_fused_applies(a)) {
-      launch_wgrad_fused(a, target_blocks, stream);
+      launch_wgrad_fused(a, target_blocks, stream, false);
+      return;
+    }
+  } else {
+    if (fused && wgrad_fused_x3_applies(a)) {  // fp32 tensors, bf16x3 contraction
+      launch_wgrad_fused(a, target_blocks, stream, true);
       return;
     }
   }

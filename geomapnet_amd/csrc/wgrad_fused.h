@@ -322,6 +322,215 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_kernel(WgradFusedAr
   }
 }
 
+// ---- fp32x3 form (round 3): the same tap-fused pass for fp32 tensors contracted on the bf16 matrix pipe -------------------
+// wgrad.h's wgrad_x3_kernel is the plain-GEMM form: every one of the nine tap tiles of a channel pair re-reads the pixels
+// (336-530 us per launch at 192 images, a third of it MFMA time).  Here the pixels of a range are read ONCE, split into bf16
+// hi + lo halves on their way from the staging registers into LDS (wgrad_x3_kernel's convert-at-LDS-write: two planes per
+// operand, same rows / swizzle / padded pixel order / mirrored ring as the fp16 kernel above), and an item = the four
+// transpose reads of a tap's B fragment (hi, lo) + three MFMAs (lo*hi + hi*lo + hi*hi).
+// fp32 rows cannot come by LDS-DMA (they have to pass the split), so loads are register-staged TWO steps ahead: the loads of
+// step s + 2 are requested before the MFMAs of step s; the rows of step s + 1 (requested a step earlier) are split and stored
+// behind those MFMAs -- the rows they overwrite were last read in step s - 1 -- one barrier per step.  (One step ahead, with
+// the fp16 kernel's wave roles and 160 accumulator registers: 230-250 us per launch, bound by the latency of the 32 KB a
+// workgroup can have in flight; profiles/r03/c20_*.)  To afford the second set of staging registers a wave owns ONE 32-row
+// block of the output channels (80 accumulator registers) and walks all 64 pixels of a step: wave = (column block of the
+// input channels) x (block of the output channels) x (taps 0-4 / 5-8); no exchange at the end.
+// LDS: 2 x (2 dY tiles + ring of 2 x 64 + 2 Gpad rows + mirror) = 128 KB, one workgroup per CU.
+constexpr int WGF_X3_RING_MAX = 2 * 64 + 2 * 96;
+static __global__ void __launch_bounds__(512, 2) wgrad_fused_x3_kernel(WgradFusedArgs a) {
+  constexpr int NW = 8, BKM = 8 * NW, ROWH = 64, NY = 2;
+  constexpr int TILE_Y = BKM * ROWH;                       // elements of one dY tile plane
+  constexpr int XPLANE = (WGF_X3_RING_MAX + BKM) * ROWH;   // ring + mirror of its first block
+  // [Y hi tiles][Y lo tiles][X hi ring + mirror][X lo ring + mirror], bf16
+  __shared__ unsigned short smem[2 * NY * TILE_Y + 2 * XPLANE] __attribute__((aligned(16)));
+  unsigned short* const yh = smem;
+  unsigned short* const yl = smem + NY * TILE_Y;
+  unsigned short* const xh = smem + 2 * NY * TILE_Y;
+  unsigned short* const xl = xh + XPLANE;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wc = wave & 1, nb = (wave >> 1) & 1, tset = wave >> 2;
+  const int tap0 = tset * 5, ntap = tset == 0 ? 5 : 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int pairs = a.tiles_n * a.tiles_c;
+  const int ci = logical / pairs, pr = logical - ci * pairs;
+  const int n0 = (pr / a.tiles_c) * 64, c0 = (pr % a.tiles_c) * 64;
+  const int j0 = ci * a.chunk;
+  const int j1 = min(a.J, j0 + a.chunk);
+  const int nsteps = (j1 - j0 + BKM - 1) / BKM;
+  const int Gpad = a.Gpad, RING = a.ring;
+  const float* __restrict__ dY = reinterpret_cast<const float*>(a.dY);
+  const float* __restrict__ X = reinterpret_cast<const float*>(a.X);
+
+  // loader role: rows t/16 and t/16 + 32 of a 64-row block, the 16-byte piece (4 floats) t%16 of the row
+  const int ldrow = t >> 4, ldp = t & 15;
+  const bool y_ok = n0 + ldp * 4 < a.N, x_ok = c0 + ldp * 4 < a.C;
+  auto pixel_of = [&](int j) -> int {
+    if ((unsigned)j >= (unsigned)a.J) return -1;
+    const int r = fastdiv(j, a.dq), q = j - r * a.Qp;
+    const int b = fastdiv(r, a.dp), p = r - b * (a.P + 1);
+    return (q < a.Q && p < a.P) ? (b * a.P + p) * a.Q + q : -1;
+  };
+  struct Staged {
+    piece_t y[2], x[2];
+  };
+  auto load_y = [&](int step, Staged& r) {  // positions [j0 + BKM step, + BKM) of dY (zero past the chunk's end)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = j0 + step * BKM + ldrow + 32 * i;
+      const int m = j < j1 ? pixel_of(j) : -1;
+      r.y[i] = (m >= 0 && y_ok) ? *reinterpret_cast<const piece_t*>(dY + (long)m * a.ldy + n0 + ldp * 4) : zero_piece();
+    }
+  };
+  auto load_x = [&](int u0, Staged& r) {  // ring-relative rows [u0, u0 + BKM): positions j0 - Gpad + u0 + ..
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = pixel_of(j0 - Gpad + u0 + ldrow + 32 * i);
+      r.x[i] = (m >= 0 && x_ok) ? *reinterpret_cast<const piece_t*>(X + (long)m * a.C + c0 + ldp * 4) : zero_piece();
+    }
+  };
+  // 4 floats -> 4 hi + 4 lo bf16 at (row, channels 4 ldp ..) of a plane pair; 16-byte pieces (8 channels) swizzled with row & 3
+  auto split_store = [&](piece_t raw, unsigned short* hp, unsigned short* lp, int row) {
+    PieceView<float> v;
+    v.p = raw;
+    union {
+      __bf16 b[4];
+      u32x2 u;
+    } h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h.b[e] = (__bf16)v.e[e];
+      l.b[e] = (__bf16)(v.e[e] - (float)h.b[e]);
+    }
+    const int at = row * ROWH + (((ldp >> 1) ^ wg_swz<8>(row)) * 8) + (ldp & 1) * 4;
+    *reinterpret_cast<u32x2*>(hp + at) = h.u;
+    *reinterpret_cast<u32x2*>(lp + at) = l.u;
+  };
+  auto store_y = [&](int step, const Staged& r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) split_store(r.y[i], yh + (step % NY) * TILE_Y, yl + (step % NY) * TILE_Y, ldrow + 32 * i);
+  };
+  auto store_x = [&](int u0, const Staged& r) {
+    const int rr = u0 % RING;  // blocks never straddle the end (RING and u0 are multiples of BKM)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      split_store(r.x[i], xh, xl, rr + ldrow + 32 * i);
+      if (rr == 0) split_store(r.x[i], xh, xl, RING + ldrow + 32 * i);  // block 0 also goes to the mirror
+    }
+  };
+
+  floatx16 acc[5];  // [tap slot: tap = tap0 + slot] of the output-channel block nb
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // transpose-read lane geometry (the fp16 kernel's), as ELEMENT offsets inside a plane; a wave walks all 64 rows of a step
+  const int gq = lane >> 4, i16 = lane & 15;
+  const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
+  const int lrow = (gq >> 1) * 8 + src_row;
+  const int colA = nb * 32 + src_chunk;
+  const int aA = lrow * ROWH + (((colA >> 3) ^ wg_swz<8>(src_row)) * 8) + (colA & 7);
+  const int colB = wc * 32 + src_chunk;
+  int xoffB[5], rbB[5];
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    const int tp = tap0 + (sl < ntap ? sl : ntap - 1);
+    const int sh = Gpad + (tp / 3 - 1) * a.Qp + (tp % 3 - 1);  // in [0, 2 Gpad] < RING
+    const int key = (sh + src_row) & 3;
+    xoffB[sl] = lrow * ROWH + (((colB >> 3) ^ (key << 1)) * 8) + (colB & 7);
+    rbB[sl] = sh * ROWH;
+  }
+  const int ring_elems = RING * ROWH;
+
+  // prologue: the halo rows [0, 2 Gpad) and step 0 into LDS; step 1 into the first register set
+  Staged st0, st1;
+  for (int u0 = 0; u0 < 2 * Gpad; u0 += BKM) {
+    load_x(u0, st0);
+    store_x(u0, st0);
+  }
+  if (nsteps > 0) {
+    load_y(0, st0);
+    load_x(2 * Gpad, st0);
+    store_y(0, st0);
+    store_x(2 * Gpad, st0);
+  }
+  if (nsteps > 1) {
+    load_y(1, st1);
+    load_x(2 * Gpad + BKM, st1);
+  }
+  __syncthreads();
+
+  // one step: request step s + 2 into `nxt2`, MFMAs of step s, split + store step s + 1 from `nxt1` (requested a step ago)
+  auto step = [&](int s, Staged& nxt2, Staged& nxt1) {
+    if (s + 2 < nsteps) {
+      load_y(s + 2, nxt2);
+      load_x(2 * Gpad + BKM * (s + 2), nxt2);
+    }
+    const unsigned short* tyh = yh + (s % NY) * TILE_Y;
+    const unsigned short* tyl = yl + (s % NY) * TILE_Y;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      TrFragB ah, al;
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const int off = aA + (ks * 16 + hlf * 4) * ROWH;
+        ah.h[hlf] = ds_read_tr16(tyh + off);
+        al.h[hlf] = ds_read_tr16(tyl + off);
+      }
+#pragma unroll
+      for (int sl = 0; sl < 5; ++sl) {
+        TrFragB bh, bl;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+          const int off = xoffB[sl] + rbB[sl] + (ks * 16 + hlf * 4) * ROWH;
+          bh.h[hlf] = ds_read_tr16(xh + off);
+          bl.h[hlf] = ds_read_tr16(xl + off);
+        }
+        if (sl < 4 || tset == 0) {  // wave-uniform: slot 4 of the 4-tap half carries no MFMA
+          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[sl], 0, 0, 0);
+          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[sl], 0, 0, 0);
+          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[sl], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+      rbB[sl] += BKM * ROWH;
+      rbB[sl] -= rbB[sl] >= ring_elems ? ring_elems : 0;
+    }
+    if (s + 1 < nsteps) {  // dY tile (s + 1) % 2 and the ring rows [64 (s - 1), 64 s) were last read in step s - 1
+      store_y(s + 1, nxt1);
+      store_x(2 * Gpad + BKM * (s + 1), nxt1);
+    }
+    __syncthreads();
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, st0, st1);
+    if (s + 1 < nsteps) step(s + 1, st1, st0);
+  }
+
+  // partial tile -> workspace slab of this pixel range, or fp32 atomics straight into dW[n][tap*C + c]
+  const int K9 = 9 * a.C;
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    if (sl >= ntap) continue;  // wave-uniform
+    const int tp = tap0 + sl;
+    const int c = c0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n < a.N && c < a.C) {
+        if (a.ws)
+          a.ws[((long)ci * a.N + n) * K9 + tp * a.C + c] = acc[sl][r];
+        else
+          unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[sl][r] * a.alpha);
+      }
+    }
+  }
+}
+
 // dW[n][k] += alpha * sum over chunks of ws[chunk][n][k], chunks added in index order.  blockIdx.y splits the chunk
 // range when there are few columns and many chunks (layer1: 36 864 columns x 512 chunks); with more than one group the
 // groups meet in dW through atomics, with one group (layers 3-4) the sum is a plain read-modify-write.
@@ -358,6 +567,15 @@ inline bool wgrad_fused_applies(const WgradArgs& a) {
          (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
 }
 
+// the fp32x3 form: fp32 tensors (16-byte pieces of 4 floats), otherwise the same shapes
+inline bool wgrad_fused_x3_applies(const WgradArgs& a) {
+  const GatherGeom& g = a.g;
+  return g.mma == MMA_BF16X3 && g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.rsign == 1 &&
+         g.ssign == 1 && g.off_h == -1 && g.off_w == -1 && g.P == g.Hi && g.Q == g.Wi && g.C % 4 == 0 && g.N % 4 == 0 &&
+         a.ldy % 4 == 0 && a.colmap == nullptr && a.ldw >= 9 * g.C && ((g.Q + 2 + 31) / 32) * 32 <= 96 &&
+         (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
+}
+
 inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
   if (!a.ws) return;
   const int K9 = 9 * a.C;
@@ -376,7 +594,7 @@ inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
 inline long wgrad_fused_ws_floats(int blocks) { return (long)blocks * 64 * 9 * 64; }
 constexpr int WGF_BLOCKS = 512;  // workgroups per launch: two per CU (the register budget), i.e. one round of the chip
 
-inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream) {
+inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream, bool x3 = false) {
   const GatherGeom& g = w.g;
   constexpr int NW = 8, BKM = 8 * NW;  // (the 4-wave form -- two 256-thread workgroups per CU, twice the partial tiles -- is not launched)
   WgradFusedArgs a;
@@ -393,8 +611,8 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   a.tiles_c = cdiv(g.C, 64);
   a.Gpad = ((g.Q + 2 + 15) / 16) * 16;
   a.Gpad = ((a.Gpad + 31) / 32) * 32;  // 2 Gpad must be a multiple of the 64-row DMA block
-  constexpr int D = 3;  // DMA steps in flight
-  a.ring = (D + 1) * BKM + 2 * a.Gpad;
+  constexpr int D = 3;  // DMA steps in flight (the fp32x3 form stages one step ahead through registers)
+  a.ring = ((x3 ? 1 : D) + 1) * BKM + 2 * a.Gpad;
   a.dq = make_fastdiv(a.Qp);
   a.dp = make_fastdiv(g.P + 1);
   a.alpha = w.alpha;
@@ -415,6 +633,11 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
     fprintf(stderr, "wgrad_fused<%d waves>: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows, ws %d\n", NW,
             a.B, a.P, a.Q, a.C, a.N, a.chunk, a.nchunks, pairs, a.ring, a.ws != nullptr);
   const dim3 grid(a.nchunks * pairs), block(NW * 64);
+  if (x3) {
+    hipLaunchKernelGGL(wgrad_fused_x3_kernel, grid, block, 0, stream, a);
+    wgrad_fused_reduce(a, stream);
+    return;
+  }
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
   {

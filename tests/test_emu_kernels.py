@@ -144,10 +144,12 @@ def test_conv_data_gradient_parity_random_geometry(lib, case):
 
 @pytest.mark.parametrize("shape", [(2, 9, 11, 64, 64, 3, 1, 1), (3, 20, 22, 128, 64, 3, 1, 1), (40, 3, 5, 64, 128, 3, 1, 1),
                                    (2, 6, 7, 72, 80, 3, 1, 1), (2, 8, 11, 256, 256, 3, 1, 1)])
-def test_fused_weight_gradient_through_workspace(lib, shape):
-    """wgrad_fused.h with partial tiles stored to a (NaN-filled) workspace and added up by the reduce kernel, as the plan
-    runs it; bit-identical between two launches when a single reduction group covers the columns"""
-    checks.check_conv_wgrad(lib, DEV, 1, *shape, ws=True)
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_fused_weight_gradient_through_workspace(lib, dtype, shape):
+    """wgrad_fused.h (fp16 kernel; fp32x3 kernel: fp32 tensors split into bf16 halves at the LDS write) with partial tiles
+    stored to a (NaN-filled) workspace and added up by the reduce kernel, as the plan runs it; bit-identical between two
+    launches when a single reduction group covers the columns"""
+    checks.check_conv_wgrad(lib, DEV, dtype, *shape, ws=True)
 
 
 @pytest.mark.parametrize("shape", [(1, 20, 27), (2, 33, 70)])

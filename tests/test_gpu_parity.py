@@ -70,10 +70,12 @@ def test_conv_weight_gradient(lib, dtype, shape, blocks):
 @pytest.mark.parametrize("shape", [(2, 9, 11, 64, 64, 3, 1, 1), (3, 20, 22, 128, 64, 3, 1, 1), (2, 6, 7, 72, 80, 3, 1, 1),
                                    (6, 64, 86, 64, 64, 3, 1, 1), (12, 32, 43, 128, 128, 3, 1, 1), (24, 16, 22, 256, 256, 3, 1, 1),
                                    (48, 8, 11, 512, 512, 3, 1, 1)])
-def test_fused_weight_gradient_through_workspace(lib, shape):
-    """wgrad_fused.h with partial tiles stored to a (NaN-filled) workspace and added up by the reduce kernel, as the plan
-    runs it (layer geometries included); bit-identical between two launches when one reduction group covers the columns"""
-    checks.check_conv_wgrad(lib, DEV, 1, *shape, ws=True)
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_fused_weight_gradient_through_workspace(lib, dtype, shape):
+    """wgrad_fused.h (fp16 kernel / fp32x3 kernel) with partial tiles stored to a (NaN-filled) workspace and added up by the
+    reduce kernel, as the plan runs it (layer geometries included); bit-identical between two launches when one reduction
+    group covers the columns"""
+    checks.check_conv_wgrad(lib, DEV, dtype, *shape, ws=True)
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])

@@ -52,7 +52,7 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
     t_d = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_r = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), ptr(gate), one, ptr(checks.zero_page("cuda")), None))
     t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, ptr(checks.zero_page("cuda")), None))
-    if dtype == 1 and k == 3 and stride == 1:  # the plan's form: partial tiles through a workspace + reduce launch
+    if dtype in (1, 2) and k == 3 and stride == 1:  # the plan's form: partial tiles through a workspace + reduce launch
         t_ws = timeit(lambda: lib.op_wgrad_ws(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, one, ptr(WS), WS.numel(), ptr(checks.zero_page("cuda")), None))
         print("%-22s wgrad through the workspace %7.1f us %6.0f TF" % (name, t_ws, flops / t_ws / 1e6), flush=True)
     if dtype == 1 and Ci == 64 and k == 3 and stride == 1:

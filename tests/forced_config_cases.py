@@ -29,6 +29,8 @@ def main(backend):
                 for shape in ((2, 64, 86, 64, 64, 3, 1, 1), (7, 16, 22, 256, 256, 3, 1, 1), (4, 8, 11, 512, 512, 3, 1, 1),
                               (6, 32, 43, 128, 128, 3, 1, 1)):
                     checks.check_conv_wgrad(lib, dev, 1, *shape, target_blocks=1024, seed=2 + rep)
+                    if os.environ.get("MN_WGRAD_FUSED") == "1":  # the fp32x3 form of the fused kernel (wgrad_fused_x3_kernel)
+                        checks.check_conv_wgrad(lib, dev, 2, *shape, seed=12 + rep, ws=True)
         print("forced-config cases ok")
         return
     if os.environ.get("MN_IGEMM_HALO") == "2" and os.environ.get("MN_IGEMM_CONFIG") is None:

@@ -448,7 +448,7 @@ def test_chunk_resident_a_kernel_race_screen():
     _run_forced(env, True)
 
 
-@pytest.mark.parametrize("dtype_name", ["fp16", "fp32"])
+@pytest.mark.parametrize("dtype_name", ["fp16", "fp32", "fp32x3"])
 def test_deterministic_mode_is_bit_reproducible(lib, dtype_name):
     """MN_DETERMINISTIC=1: three MapNet training steps (clipping on) twice from the same state -> identical bits; the
     default mode's atomics only differ from it by summation order"""

@@ -337,6 +337,18 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_kernel(WgradFusedAr
 // input channels) x (block of the output channels) x (taps 0-4 / 5-8); no exchange at the end.
 // LDS: 2 x (2 dY tiles + ring of 2 x 64 + 2 Gpad rows + mirror) = 128 KB, one workgroup per CU.
 constexpr int WGF_X3_RING_MAX = 2 * 64 + 2 * 96;
+// Measured on this kernel (profiles/r03/c23_*, c25_*, c26_*), layer2, 231 us per launch including the 11 us reduce launch:
+// everything but the step loop 32 us; the loop with MFMAs only 108 us, with fragment reads only 52, with loads + splits + LDS
+// stores only 93 (68 steps, latency exposed without the MFMAs; removing them from the full kernel saves 54); the barrier 8.
+// Three restructurings left the 231 us unchanged: software-pipelined fragment reads (B fragments two items ahead, counted
+// waits), the split + store of the staged rows interleaved piece by piece under the MFMAs of the following step instead of
+// behind the last MFMA, and one instead of two steps of prefetch -- as in the fp16 kernel (103 us: 74 without its MFMAs, 88
+// without its DMA) the instruction classes of two lockstepped waves per SIMD overlap only partly.  Dependent MFMA chains are
+// not it: three back-to-back MFMAs into one accumulator run at 15.7 ns each against 14.4 ns round-robin
+// (tools/probes/mfma_dep_probe.hip, c24_*).
+// ABL (timing experiments only, MN_WGF_ABLATE in the ablation build; results are wrong): bit 0 = no loads / splits / LDS stores
+// after the prologue, bit 1 = fragment reads only in the first step, bit 2 = no MFMAs, bit 3 = no barrier per step.
+template <int ABL = 0>
 static __global__ void __launch_bounds__(512, 2) wgrad_fused_x3_kernel(WgradFusedArgs a) {
   constexpr int NW = 8, BKM = 8 * NW, ROWH = 64, NY = 2;
   constexpr int TILE_Y = BKM * ROWH;                       // elements of one dY tile plane
@@ -464,7 +476,7 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_x3_kernel(WgradFuse
 
   // one step: request step s + 2 into `nxt2`, MFMAs of step s, split + store step s + 1 from `nxt1` (requested a step ago)
   auto step = [&](int s, Staged& nxt2, Staged& nxt1) {
-    if (s + 2 < nsteps) {
+    if (s + 2 < nsteps && (ABL & 1) == 0) {
       load_y(s + 2, nxt2);
       load_x(2 * Gpad + BKM * (s + 2), nxt2);
     }
@@ -473,22 +485,30 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_x3_kernel(WgradFuse
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       TrFragB ah, al;
+      const bool rd = (ABL & 2) == 0 || s == 0;
 #pragma unroll
       for (int hlf = 0; hlf < 2; ++hlf) {
         const int off = aA + (ks * 16 + hlf * 4) * ROWH;
-        ah.h[hlf] = ds_read_tr16(tyh + off);
-        al.h[hlf] = ds_read_tr16(tyl + off);
+        ah.h[hlf] = ds_read_tr16(tyh + (rd ? off : 0));
+        al.h[hlf] = ds_read_tr16(tyl + (rd ? off : 0));
       }
 #pragma unroll
       for (int sl = 0; sl < 5; ++sl) {
         TrFragB bh, bl;
+        if ((ABL & 2) != 0 && s > 0) {
+          bh = ah;
+          bl = al;
+        } else {
 #pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-          const int off = xoffB[sl] + rbB[sl] + (ks * 16 + hlf * 4) * ROWH;
-          bh.h[hlf] = ds_read_tr16(xh + off);
-          bl.h[hlf] = ds_read_tr16(xl + off);
+          for (int hlf = 0; hlf < 2; ++hlf) {
+            const int off = xoffB[sl] + rbB[sl] + (ks * 16 + hlf * 4) * ROWH;
+            bh.h[hlf] = ds_read_tr16(xh + off);
+            bl.h[hlf] = ds_read_tr16(xl + off);
+          }
         }
-        if (sl < 4 || tset == 0) {  // wave-uniform: slot 4 of the 4-tap half carries no MFMA
+        if constexpr ((ABL & 4) != 0) {
+          asm volatile("" ::"v"(al.v), "v"(ah.v), "v"(bh.v), "v"(bl.v));
+        } else if (sl < 4 || tset == 0) {  // wave-uniform: slot 4 of the 4-tap half carries no MFMA
           acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[sl], 0, 0, 0);
           acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[sl], 0, 0, 0);
           acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[sl], 0, 0, 0);
@@ -500,11 +520,11 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_x3_kernel(WgradFuse
       rbB[sl] += BKM * ROWH;
       rbB[sl] -= rbB[sl] >= ring_elems ? ring_elems : 0;
     }
-    if (s + 1 < nsteps) {  // dY tile (s + 1) % 2 and the ring rows [64 (s - 1), 64 s) were last read in step s - 1
+    if (s + 1 < nsteps && (ABL & 1) == 0) {  // dY tile (s + 1) % 2 and the ring rows [64 (s - 1), 64 s) were last read in step s - 1
       store_y(s + 1, nxt1);
       store_x(2 * Gpad + BKM * (s + 1), nxt1);
     }
-    __syncthreads();
+    if constexpr ((ABL & 8) == 0) __syncthreads();
   };
   for (int s = 0; s < nsteps; s += 2) {
     step(s, st0, st1);
@@ -634,7 +654,18 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
             a.B, a.P, a.Q, a.C, a.N, a.chunk, a.nchunks, pairs, a.ring, a.ws != nullptr);
   const dim3 grid(a.nchunks * pairs), block(NW * 64);
   if (x3) {
-    hipLaunchKernelGGL(wgrad_fused_x3_kernel, grid, block, 0, stream, a);
+#ifdef MN_ABLATION_BUILD
+    static const int ablx = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
+#define MN_WGFX_ABL(V_)                                                          \
+  if (ablx == V_) {                                                              \
+    hipLaunchKernelGGL((wgrad_fused_x3_kernel<V_>), grid, block, 0, stream, a); \
+    wgrad_fused_reduce(a, stream);                                               \
+    return;                                                                      \
+  }
+    MN_WGFX_ABL(1) MN_WGFX_ABL(2) MN_WGFX_ABL(4) MN_WGFX_ABL(8) MN_WGFX_ABL(3) MN_WGFX_ABL(5) MN_WGFX_ABL(6) MN_WGFX_ABL(7) MN_WGFX_ABL(15)
+#undef MN_WGFX_ABL
+#endif
+    hipLaunchKernelGGL((wgrad_fused_x3_kernel<0>), grid, block, 0, stream, a);
     wgrad_fused_reduce(a, stream);
     return;
   }

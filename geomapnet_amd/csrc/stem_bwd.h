@@ -11,7 +11,8 @@
 // gathered from global memory issued 4 x 24 B of requests per 16 bytes of conv output and ran at the L2 request rate:
 // 450 + 570 us, no better than the four launches).
 //   1. stem_bn_reduce_kernel: sum(gm), sum(gm * xhat) per channel, gm = gathered gradient gated by the ReLU recomputed
-//      from the conv output; then bn_finalize_bwd_kernel (elementwise.h): d(gamma), d(beta), coefficients of the apply step;
+//      from the conv output (since round 3 in the order of the pooled windows, see the kernel); then bn_finalize_bwd_kernel
+//      (elementwise.h): d(gamma), d(beta), coefficients of the apply step;
 //   2. stem_wgrad_kernel: per tile, d(conv output) = k1 (gm - mean(gm) - xhat mean(gm xhat)) is computed into LDS, rounded
 //      to fp16 exactly as the stored tensor was, and contracted with the input read from an LDS-resident image of the
 //      zero-padded NHWC4 input (as stem.h's forward: a B fragment of the weight-gradient GEMM is a transpose read over
@@ -111,14 +112,28 @@ __device__ __forceinline__ void sb_tile_coords(const StemBwdArgs& a, int tile, i
 }
 
 // ---- 1. BatchNorm backward sums -----------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(256, 2) stem_bn_reduce_kernel(StemBwdArgs a) {
-  __shared__ piece_t smem[2 * kSbPOOL];  // ONE LDS object: two pool buffers (reused for the block reduction at the end)
+// Walks the POOLED windows, not the conv-output pixels (round 3): a window's gradient goes to exactly one pixel -- its recorded
+// argmax -- so  sum(gm) = sum over windows of gp * gate(y at the argmax),  sum(gm * xhat) likewise with xhat of that pixel:
+// one 2-byte LDS read per (window, channel) instead of, per conv-output element, four windows' argmax bytes compared against
+// the pixel's position (rounds 2: 348 us, bound by those ~110 VALU operations per 16-byte piece; the pixel order has 4x the
+// elements).  A workgroup of 512 threads owns tiles of 2 x 32 windows: the 5 x 65 conv-output pixels they cover (41.6 KB) are
+// staged in LDS by DMA, double-buffered; gp and the argmax bytes are read straight from memory, one 16-byte + one 8-byte
+// piece per thread and tile, requested one tile ahead.  (The sums differ from the pixel-order form's in one respect: that
+// form rounds a pixel's summed gradient to fp16 first, as the stored tensor of the four-launch chain was; here every window's
+// fp16 gradient enters the fp32 sums directly.)
+constexpr int kSrPH = 2, kSrPW = 32;                           // tile of pooled windows
+constexpr int kSrCH = 2 * kSrPH + 1, kSrCW = 2 * kSrPW + 1;    // 5 x 65 conv-output pixels
+constexpr int kSrPieces = kSrCH * kSrCW * 8;                   // 2600
+constexpr int kSrPasses = (kSrPieces + 511) / 512;             // 6
+constexpr int kSrBuf = kSrPasses * 512;                        // pieces per buffer (3072)
+static __global__ void __launch_bounds__(512, 2) stem_bn_reduce_kernel(StemBwdArgs a) {
+  __shared__ piece_t smem[2 * kSrBuf];  // two conv-output tiles (reused for the block reduction at the end)
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int ntiles = a.B * a.tiles_x * a.tiles_y;
-  const __amdgpu_buffer_rsrc_t rsrc_g = make_rsrc(a.gp, (long)a.B * a.Po * a.Qo * 64 * 2L);
-  const __amdgpu_buffer_rsrc_t rsrc_i = make_rsrc(a.idx, (long)a.B * a.Po * a.Qo * 64L);
-  const int cp = t & 7;
+  const int tiles_px = (a.Qo + kSrPW - 1) / kSrPW, tiles_py = (a.Po + kSrPH - 1) / kSrPH;
+  const int ntiles = a.B * tiles_px * tiles_py;
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.y, (long)a.B * a.H0 * a.W0 * 64 * 2L);
+  const int cp = t & 7, pc = (t >> 3) & 31, pr = t >> 8;
   float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -129,61 +144,72 @@ static __global__ void __launch_bounds__(256, 2) stem_bn_reduce_kernel(StemBwdAr
     sh[e] = a.beta[c] - mu[e] * sc[e];
     s1[e] = s2[e] = 0.f;
   }
-  // conv-output pieces of this thread in a tile: pixels (t >> 3) + 32 i, i < 4 -- plain loads, requested ONE TILE AHEAD
-  // (with the tile's windows) so that neither latency is exposed
-  auto load_y = [&](int tl, PieceView<half> (&v)[4]) {
-    int lb, ly0, lx0;
-    sb_tile_coords(a, tl, lb, ly0, lx0);
+  auto tile_coords = [&](int tile, int& b, int& p0, int& q0) {
+    const int tx = tile % tiles_px, tmp = tile / tiles_px;
+    b = tmp / tiles_py;
+    p0 = (tmp % tiles_py) * kSrPH;
+    q0 = tx * kSrPW;
+  };
+  auto issue_y = [&](int tile, int buf) {  // conv-output pixels rows 2 p0 - 1 .., columns 2 q0 - 1 ..
+    int b, p0, q0;
+    tile_coords(tile, b, p0, q0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int px = (t >> 3) + 32 * i, oy = ly0 + (px >> 5), ox = lx0 + (px & 31);
-      const int oyc = oy < a.H0 ? oy : a.H0 - 1, oxc = ox < a.W0 ? ox : a.W0 - 1;
-      v[i].p = *reinterpret_cast<const piece_t*>(a.y + (((long)lb * a.H0 + oyc) * a.W0 + oxc) * 64 + cp * 8);
+    for (int i = 0; i < kSrPasses; ++i) {
+      const int q = t + i * 512;
+      const int row = q / (kSrCW * 8), rem = q - row * (kSrCW * 8);
+      const int iy = 2 * p0 - 1 + row, ix = 2 * q0 - 1 + (rem >> 3);
+      const bool ok = q < kSrPieces && (unsigned)iy < (unsigned)a.H0 && (unsigned)ix < (unsigned)a.W0;
+      const unsigned off = ok ? (unsigned)(((b * a.H0 + iy) * a.W0 + ix) * 128 + (rem & 7) * 16) : ~0u;
+      if (wave * 64 + i * 512 < kSrPieces) dma16(rsrc_y, off, 0u, &smem[buf * kSrBuf + wave * 64 + i * 512]);
     }
   };
-  int tile = blockIdx.x, b, y0, x0;
-  PieceView<half> vy[4], vyn[4];
+  // this thread's window of a tile: gradient piece + argmax bytes, plain loads requested one tile ahead
+  struct Win {
+    PieceView<half> g;
+    unsigned long long taps;
+    bool ok;
+  };
+  auto load_win = [&](int tile, Win& w) {
+    int b, p0, q0;
+    tile_coords(tile, b, p0, q0);
+    const int po = p0 + pr, qo = q0 + pc;
+    w.ok = po < a.Po && qo < a.Qo;
+    const long at = (((long)b * a.Po + (w.ok ? po : 0)) * a.Qo + (w.ok ? qo : 0)) * 64 + cp * 8;
+    w.g.p = *reinterpret_cast<const piece_t*>(a.gp + at);
+    w.taps = *reinterpret_cast<const unsigned long long*>(a.idx + at);
+  };
+  int tile = blockIdx.x;
+  Win cur, nxt;
   if (tile < ntiles) {
-    sb_tile_coords(a, tile, b, y0, x0);
-    sb_issue_pool(a, rsrc_g, rsrc_i, b, y0, x0, &smem[0], t, wave);
-    load_y(tile, vy);
+    issue_y(tile, 0);
+    load_win(tile, cur);
   }
   for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-    sb_tile_coords(a, tile, b, y0, x0);
     wait_vmcnt<0>();
-    __syncthreads();  // this tile's windows are staged for everyone; everyone is done with the other buffer
+    __syncthreads();  // this tile's pixels are staged for everyone; everyone is done with the other buffer
     const bool more = tile + (int)gridDim.x < ntiles;
     if (more) {
-      int nb, ny0, nx0;
-      sb_tile_coords(a, tile + gridDim.x, nb, ny0, nx0);
-      sb_issue_pool(a, rsrc_g, rsrc_i, nb, ny0, nx0, &smem[((it + 1) & 1) * kSbPOOL], t, wave);
-      load_y(tile + gridDim.x, vyn);
+      issue_y(tile + gridDim.x, (it + 1) & 1);
+      load_win(tile + gridDim.x, nxt);
     }
-    const piece_t* pool = &smem[(it & 1) * kSbPOOL];
+    const half* yt = reinterpret_cast<const half*>(&smem[(it & 1) * kSrBuf]);
+    const int base = ((2 * pr) * kSrCW + 2 * pc) * 64 + cp * 8;  // element offset of the window's top-left pixel
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int px = (t >> 3) + 32 * i, oy = y0 + (px >> 5), ox = x0 + (px & 31);
-      const bool ok = oy < a.H0 && ox < a.W0;
-      float g[8];
-      sb_pool_grad(pool, ok ? oy : y0, ok ? ox : x0, y0, x0, cp, a.Po, a.Qo, g);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float yv = (float)vy[i].e[e];
-        float gv = ok ? g[e] : 0.f;
-        if (!(yv * sc[e] + sh[e] > 0.f)) gv = 0.f;
-        s1[e] += gv;
-        s2[e] += gv * (yv - mu[e]) * is[e];
-      }
+    for (int e = 0; e < 8; ++e) {
+      const int tap = (int)((cur.taps >> (8 * e)) & 0xffull);
+      const int r = (tap * 11) >> 5, sx = tap - 3 * r;  // tap = 3 r + s, tap <= 8
+      const float yv = (float)yt[base + (r * kSrCW + sx) * 64 + e];
+      float gv = cur.ok ? (float)cur.g.e[e] : 0.f;
+      if (!(yv * sc[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
+      s1[e] += gv;
+      s2[e] += gv * (yv - mu[e]) * is[e];
     }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) vy[i].p = vyn[i].p;
-    }
+    if (more) cur = nxt;
   }
-  // block reduction over the 32 threads that share a channel piece (t & 7), then fp64 atomics
+  // block reduction over the 64 threads that share a channel piece (t & 7), then fp64 atomics
   wait_vmcnt<0>();
   __syncthreads();
-  float* r1 = reinterpret_cast<float*>(&smem[0]);  // [256 threads][16]: 16 KB of the 24 KB
+  float* r1 = reinterpret_cast<float*>(&smem[0]);  // [512 threads][16]: 32 KB
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     r1[t * 16 + e] = s1[e];
@@ -193,7 +219,7 @@ static __global__ void __launch_bounds__(256, 2) stem_bn_reduce_kernel(StemBwdAr
   if (t < 128) {  // t = which * 64 + channel
     const int which = t >> 6, c = t & 63, ccp = c >> 3, ce = c & 7;
     double s = 0;
-    for (int l = 0; l < 32; ++l) s += r1[(l * 8 + ccp) * 16 + which * 8 + ce];
+    for (int l = 0; l < 64; ++l) s += r1[(l * 8 + ccp) * 16 + which * 8 + ce];
     double* row = a.accum + (long)((int)blockIdx.x % a.accum_rows) * 2 * 64;
     atomicAdd(row + which * 64 + c, s);
   }
@@ -378,7 +404,10 @@ inline int stem_bwd_grid(const StemBwdArgs& a, int per_cu) {
 // sums into a.accum (zero on entry); the caller runs bn_finalize_bwd_kernel on them
 inline void launch_stem_bn_reduce(StemBwdArgs a, int B, int H, int W, int Wp, hipStream_t stream) {
   stem_bwd_geometry(a, B, H, W, Wp);
-  hipLaunchKernelGGL(stem_bn_reduce_kernel, dim3(stem_bwd_grid(a, 2)), dim3(256), 0, stream, a);
+  const int ntiles = a.B * cdiv(a.Po, kSrPH) * cdiv(a.Qo, kSrPW);  // (tiles of pooled windows; one workgroup per CU)
+  static const int wgs = getenv("MN_STEM_WGS") ? atoi(getenv("MN_STEM_WGS")) : 0;
+  const int want = wgs > 0 ? wgs : 256;
+  hipLaunchKernelGGL(stem_bn_reduce_kernel, dim3(ntiles < want ? ntiles : want), dim3(512), 0, stream, a);
 }
 inline void launch_stem_wgrad(StemBwdArgs a, int B, int H, int W, int Wp, hipStream_t stream) {
   stem_bwd_geometry(a, B, H, W, Wp);

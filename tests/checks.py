@@ -1364,8 +1364,12 @@ def check_stem_bwd(lib, dev, B, H, W, seed=5):
     scale = dW_ref.abs().max().item()
     assert scale > 0
     assert (dW - dW_ref).abs().max().item() <= 2e-4 * scale, ((dW - dW_ref).abs().max().item(), scale)
-    np.testing.assert_allclose(dg.cpu().numpy(), dg_ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dg_ref.abs().max()))
-    np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(db_ref.abs().max()))
+    # d(gamma), d(beta): the chain sums the max-pool's input gradient as STORED (a pixel that is the argmax of several
+    # windows holds their sum rounded to fp16); stem_bn_reduce_kernel walks the windows and adds every window's fp16
+    # gradient to its fp32 sums unrounded -- the two differ by that rounding (5e-4 relative on the affected pixels), the
+    # window-order sums being the ones closer to exact arithmetic (part 2 below)
+    np.testing.assert_allclose(dg.cpu().numpy(), dg_ref.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(dg_ref.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(db_ref.abs().max()))
     # (2) torch fp64 on the same (fp16-representable) inputs: y is a leaf standing for the conv output
     y64 = y.cpu().double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
     g64 = gamma.cpu().double().requires_grad_(True)

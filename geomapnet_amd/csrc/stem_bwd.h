@@ -321,7 +321,11 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemBwdArgs a
       issue_tile(tile + gridDim.x, (it + 1) & 1);
       load_y(tile + gridDim.x, vyn);
     }
-    // ---- d(conv output) of the tile -> LDS
+    // ---- d(conv output) of the tile -> LDS.  (Measured and removed, round 3: the gather in WINDOW order as in
+    //      stem_bn_reduce_kernel -- every staged window adds its gradient with ds_add_f32 to an fp32 sum of its argmax pixel,
+    //      two tile rows at a time, then the sums are read back, rounded and turned into d(conv output) -- is slower, 869 vs
+    //      700 us for the two launches: the LDS atomics and three more barriers per tile cost more than the byte compares
+    //      they replace.  profiles/r03/c28_stem_wgrad_window_order_scatter.txt)
     const piece_t* pool = &smem[2 * IMG + (it & 1) * kSbPOOL];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

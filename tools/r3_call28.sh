@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 3, GPU call 27: stem BatchNorm-backward sums in pooled-window order (prev = pixel order)
+# round 3, GPU call 28: stem BatchNorm-backward sums in pooled-window order (prev = pixel order)
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r3c27; mkdir -p $O
+O=gpurun_out/r3c28; mkdir -p $O
 PREV=$PWD/tools/ablation/libmapnet_hip_prev.so
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "stem_backward or train_step or full_size_parity_mapnet" 2>&1 | tail -2 | tee $O/pytest.txt
 for l in prev new prev new; do

@@ -159,7 +159,7 @@ static __global__ void __launch_bounds__(512, 2) stem_bn_reduce_kernel(StemBwdAr
       const int row = q / (kSrCW * 8), rem = q - row * (kSrCW * 8);
       const int iy = 2 * p0 - 1 + row, ix = 2 * q0 - 1 + (rem >> 3);
       const bool ok = q < kSrPieces && (unsigned)iy < (unsigned)a.H0 && (unsigned)ix < (unsigned)a.W0;
-      const unsigned off = ok ? (unsigned)(((b * a.H0 + iy) * a.W0 + ix) * 128 + (rem & 7) * 16) : ~0u;
+      const unsigned off = ok ? (unsigned)((b * a.H0 + iy) * a.W0 + ix) * 128u + (unsigned)((rem & 7) * 16) : ~0u;  // (< 4 GiB: net.hip validate())
       if (wave * 64 + i * 512 < kSrPieces) dma16(rsrc_y, off, 0u, &smem[buf * kSrBuf + wave * 64 + i * 512]);
     }
   };

@@ -9,6 +9,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Last-use loads of the streaming kernels are NON-TEMPORAL: the BatchNorm forward apply's conv output (read again only in the
+// backward pass, a whole network later) and the backward apply's incoming gradient and conv output (never read again) do not
+// have to displace what the next convolution is about to read from L2 / Infinity Cache.  Whole step 13.59 -> 13.49 ms and
+// 14.33 -> 14.28 ms on two boxes (profiles/r03/c31_*, c32_*); making the backward REDUCTION's loads and the forward residual
+// non-temporal as well (they are read again by the apply kernel that follows / by the backward pass) measured no better.
+// The stem max-pool's input and the fused weight gradient's partial slabs as well: slightly slower (14.36 -> 14.40 ms, c33_*).
+#define MN_LOAD_LAST(p) __builtin_nontemporal_load(p)
+
 namespace mn {
 
 typedef _Float16 half;

@@ -216,7 +216,7 @@ static __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restric
   }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
     PieceView<T> v, r, o;
-    v.p = reinterpret_cast<const piece_t*>(y)[i];
+    v.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(y) + i);
     if (res) r.p = reinterpret_cast<const piece_t*>(res)[i];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -467,9 +467,9 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
 #pragma unroll
       for (int e = 0; e < VEC; ++e) vg.e[e] = (T)a[e];
     } else {
-      vg.p = reinterpret_cast<const piece_t*>(g)[i];
+      vg.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(g) + i);
     }
-    vy.p = reinterpret_cast<const piece_t*>(y)[i];
+    vy.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(y) + i);
     if (gate) vm.p = reinterpret_cast<const piece_t*>(gate)[i];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {

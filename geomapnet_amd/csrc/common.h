@@ -40,7 +40,22 @@ enum { MN_F32 = 0, MN_F16 = 1 };
 //               tools/probes/mfma_denorm_probe.hip -- so their absolute error stays below 2^-25).
 //   MMA_BF16X3  the same with bf16 halves (x = hi + lo to ~2^-16, fp32's exponent range: no scaling, nothing can over- or
 //               underflow).  Used for the backward pass, whose operands (activation gradients) span many binades.
-enum { MMA_NATIVE = 0, MMA_F16X3 = 1, MMA_BF16X3 = 2 };
+//   MMA_H2      (fp16-PAIR tensors, "h2", round 4; kernels instantiated for `half`): the operands are ALREADY split -- every
+//               conv-consumed tensor is stored as hi + lo fp16 halves (layout below), so tiles travel HBM -> LDS by DMA like
+//               fp16 tiles and a product is the same three v_mfma_f32_32x32x16_f16, with no conversion in the K loop.
+enum { MMA_NATIVE = 0, MMA_F16X3 = 1, MMA_BF16X3 = 2, MMA_H2 = 3 };
+
+// ---- the h2 ("fp16 pair") tensor layout ---------------------------------------------------------------------------------
+// A tensor [rows][C] of fp32-class values, C a multiple of 32, 4 bytes per element like fp32: per row and per GROUP of 32
+// channels 64 bytes of hi halves (rn/rtz fp16 of x) followed by 64 bytes of lo halves (fp16 of x - hi):
+//     half index of (row, c) = row * 2C + (c / 32) * 64 + (c % 32)   [hi]      + 32   [lo]
+// x = hi + lo to 2^-22 relative while lo is a normal fp16 number, 2^-25 absolute below that; |x| must stay below 65504
+// (activations are O(1); gradients are kept in range by the loss scale and the overflow guard of the fp16 mode).
+// Why groups of 32: a 128-byte K-step of an MFMA kernel is then ONE group -- 16-k fragments hi[0:16], hi[16:32], lo[0:16],
+// lo[16:32] -- and in the transposed (weight-gradient) use a 32-row MFMA operand block is 32 hi or 32 lo channels, so
+// hi*hi + hi*lo + lo*hi accumulate into ONE 32x32 tile.  To every DMA / gather path the tensor is simply an fp16 tensor
+// with 2C channels.
+__host__ __device__ inline long h2_index(long row, int C, int c) { return row * 2L * C + (long)(c >> 5) * 64 + (c & 31); }
 
 template <typename T>
 struct ElemTraits;

@@ -58,9 +58,28 @@ inline DgradGeom make_dgrad_geom(int B, int Hin, int Win, int cin, int cout, int
 // `wd`: weights in the data-gradient layout [Cin][R][S][Cout].  `parity`: use the decomposition when it applies.
 // Classes no tap reaches (1x1 stride 2: three of four) have a zero gradient: they are only skipped when the residual
 // is accumulated in place (ep.res == ep.out), where they are already right; otherwise the generic form runs.
+// `h2` (T = half only): gy / wd are h2 tensors (common.h), the gradient and the residual fp32, the gates h2; the geometry
+// counts real channels (make_dgrad_geom with vec = 4).
 template <typename T>
 inline void launch_conv_dgrad(const DgradGeom& d, const T* gy, const T* wd, const Epilogue& ep, hipStream_t s, const T* zero_page,
-                              bool parity) {
+                              bool parity, bool h2 = false) {
+  if constexpr (std::is_same<T, half>::value) {
+    if (h2) {
+      if (parity && d.n_pc > 0 && (d.n_pc == 4 || ep.res == ep.out)) {
+        for (int i = 0; i < d.n_pc; ++i) {
+          const DgradParityClass& c = d.pc[i];
+          Epilogue e2 = ep;
+          e2.om_on = 1; e2.om_P = c.P; e2.om_Q = c.Q; e2.om_H = d.Hin; e2.om_W = d.Win; e2.om_a = c.a; e2.om_b = c.b;
+          e2.om_dq = make_fastdiv(c.Q);
+          e2.om_dp = make_fastdiv(c.P);
+          launch_igemm_h2(c.g, gy, wd, e2, s, zero_page);
+        }
+        return;
+      }
+      launch_igemm_h2(d.full, gy, wd, ep, s, zero_page);
+      return;
+    }
+  }
   if (parity && d.n_pc > 0 && (d.n_pc == 4 || ep.res == ep.out)) {
     for (int i = 0; i < d.n_pc; ++i) {
       const DgradParityClass& c = d.pc[i];

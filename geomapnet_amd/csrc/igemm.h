@@ -31,6 +31,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mn {
@@ -221,6 +223,10 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
                                                                          const T* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                          const T* __restrict__ zero_page, RowDiv rd) {
   constexpr int VEC = ElemTraits<T>::VEC;
+  // h2 (MM = MMA_H2, T = half): g.C / g.K / g.ldb count the 2C fp16 "channels" of the pair layout (common.h) -- every gather
+  // and DMA below is the fp16 kernel's; what differs is the MFMA order of a K-step and the epilogue (fp32 output)
+  constexpr bool H2 = MM == MMA_H2;
+  static_assert(!H2 || (sizeof(T) == 2 && NP == 8 && UNI), "h2: fp16 pieces, one 32-channel group per K-step");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int WTM = TM * 32, WTN = TN * 32;
@@ -410,7 +416,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   // group of tile kt + 1 can be split under the MFMAs of the second group of tile kt:
   //     [M(kt, 0) | C(kt, 1)]  wait + barrier  DMA(kt + 2)  [M(kt, 1) | C(kt + 1, 0)]
   // (the form without this overlap: layer3 forward 313 us of which ~94 us are the splits, c5_ablation_fp32x3_*.txt)
-  constexpr bool X3_PIPE = MM != MMA_NATIVE && NP == 8 && NBUF == 2 && !SPL && ABL == 0;
+  constexpr bool X3_PIPE = MM != MMA_NATIVE && !H2 && NP == 8 && NBUF == 2 && !SPL && ABL == 0;
   if constexpr (X3_PIPE) {
     constexpr int P = TM * TN, F = TM + TN;
     X3Frag<MM> xa[2][TM], xb[2][TN];  // [group parity]
@@ -499,7 +505,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #else
     const int ln = lane;
 #endif
-    if constexpr (MM != MMA_NATIVE) {
+    if constexpr (MM != MMA_NATIVE && !H2) {
       static_assert(sizeof(T) == 4 && NP % 4 == 0, "x3 modes: fp32 tensors, whole groups of four pieces");
       // (ABL, timing experiments: bits 0-2 as above; bit 3 = no operand splits, bit 4 = no MFMAs)
       constexpr int NKP = NP / 4;
@@ -562,6 +568,42 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
           if (more) issue_part(nxt, kp * IPT / NKP, (kp + 1) * IPT / NKP);
         }
       }
+    } else if constexpr (H2) {
+      // h2 operands (common.h): the K-step's eight pieces are one 32-channel group, pieces 0-3 its hi halves, 4-7 its lo
+      // halves; 16-k fragment (plane pl, half h of the group) = pieces 4 pl + 2 h + {0, 1}.  Per half: hi and lo fragments of
+      // both operands, three MFMAs per tile pair (small terms first); the second half's reads fly under the first half's MFMAs.
+      PieceView<half> fa[2][2][TM], fb[2][2][TN];  // [half of the group][plane]
+      auto load_h2 = [&](int h) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const int pxs = (4 * pl + 2 * h + (ln >> 5)) ^ lds_swz<NP>(ln & 31);
+          const piece_t* pa = ta + (wm * WTM + (ln & 31)) * NP + pxs;
+          const piece_t* pb = ta + (BM + wn * WTN + (ln & 31)) * NP + pxs;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[h][pl][i].p = pa[i * 32 * NP];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[h][pl][j].p = pb[j * 32 * NP];
+        }
+      };
+      load_h2(0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 0) load_h2(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            mma_piece<half>(fa[h][1][i], fb[h][0][j], acc[i][j]);
+            mma_piece<half>(fa[h][0][i], fb[h][1][j], acc[i][j]);
+            mma_piece<half>(fa[h][0][i], fb[h][0][j], acc[i][j]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SPL) {
+          if (more) issue_part(nxt, h * IPT / 2, (h + 1) * IPT / 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     } else {
     PieceView<T> fa[2][TM], fb[2][TN];
     auto load_frags = [&](int ks, int slot) {
@@ -604,14 +646,18 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   __syncthreads();  // all fragment reads done before the ring is reused as epilogue staging
 
   // ---- epilogue ---------------------------------------------------------------------------------
-  T* out = reinterpret_cast<T*>(ep.out);
-  const T* res = reinterpret_cast<const T*>(ep.res);
+  // h2: the output (raw conv output / data gradient, consumed by the BatchNorm kernels) and the residual are fp32 [M][ldc];
+  // the gates are h2 activations, of which only the hi halves are read (the sign of x is the sign of its hi half)
+  using OT = typename std::conditional<H2, float, T>::type;
+  constexpr int OVEC = 16 / (int)sizeof(OT);
+  OT* out = reinterpret_cast<OT*>(ep.out);
+  const OT* res = reinterpret_cast<const OT*>(ep.res);
   const T* gate = reinterpret_cast<const T*>(ep.res_gate);
   const T* ogate = reinterpret_cast<const T*>(ep.out_gate);
   const float alpha = ep.alpha;
   float* stage = reinterpret_cast<float*>(&smem[0]);  // [64][SC] fp32 sub-block
   constexpr int SC = BN < 128 ? BN : 128;             // columns staged per round
-  constexpr int CPR = SC / VEC;                       // output pieces per staged row
+  constexpr int CPR = SC / OVEC;                      // output pieces per staged row
   // wave rows staged per round: two (64 rows, fits every ring), or all three of the 12-wave configuration (96 rows =
   // 48 KB of its 150 KB ring: 6 rounds of two full store passes instead of 12 rounds of 1.33)
   constexpr int WR = (WM == 3 && NBUF * TILE_PIECES * 16 >= 96 * SC * 4) ? 3 : 2;
@@ -648,12 +694,12 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
           const int id = t + ps * NT;
           const int lr = id / CPR, cpc = id % CPR;
           const int row = m0 + (WR * mh + (lr >> 5)) * WTM + i * 32 + (lr & 31);
-          const int col = n0 + nh * SC + cpc * VEC;
+          const int col = n0 + nh * SC + cpc * OVEC;
           if (lr < WR * 32 && WR * mh + (lr >> 5) < WM && row < g.M && col < g.N) {
-            float v[VEC];
+            float v[OVEC];
 #pragma unroll
-            for (int e = 0; e < VEC; e += 4) {
-              floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * SC + cpc * VEC + e]);
+            for (int e = 0; e < OVEC; e += 4) {
+              floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * SC + cpc * OVEC + e]);
               v[e] = f[0];
               v[e + 1] = f[1];
               v[e + 2] = f[2];
@@ -666,6 +712,32 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
               orow = ((long)ob * ep.om_H + 2 * op + ep.om_a) * ep.om_W + 2 * oq + ep.om_b;
             }
             const long idx = orow * ep.ldc + col;
+            if constexpr (H2) {
+              const long gidx = h2_index(orow, ep.ldc, col);  // hi halves of the gate's channels col .. col + 3
+              if (res) {
+                PieceView<float> rv;
+                Half4View gv;
+                rv.p = *reinterpret_cast<const piece_t*>(res + idx);
+                if (gate) gv.p = *reinterpret_cast<const u32x2*>(gate + gidx);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float x = rv.e[e];
+                  if (gate && !((float)gv.e[e] > 0.f)) x = 0.f;
+                  v[e] += x;
+                }
+              }
+              if (ogate) {
+                Half4View ov;
+                ov.p = *reinterpret_cast<const u32x2*>(ogate + gidx);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (!((float)ov.e[e] > 0.f)) v[e] = 0.f;
+              }
+              PieceView<float> o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o.e[e] = v[e];
+              *reinterpret_cast<piece_t*>(out + idx) = o.p;
+            } else {
             if (res) {
               PieceView<T> rv, gv;
               rv.p = *reinterpret_cast<const piece_t*>(res + idx);
@@ -688,6 +760,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o.e[e] = (T)v[e];
             *reinterpret_cast<piece_t*>(out + idx) = o.p;
+            }
           }
         }
         __syncthreads();
@@ -895,6 +968,39 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
   // on layer3, so the ring depth is not what limits it; 288x128 tiles of 6 waves, two workgroups per CU -- 131 us)
   if (wide_k) return launch_igemm_cfg<T, 2, 2, 2, 2, 8, 2, 2>(g, A, Bw, ep, stream, zero_page);
   return launch_igemm_cfg<T, 2, 2, 2, 2, 4, 4, 2>(g, A, Bw, ep, stream, zero_page);
+}
+
+// h2 operands (common.h MMA_H2): `g_in` describes the convolution in REAL channels; A is an h2 tensor [B][Hi][Wi][C], Bw an
+// h2 weight matrix [N][taps][C] (row pitch ldb real elements), out / res fp32, gates h2.  The kernels see fp16 tensors with 2C
+// channels.  128x128 / 128x64 tiles of four waves, two workgroups per CU (3x3 stride-1 shapes go to igemm_halo.h).
+inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream);
+inline int launch_igemm_h2(const GatherGeom& g_in, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
+                           const half* zero_page) {
+  GatherGeom g = g_in;
+  g.C = 2 * g_in.C;
+  g.K = 2 * g_in.K;
+  g.ldb = 2 * g_in.ldb;
+  g.mma = MMA_H2;
+  g.tap_inner = (g.R * g.S > 1 || g.bt_on) ? 1 : 0;
+  RowDiv rd;
+  rd.q = make_fastdiv(g.Q);
+  rd.p = make_fastdiv(g.P);
+  static const int halo_level = getenv("MN_IGEMM_HALO") ? atoi(getenv("MN_IGEMM_HALO")) : 2;
+  if (halo_level > 0) {
+    const int gm_halo = launch_igemm_halo_h2(g, A, Bw, ep, stream);
+    if (gm_halo >= 0) return gm_halo;
+  }
+#define MN_H2_CFG(WM_, WN_, TM_, TN_, NP_, NBUF_, MINW_)                                                                   \
+  {                                                                                                                        \
+    constexpr int BM = WM_ * TM_ * 32, BN = WN_ * TN_ * 32;                                                                \
+    const int gm = cdiv(g.M, BM), gn = cdiv(g.N, BN);                                                                      \
+    hipLaunchKernelGGL((igemm_kernel<half, WM_, WN_, TM_, TN_, NP_, NBUF_, MINW_, true, false, 0, MMA_H2>), dim3(gm * gn), \
+                       dim3(WM_ * WN_ * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd);                                  \
+    return gm;                                                                                                             \
+  }
+  if (g.N <= 64) MN_H2_CFG(2, 2, 2, 1, 8, 2, 2)
+  MN_H2_CFG(2, 2, 2, 2, 8, 2, 2)
+#undef MN_H2_CFG
 }
 
 }  // namespace mn

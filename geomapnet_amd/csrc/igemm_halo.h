@@ -38,7 +38,10 @@ namespace mn {
 // ABL (timing experiments only, ablation build, MN_HALO_ABLATE; results are wrong): bit 0 = no epilogue (no staging, stores,
 // residual / gate loads, statistics), bit 1 = K loop cut to its first K-step, bit 2 = no DMA in the K loop, bit 3 = fragment
 // reads only in the first K-step, bit 4 = no MFMAs.
-template <int BN, int kAH, int ABL = 0, int DP = 1>
+// H2 (round 4): h2 operands (common.h MMA_H2) -- g.C / g.K count the 2C fp16 channels of the pair layout, a 64-"channel" chunk
+// is one 32-channel group (hi halves | lo halves), a K-step = three MFMAs per tile pair and 16-k half of the group, the output
+// (and the residual) fp32, the gates h2.  Same LDS-DMA traffic per K-step as the fp16 kernel for 1.5x its MFMAs.
+template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false>
 static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
@@ -159,6 +162,48 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
       ainv[i] = ((inv_mask >> (9 * i + tap)) & 1u) != 0;
     }
     const int brow = wn * WTN + l31, bswz = lds_swz<NP>(l31);  // B rows: multiples of 32 plus l31
+    if constexpr (H2) {
+      // fragment (plane pl, 16-k half h of the group) = pieces 4 pl + 2 h + {0, 1}.  The 128-column shape (48 accumulator
+      // registers) keeps both halves' fragments in registers -- the second half's reads fly under the first half's MFMAs --
+      // the 256-column shape (96 accumulator registers of the 168 a wave may have) one half at a time.
+      constexpr int NS = BN == 128 ? 2 : 1;
+      PieceView<half> xa[NS][2][TM], xb[NS][2][TN];  // [slot][plane]
+      auto load_h2 = [&](int h, int slot) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const int piece = 4 * pl + 2 * h + hi;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const piece_t* p = ainv[i] ? &smem[RING] : img + arow[i] * NP + (piece ^ aswz[i]);
+            xa[slot][pl][i].p = *p;
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) xb[slot][pl][j].p = tb[(brow + j * 32) * NP + (piece ^ bswz)];
+        }
+      };
+      load_h2(0, 0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int sl = NS == 2 ? h : 0;
+        if (NS == 2 && h == 0) load_h2(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            mma_piece<half>(xa[sl][1][i], xb[sl][0][j], acc[i][j]);
+            mma_piece<half>(xa[sl][0][i], xb[sl][1][j], acc[i][j]);
+            mma_piece<half>(xa[sl][0][i], xb[sl][0][j], acc[i][j]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (NS == 1 && h == 0) load_h2(1, 0);
+        if constexpr (DP > 0)
+          if (h == 0) {
+            issue_step();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+    } else {
     PieceView<half> fa[2][TM], fb[2][TN];
     auto load_frags = [&](int ks, int slot) {
       const int piece = ks * 2 + hi;
@@ -193,6 +238,7 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
           __builtin_amdgcn_sched_barrier(0);
         }
     }
+    }  // fp16 / h2
     if (++ts == 3) {
       ts = 0;
       ++tr;
@@ -215,12 +261,14 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
 
   // ---- epilogue: igemm.h's (alpha, bias, ReLU, BatchNorm column sums, residual / gates, 16-byte stores), three wave
   //      rows staged per round; no output row map, no stream-K -------------------------------------------------------
-  half* out = reinterpret_cast<half*>(ep.out);
-  const half* res = reinterpret_cast<const half*>(ep.res);
+  using OT = typename std::conditional<H2, float, half>::type;  // h2: fp32 output and residual, h2 gates (hi halves read)
+  constexpr int OVEC = 16 / (int)sizeof(OT);
+  OT* out = reinterpret_cast<OT*>(ep.out);
+  const OT* res = reinterpret_cast<const OT*>(ep.res);
   const half* gate = reinterpret_cast<const half*>(ep.res_gate);
   const half* ogate = reinterpret_cast<const half*>(ep.out_gate);
   float* stage = reinterpret_cast<float*>(&smem[0]);  // [96][128] fp32
-  constexpr int SC = 128, CPR = SC / VEC, PASSES = (WM * 32 * CPR + NT - 1) / NT;  // 2
+  constexpr int SC = 128, CPR = SC / OVEC, PASSES = (WM * 32 * CPR + NT - 1) / NT;  // 2 (h2: 4)
   float s1[TN], s2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
@@ -249,18 +297,44 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
         const int id = t + ps * NT;
         const int lr = id / CPR, cpc = id % CPR;
         const int row = m0 + (lr >> 5) * WTM + i * 32 + (lr & 31);
-        const int col = n0 + nh * SC + cpc * VEC;
+        const int col = n0 + nh * SC + cpc * OVEC;
         if (lr < WM * 32 && row < g.M && col < g.N) {
-          float v[VEC];
+          float v[OVEC];
 #pragma unroll
-          for (int e = 0; e < VEC; e += 4) {
-            floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * SC + cpc * VEC + e]);
+          for (int e = 0; e < OVEC; e += 4) {
+            floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * SC + cpc * OVEC + e]);
             v[e] = f[0];
             v[e + 1] = f[1];
             v[e + 2] = f[2];
             v[e + 3] = f[3];
           }
           const long idx = (long)row * ep.ldc + col;
+          if constexpr (H2) {
+            const long gidx = h2_index(row, ep.ldc, col);
+            if (res) {
+              PieceView<float> rv;
+              Half4View gv;
+              rv.p = *reinterpret_cast<const piece_t*>(res + idx);
+              if (gate) gv.p = *reinterpret_cast<const u32x2*>(gate + gidx);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float x = rv.e[e];
+                if (gate && !((float)gv.e[e] > 0.f)) x = 0.f;
+                v[e] += x;
+              }
+            }
+            if (ogate) {
+              Half4View ov;
+              ov.p = *reinterpret_cast<const u32x2*>(ogate + gidx);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (!((float)ov.e[e] > 0.f)) v[e] = 0.f;
+            }
+            PieceView<float> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.e[e] = v[e];
+            *reinterpret_cast<piece_t*>(out + idx) = o.p;
+          } else {
           if (res) {
             PieceView<half> rv, gv;
             rv.p = *reinterpret_cast<const piece_t*>(res + idx);
@@ -283,6 +357,7 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
 #pragma unroll
           for (int e = 0; e < VEC; ++e) o.e[e] = (half)v[e];
           *reinterpret_cast<piece_t*>(out + idx) = o.p;
+          }
         }
       }
       __syncthreads();
@@ -362,6 +437,28 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
 #undef MN_HALO_ABL
 #endif
     hipLaunchKernelGGL((igemm_halo_kernel<128, 384>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 128, rd);
+    return gm;
+  }
+  return -1;
+}
+
+// h2 form: `g2` is the doubled geometry launch_igemm_h2 builds (g2.C = 2 x real channels); every 3x3 stride-1 shape the fp16
+// kernels cover, the 256-column shape when it fills the chip in one round (layer3), the 128-column shape otherwise
+inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream) {
+  const int gm = cdiv(g2.M, 288);
+  RowDiv rd;
+  rd.q = make_fastdiv(g2.Q);
+  rd.p = make_fastdiv(g2.P);
+  const long tiles288 = (long)gm * (g2.N / 256);
+  static const bool force256 = getenv("MN_H2_HALO256") && atoi(getenv("MN_H2_HALO256")) != 0;  // (parity tests on small problems)
+  if (g2.N % 256 == 0 && ((tiles288 > 192 && tiles288 <= device_cus()) || force256) && igemm_halo_applies(g2, ep, 256, 352)) {
+    hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
+                       g2.N / 256, rd);
+    return gm;
+  }
+  if (igemm_halo_applies(g2, ep, 128, 384)) {
+    hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,
+                       g2.N / 128, rd);
     return gm;
   }
   return -1;

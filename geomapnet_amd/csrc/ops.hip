@@ -41,6 +41,7 @@ static GatherGeom to_geom(const mn_gather_geom* g) {
 
 static int check_geom(const GatherGeom& g, int dtype) {
   int vec = dtype == MN_F16 ? 8 : 4;
+  if (dtype == MN_DTYPE_F16X2 && (g.C % 32 != 0 || g.N % 4 != 0)) return fail("igemm: h2 operands need C % 32 == 0");
   if (g.C % vec != 0) return fail("igemm: C must be a multiple of the 16-byte piece");
   if (g.K != g.R * g.S * g.C) return fail("igemm: K != R*S*C");
   if (g.K % (4 * vec) != 0) return fail("igemm: K must be a multiple of the 64-byte K-step");
@@ -70,6 +71,10 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
   ep.alpha = alpha;
   if (dtype == MN_DTYPE_F32X3) g.mma = MMA_F16X3;  // fp32 tensors, f16 matrix pipe with split operands
+  if (dtype == MN_DTYPE_F16X2) {  // h2 operands (A, Bw, res_gate), fp32 out / res
+    launch_igemm_h2(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, (const half*)zero_page);
+    return check_launch("igemm");
+  }
   if (dtype == MN_F16)
     launch_igemm<half>(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, (const half*)zero_page);
   else
@@ -190,6 +195,7 @@ extern "C" int mn_op_conv_dgrad(int dtype, int B, int Hin, int Win, int Cin, int
   if (!zero_page) return fail("conv_dgrad: zero_page (>= 16 zero bytes of device memory) is required");
   const int Hout = (Hin + 2 * pad - k) / stride + 1, Wout = (Win + 2 * pad - k) / stride + 1;
   const int vec = dtype == MN_F16 ? 8 : 4;
+  if (dtype == MN_DTYPE_F16X2 && (Cin % 32 != 0 || Cout % 32 != 0)) return fail("conv_dgrad: h2 operands need channel counts % 32 == 0");
   DgradGeom d = make_dgrad_geom(B, Hin, Win, Cin, Cout, k, stride, pad, Hout, Wout, vec);
   if (int e = check_geom(d.full, dtype)) return e;
   if (Cin % vec != 0) return fail("conv_dgrad: Cin must be a multiple of the 16-byte piece");
@@ -200,7 +206,9 @@ extern "C" int mn_op_conv_dgrad(int dtype, int B, int Hin, int Win, int Cin, int
     d.full.mma = MMA_BF16X3;
     for (int i = 0; i < d.n_pc; ++i) d.pc[i].g.mma = MMA_BF16X3;
   }
-  if (dtype == MN_F16)
+  if (dtype == MN_DTYPE_F16X2)  // gy, wd, res_gate, out_gate h2; gx, res fp32
+    launch_conv_dgrad<half>(d, (const half*)gy, (const half*)wd, ep, (hipStream_t)stream, (const half*)zero_page, parity != 0, true);
+  else if (dtype == MN_F16)
     launch_conv_dgrad<half>(d, (const half*)gy, (const half*)wd, ep, (hipStream_t)stream, (const half*)zero_page, parity != 0);
   else
     launch_conv_dgrad<float>(d, (const float*)gy, (const float*)wd, ep, (hipStream_t)stream, (const float*)zero_page,

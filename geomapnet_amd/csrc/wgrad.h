@@ -520,8 +520,19 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
 union TrFragB {
   v4s16 h[2];
   bf16x8 v;
+  half8 f;
 };
-template <int BMO, int BNO>
+// the hi halves and the lo halves of channels c .. c + 3 (c % 4 == 0) of row `row` of an h2 tensor with C channels: {hi, hi, lo, lo}
+__device__ __forceinline__ piece_t h2_load4(const half* base, long row, int C, int c) {
+  const half* p = base + h2_index(row, C, c);
+  const u32x2 hi = *reinterpret_cast<const u32x2*>(p), lo = *reinterpret_cast<const u32x2*>(p + 32);
+  piece_t r = {hi[0], hi[1], lo[0], lo[1]};
+  return r;
+}
+// H2 (round 4, MMA_H2): dY and X are h2 tensors (common.h) -- already split: a thread fetches the 4 hi and the 4 lo halves of its
+// four channels (two 8-byte loads) and stores them to the planes as they are; fp16 MFMAs.  (Stride-2 / 1x1 shapes only: the
+// 3x3 stride-1 layers go to wgrad_fused.h's DMA-fed h2 kernel.)
+template <int BMO, int BNO, bool H2 = false>
 static __global__ void __launch_bounds__(256, 2) wgrad_x3_kernel(WgradArgs a) {
   constexpr int BKM = 32;                       // m rows per step
   constexpr int YCP = BMO / 4, XCP = BNO / 4;   // float pieces per row
@@ -563,6 +574,9 @@ static __global__ void __launch_bounds__(256, 2) wgrad_x3_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < YPT; ++i) {
       const int m = mt + yrow + i * YRS;
+      if constexpr (H2)
+        ry[i] = (y_col_ok && m < m_end) ? h2_load4(reinterpret_cast<const half*>(a.dY), m, a.ldy, n0 + ycp * 4) : zero_piece();
+      else
       ry[i] = (y_col_ok && m < m_end) ? *reinterpret_cast<const piece_t*>(dY + (long)m * a.ldy + n0 + ycp * 4) : zero_piece();
     }
 #pragma unroll
@@ -576,6 +590,9 @@ static __global__ void __launch_bounds__(256, 2) wgrad_x3_kernel(WgradArgs a) {
         wn_ >>= 1;
       }
       ok = ok && (unsigned)hn < (unsigned)g.Hi && (unsigned)wn_ < (unsigned)g.Wi;
+      if constexpr (H2)
+        rx[i] = ok ? h2_load4(reinterpret_cast<const half*>(a.X), (long)(xb[i] * g.Hi + hn) * g.Wi + wn_, g.C, c0) : zero_piece();
+      else
       rx[i] = ok ? *reinterpret_cast<const piece_t*>(X + ((long)((xb[i] * g.Hi + hn) * g.Wi + wn_) * g.C + c0)) : zero_piece();
       xq[i] += BKM;
       while (xq[i] >= g.Q) {
@@ -595,10 +612,17 @@ static __global__ void __launch_bounds__(256, 2) wgrad_x3_kernel(WgradArgs a) {
       __bf16 b[4];
       u32x2 u;
     } h, l;
+    if constexpr (H2) {  // {hi halves, lo halves} as loaded
+      h.u[0] = raw[0];
+      h.u[1] = raw[1];
+      l.u[0] = raw[2];
+      l.u[1] = raw[3];
+    } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       h.b[e] = (__bf16)v.e[e];
       l.b[e] = (__bf16)(v.e[e] - (float)h.b[e]);
+    }
     }
     const int at = row * W + (((col >> 3) ^ swz) * 8) + (col & 7);
     *reinterpret_cast<u32x2*>(hi_plane + at) = h.u;
@@ -669,9 +693,15 @@ static __global__ void __launch_bounds__(256, 2) wgrad_x3_kernel(WgradArgs a) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+          if constexpr (H2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].f, bh[j].f, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].f, bl[j].f, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].f, bh[j].f, acc[i][j], 0, 0, 0);
+          } else {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+          }
         }
     }
     if (more) store_tile(cur ^ 1);

@@ -36,8 +36,16 @@ extern "C" {
  *                 in the backward pass).  fp32-class results (the reference computes in fp32, common/train.py:322-363)
  *                 at several times the fp32 pipe's rate: the mode the parity bar is met in.  Operator entry points accept
  *                 it where their dtype argument selects the arithmetic (mn_op_igemm, mn_op_wgrad, mn_op_conv_dgrad: 2 =
- *                 f16x3 for igemm, bf16x3 for wgrad / dgrad; tensors are fp32). */
-enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1, MN_DTYPE_F32X3 = 2 };
+ *                 f16x3 for igemm, bf16x3 for wgrad / dgrad; tensors are fp32).
+ * MN_DTYPE_F16X2: (round 4) fp32-class values stored as fp16 PAIRS ("h2": hi + lo halves, 4 bytes per element like fp32, x to
+ *                 2^-22; layout in geomapnet_amd/csrc/common.h: per row and 32-channel group 64 bytes of hi halves, then 64
+ *                 bytes of lo halves).  Every tensor a convolution CONSUMES (activations, weight copies, d(conv output)) is
+ *                 h2 and is split once, by the kernel that produces it; conv outputs, data gradients and everything the
+ *                 BatchNorm / pooling / head / optimiser kernels compute on stay fp32.  The convolutions then run three
+ *                 v_mfma_f32_32x32x16_f16 per product on operands that reach LDS by DMA, with no conversion in their K loops.
+ *                 Gradients are kept inside fp16's range by the loss scale + overflow guard of MN_DTYPE_F16.  Operator entry
+ *                 points: dtype 3 = A / Bw / dY / X / gates h2, out / res / dW fp32. */
+enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1, MN_DTYPE_F32X3 = 2, MN_DTYPE_F16X2 = 3 };
 /* criterion / batch-layout modes */
 enum {
   MN_MODE_POSENET = 0,      /* PoseNetCriterion,        common/criterion.py:33-52   */

@@ -15,10 +15,11 @@ from geomapnet_amd._binding import GatherGeom, ptr
 from geomapnet_amd.posenet import _view
 
 # dtype 2 = MN_DTYPE_F32X3: fp32 tensors, contraction on the f16 / bf16 matrix pipe with split (hi + lo) operands
-TD = {0: torch.float32, 1: torch.float16, 2: torch.float32}
+# dtype 3 = MN_DTYPE_F16X2: conv operands / gates are h2 tensors (fp16 pairs, helpers below), everything else fp32
+TD = {0: torch.float32, 1: torch.float16, 2: torch.float32, 3: torch.float32}
 # output rounding of the storage type relative to the largest output magnitude (x3: 2^-22 per product with fp16 halves,
 # 2^-16 with the bf16 halves of the backward operators)
-OUT_TOL = {0: 2e-5, 1: 2e-3, 2: 5e-5}
+OUT_TOL = {0: 2e-5, 1: 2e-3, 2: 5e-5, 3: 2e-5}
 
 
 def f32(x):
@@ -73,15 +74,51 @@ def _nhwc(x, td, dev):
     return x.permute(0, 2, 3, 1).contiguous().to(td).to(dev)
 
 
+# ---- h2 tensors (geomapnet_amd/csrc/common.h): [..., C] fp32-class values as [..., C/32][hi | lo][32] fp16 ----------------
+def h2_value(x):
+    """the value an h2 tensor holds for x (fp32): hi + lo with hi = fp16(x), lo = fp16(x - hi)"""
+    x = x.float()
+    hi = x.to(torch.float16).float()
+    return hi + (x - hi).to(torch.float16).float()
+
+
+def to_h2(x):
+    """fp32 [..., C] (C % 32 == 0) -> fp16 [..., 2C] in the pair layout"""
+    x = x.float()
+    Cc = x.shape[-1]
+    assert Cc % 32 == 0
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    g = torch.stack([hi.reshape(*x.shape[:-1], Cc // 32, 32), lo.reshape(*x.shape[:-1], Cc // 32, 32)], dim=-2)
+    return g.reshape(*x.shape[:-1], 2 * Cc).contiguous()
+
+
+def from_h2(h):
+    """fp16 [..., 2C] pair layout -> fp32 [..., C]"""
+    Cc = h.shape[-1] // 2
+    g = h.reshape(*h.shape[:-1], Cc // 32, 2, 32).float()
+    return (g[..., 0, :] + g[..., 1, :]).reshape(*h.shape[:-1], Cc)
+
+
+def q_op(x, dtype):
+    """x rounded to what a conv OPERAND of `dtype` holds (fp32 values)"""
+    return h2_value(x) if dtype == 3 else x.to(TD[dtype]).float()
+
+
+def up_op(x_last_c, dtype, dev):
+    """upload a channels-last conv operand / gate in the storage form of `dtype`"""
+    return (to_h2(x_last_c) if dtype == 3 else x_last_c.contiguous().to(TD[dtype])).to(dev)
+
+
 def check_conv_fwd(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, seed=0):
     _fresh()
     td = TD[dtype]
     gen = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, Cin, H, W, generator=gen).to(td).float()
-    w = (torch.randn(Cout, Cin, k, k, generator=gen) * (2.0 / (Cin * k * k)) ** 0.5).to(td).float()
+    x = q_op(torch.randn(B, Cin, H, W, generator=gen), dtype)
+    w = q_op(torch.randn(Cout, Cin, k, k, generator=gen) * (2.0 / (Cin * k * k)) ** 0.5, dtype)
     ref = F.conv2d(x.double(), w.double(), stride=stride, padding=pad)
     g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, k, stride, pad)
-    xn, wn = _nhwc(x, td, dev), _nhwc(w, td, dev)
+    xn, wn = up_op(x.permute(0, 2, 3, 1), dtype, dev), up_op(w.permute(0, 2, 3, 1), dtype, dev)
     out = torch.zeros(B, Ho, Wo, Cout, dtype=td, device=dev)
     gm = lib.op_igemm_grid_m(g.M)
     st = torch.zeros(gm, 2, Cout, device=dev)
@@ -101,20 +138,20 @@ def check_conv_dgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, with_r
     td = TD[dtype]
     gen = torch.Generator().manual_seed(seed)
     g, Ho, Wo = dgrad_geom(B, H, W, Cin, Cout, k, stride, pad)
-    gy = torch.randn(B, Cout, Ho, Wo, generator=gen).to(td).float()
-    w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.1).to(td).float()
+    gy = q_op(torch.randn(B, Cout, Ho, Wo, generator=gen), dtype)
+    w = q_op(torch.randn(Cout, Cin, k, k, generator=gen) * 0.1, dtype)
     x = torch.zeros(B, Cin, H, W, dtype=torch.double, requires_grad=True)
     F.conv2d(x, w.double(), stride=stride, padding=pad).backward(gy.double())
     want = x.grad.permute(0, 2, 3, 1)
-    wt = w.permute(1, 2, 3, 0).contiguous().to(td).to(dev)  # [Cin][R][S][Cout]
+    wt = up_op(w.permute(1, 2, 3, 0), dtype, dev)  # [Cin][R][S][Cout]
     res = gate = None
     if with_res:
         res = torch.randn(B, H, W, Cin, generator=gen).to(td)
-        gate = torch.randn(B, H, W, Cin, generator=gen).to(td)
+        gate = q_op(torch.randn(B, H, W, Cin, generator=gen), dtype)
         want = want + torch.where(gate.double() > 0, res.double(), torch.zeros_like(res.double()))
-        res, gate = res.to(dev), gate.to(dev)
+        res, gate = res.to(dev), up_op(gate, dtype, dev)
     out = torch.zeros(B, H, W, Cin, dtype=td, device=dev)
-    lib.check(lib.op_igemm(dtype, C.byref(g), K(_nhwc(gy, td, dev)), K(wt), K(out), Cin, None, None, 0, K(res),
+    lib.check(lib.op_igemm(dtype, C.byref(g), K(up_op(gy.permute(0, 2, 3, 1), dtype, dev)), K(wt), K(out), Cin, None, None, 0, K(res),
                            K(gate), f32(1), K(zero_page(dev)), None))
     dev_sync(dev)
     assert (out.cpu().double() - want).abs().max().item() <= OUT_TOL[dtype] * want.abs().max().item() + 1e-6
@@ -129,20 +166,20 @@ def check_conv_dgrad_op(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, par
     td = TD[dtype]
     gen = torch.Generator().manual_seed(seed)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    gy = torch.randn(B, Cout, Ho, Wo, generator=gen).to(td).float()
-    w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.1).to(td).float()
+    gy = q_op(torch.randn(B, Cout, Ho, Wo, generator=gen), dtype)
+    w = q_op(torch.randn(Cout, Cin, k, k, generator=gen) * 0.1, dtype)
     x = torch.zeros(B, Cin, H, W, dtype=torch.double, requires_grad=True)
     F.conv2d(x, w.double(), stride=stride, padding=pad).backward(gy.double())
     want = x.grad.permute(0, 2, 3, 1).contiguous()
-    wt = w.permute(1, 2, 3, 0).contiguous().to(td).to(dev)  # [Cin][R][S][Cout]
+    wt = up_op(w.permute(1, 2, 3, 0), dtype, dev)  # [Cin][R][S][Cout]
     out = torch.full((B, H, W, Cin), 7.0, dtype=td, device=dev)  # poison: every pixel must be written (or kept, in place)
     res = rgate = ogate = None
     if mode in ("res_gate", "out_gate", "inplace"):
         res = torch.randn(B, H, W, Cin, generator=gen).to(td)
         if mode == "res_gate":
-            rgate = torch.randn(B, H, W, Cin, generator=gen).to(td)
+            rgate = q_op(torch.randn(B, H, W, Cin, generator=gen), dtype)
             want = want + torch.where(rgate.double() > 0, res.double(), torch.zeros_like(res.double()))
-            rgate = rgate.to(dev)
+            rgate = up_op(rgate, dtype, dev)
         else:
             want = want + res.double()
         if mode == "inplace":
@@ -151,7 +188,7 @@ def check_conv_dgrad_op(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, par
         else:
             res = res.to(dev)
     if mode in ("out_gate", "inplace"):
-        ogate = torch.randn(B, H, W, Cin, generator=gen).to(td)
+        ogate = q_op(torch.randn(B, H, W, Cin, generator=gen), dtype)
         if mode == "out_gate" or parity == 0 or k > 1:
             want = torch.where(ogate.double() > 0, want, torch.zeros_like(want))
         else:
@@ -159,8 +196,8 @@ def check_conv_dgrad_op(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, par
             m = torch.zeros(B, H, W, 1, dtype=torch.bool)
             m[:, ::2, ::2] = True
             want = torch.where(m & ~(ogate.double() > 0), torch.zeros_like(want), want)
-        ogate = ogate.to(dev)
-    lib.check(lib.op_conv_dgrad(dtype, B, H, W, Cin, Cout, k, stride, pad, K(_nhwc(gy, td, dev)), K(wt), K(out), K(res), K(rgate),
+        ogate = up_op(ogate, dtype, dev)
+    lib.check(lib.op_conv_dgrad(dtype, B, H, W, Cin, Cout, k, stride, pad, K(up_op(gy.permute(0, 2, 3, 1), dtype, dev)), K(wt), K(out), K(res), K(rgate),
                                 K(ogate), parity, K(zero_page(dev)), None))
     dev_sync(dev)
     err = (out.cpu().double() - want).abs().max().item()

@@ -33,6 +33,28 @@ def main(backend):
                         checks.check_conv_wgrad(lib, dev, 2, *shape, seed=12 + rep, ws=True)
         print("forced-config cases ok")
         return
+    if os.environ.get("MN_H2_CASES") == "1":
+        # h2 operands (dtype 3) through igemm_halo.h: the 128-column shape takes every 3x3 stride-1 launch it covers; with
+        # MN_H2_HALO256=1 the 256-column shape (layer3 at 192 images) runs on small ragged problems
+        if os.environ.get("MN_H2_HALO256") == "1":
+            shapes = ((4, 9, 11, 64, 256, 3, 1, 1), (3, 16, 22, 256, 256, 3, 1, 1), (2, 13, 31, 192, 256, 3, 1, 1))
+            dg = ((3, 16, 22, 256, 256, 3, 1, 1), (5, 8, 11, 256, 128, 3, 1, 1))
+        else:
+            shapes = ((3, 9, 11, 64, 128, 3, 1, 1), (2, 12, 43, 128, 128, 3, 1, 1), (2, 7, 47, 64, 384, 3, 1, 1), (40, 3, 5, 64, 128, 3, 1, 1))
+            dg = ((2, 12, 43, 128, 128, 3, 1, 1), (9, 8, 11, 512, 512, 3, 1, 1))
+        for shape in shapes:
+            checks.check_conv_fwd(lib, dev, 3, *shape)
+        for mode in ("plain", "out_gate", "res_gate"):
+            checks.check_conv_dgrad_op(lib, dev, 3, *dg[0], parity=1, mode=mode)
+        checks.check_conv_dgrad_op(lib, dev, 3, *dg[1], parity=1, mode="out_gate")
+        if backend != "emu":  # layer geometries with hundreds of concurrent workgroups, repeated (race screen)
+            for rep in range(3):
+                checks.check_conv_fwd(lib, dev, 3, 48, 32, 43, 128, 128, 3, 1, 1, seed=rep)
+                checks.check_conv_fwd(lib, dev, 3, 96, 16, 22, 256, 256, 3, 1, 1, seed=5 + rep)
+                checks.check_conv_fwd(lib, dev, 3, 96, 8, 11, 512, 512, 3, 1, 1, seed=10 + rep)
+                checks.check_conv_dgrad_op(lib, dev, 3, 96, 16, 22, 256, 256, 3, 1, 1, parity=1, mode="res_gate", seed=20 + rep)
+        print("forced-config cases ok")
+        return
     if os.environ.get("MN_IGEMM_HALO") == "2" and os.environ.get("MN_IGEMM_CONFIG") is None:
         # the 128-column shape of igemm_halo.h (no forced tile configuration: it takes every launch it covers):
         # N = 128 / 384 / 512, rows up to the 47-pixel limit, one to eight chunks

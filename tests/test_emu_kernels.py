@@ -13,7 +13,7 @@ def lib():
     return emu_lib.load()
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1),     # layer1-like, BN=64 tile
     (2, 9, 11, 64, 128, 3, 2, 1),    # stride-2 3x3
@@ -24,7 +24,7 @@ def test_conv_forward(lib, dtype, shape):
     checks.check_conv_fwd(lib, DEV, dtype, *shape)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1),
     (2, 9, 11, 64, 128, 3, 2, 1),    # stride-2 data gradient (div = 2 gather)
@@ -105,7 +105,7 @@ def test_pose_graph_properties(lib):
     checks.check_pgo_properties(lib, DEV, W=24, N=7, fc=True)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape,mode", [
     ((2, 8, 11, 64, 128, 3, 2, 1), "plain"),      # odd width: the parity classes have 6 and 5 columns
     ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"),   # odd height
@@ -202,3 +202,15 @@ def test_experimental_chunk_resident_a_kernel():
     env = dict(os.environ, MN_IGEMM_HALO="2")                        # the 128-column shape (layers 2 and 4)
     env.pop("MN_IGEMM_CONFIG", None)
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
+
+
+@pytest.mark.parametrize("force256", ["0", "1"])
+def test_chunk_resident_a_kernel_h2(force256):
+    """igemm_halo.h with h2 operands (dtype 3: fp16-pair tensors, three MFMAs per product, fp32 output): the 128-column shape
+    and, forced onto small problems, the 256-column shape -- forward with BatchNorm sums, data gradients with residual / gates"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256=force256)
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=1500)

@@ -1,5 +1,5 @@
 """GPU micro-benchmark of the conv MFMA kernels at the BASELINE layer shapes (B=192, fp16 by default).
-usage: python tools/conv_bench.py [fp16|fp32|fp32x3] [B]"""
+usage: python tools/conv_bench.py [fp16|fp32|fp32x3|fp16x2] [B]"""
 import ctypes as C
 import os
 import sys
@@ -15,7 +15,12 @@ from geomapnet_amd._binding import ptr  # noqa: E402
 
 # MN_LIB: an alternative build of the library (the ablation build, `make -C geomapnet_amd/csrc ablation`)
 lib = _binding.Binding(C.CDLL(os.environ["MN_LIB"])) if os.environ.get("MN_LIB") else _binding.hip()
-dtype = {"fp16": 1, "fp32": 0, "fp32x3": 2}[sys.argv[1] if len(sys.argv) > 1 else "fp16"]
+dtype = {"fp16": 1, "fp32": 0, "fp32x3": 2, "fp16x2": 3}[sys.argv[1] if len(sys.argv) > 1 else "fp16"]
+H2 = dtype == 3
+
+
+def up(t):  # a channels-last operand in the storage form of `dtype` (dtype 3: h2 pairs, split on the device)
+    return checks.to_h2(t) if H2 else t.to(td)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 td = checks.TD[dtype]
 one = C.c_float(1.0)
@@ -38,19 +43,24 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
         return
     g, Ho, Wo = checks.fwd_geom(B, H, W, Ci, Co, k, stride, pad)
     gd, _, _ = checks.dgrad_geom(B, H, W, Ci, Co, k, stride, pad)
-    x = torch.randn(B, H, W, Ci, device="cuda").to(td)
-    w = (torch.randn(Co, k, k, Ci, device="cuda") * 0.05).to(td)
-    wt = w.permute(3, 1, 2, 0).contiguous()
-    gy = torch.randn(B, Ho, Wo, Co, device="cuda").to(td)
+    w32 = torch.randn(Co, k, k, Ci, device="cuda") * 0.05
+    x = up(torch.randn(B, H, W, Ci, device="cuda"))
+    w = up(w32)
+    wt = up(w32.permute(3, 1, 2, 0).contiguous())
+    gy = up(torch.randn(B, Ho, Wo, Co, device="cuda"))
     y = torch.empty(B, Ho, Wo, Co, dtype=td, device="cuda")
     gx = torch.empty(B, H, W, Ci, dtype=td, device="cuda")
-    res, gate = torch.randn_like(gx), torch.randn_like(gx)
+    res, gate = torch.randn_like(gx), up(torch.randn(B, H, W, Ci, device="cuda"))
     gw = torch.zeros(Co, k * k * Ci, device="cuda")
     st = torch.zeros(lib.op_igemm_grid_m(g.M), 2, Co, device="cuda")
     flops = 2.0 * g.M * Co * k * k * Ci
     t_f = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, ptr(st), None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_d = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_r = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), ptr(gate), one, ptr(checks.zero_page("cuda")), None))
+    if H2 and not hasattr(lib, "h2_wgrad"):  # (first h2 measurements: forward / data gradient only)
+        print("%-22s M=%8d N=%4d K=%5d  fwd %7.1f us %6.0f TF | dgrad %7.1f us %6.0f TF | +res %7.1f us"
+              % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6, t_r), flush=True)
+        return
     t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, ptr(checks.zero_page("cuda")), None))
     if dtype in (1, 2) and k == 3 and stride == 1:  # the plan's form: partial tiles through a workspace + reduce launch
         t_ws = timeit(lambda: lib.op_wgrad_ws(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, one, ptr(WS), WS.numel(), ptr(checks.zero_page("cuda")), None))
@@ -69,7 +79,7 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
           % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, io / t_f / 1e6, t_d, flops / t_d / 1e6, t_r, t_w, flops / t_w / 1e6), flush=True)
 
 
-print("dtype", {1: "fp16", 0: "fp32", 2: "fp32x3 (fp32 tensors, f16x3 igemm / bf16x3 wgrad)"}[dtype], "B", B)
+print("dtype", {1: "fp16", 0: "fp32", 2: "fp32x3 (fp32 tensors, f16x3 igemm / bf16x3 wgrad)", 3: "fp16x2 (h2 operands, fp32 outputs)"}[dtype], "B", B)
 WS = torch.empty(int(lib.op_wgrad_ws_floats()), device="cuda")
 ONLY_GEMM = os.environ.get("CB_ONLY") == "gemm"
 if ONLY_GEMM:
@@ -81,6 +91,8 @@ bench("layer2 3x3 128->128", 32, 43, 128, 128, 3, 1, 1)
 bench("layer2.0 1x1/2 64->128", 64, 86, 64, 128, 1, 2, 0)
 bench("layer3 3x3 256->256", 16, 22, 256, 256, 3, 1, 1)
 bench("layer4 3x3 512->512", 8, 11, 512, 512, 3, 1, 1)
+if H2:
+    sys.exit(0)
 # stem through the pixel-pair formulation
 if ONLY_GEMM:
     B = 2

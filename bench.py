@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--windows", type=int, default=64, help="windows per GPU per step")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32x3", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp16x2", "fp32x3", "fp32"])
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=341)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline + parity)")
@@ -331,7 +331,7 @@ def main():
         def roofline(rec, ms_per_step):
             if rec["conv_ms_per_step"] is None or rec["conv_ms_per_step"] <= 0:
                 return None
-            x3 = rec["dtype"] == "fp32x3"
+            x3 = rec["dtype"] in ("fp32x3", "fp16x2")
             peak = PEAK_F32_TFLOPS if rec["dtype"] == "fp32" else PEAK_F16_TFLOPS
             ach = flops_G / rec["conv_ms_per_step"]  # GFLOP / ms = TFLOP/s per GPU; fp32x3: fp32-EQUIVALENT flops
             traffic, src = None, None  # HBM bytes of the same launches: separate rocprofv3 --pmc passes (profiles/), static
@@ -363,7 +363,8 @@ def main():
         out = {"metric": "images/sec MapNet ResNet-34 256x341 T=3 train step", "value": round(value, 2), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": {"fp16": "f16", "fp32": "f32", "fp32x3": "f32 tensors, f16x3/bf16x3 MFMA"}[args.dtype], "data": "synthetic",
+               "dtype": {"fp16": "f16", "fp32": "f32", "fp32x3": "f32 tensors, f16x3/bf16x3 MFMA",
+                         "fp16x2": "f16 pairs (hi + lo) for conv operands, f32 elsewhere, 3 x f16 MFMA per product"}[args.dtype], "data": "synthetic",
                "config": {"workload": "BASELINE configs[2]: MapNet ResNet-34, %d windows x T=3 = %d images/GPU/step, %dx%d, "
                                       "MapNetCriterion learned beta/gamma, Adam, random-init weights" % (n, n * T, H, W),
                           "global_windows": n * world, "parallelism": "dp%d" % world, "n_ranks_seen": ranks_seen,

@@ -1,0 +1,233 @@
+// The HBM-bound kernels of the training step that PRODUCE or READ h2 tensors (common.h: fp32-class values as fp16 hi + lo
+// halves, per row and 32-channel group 64 bytes of hi halves then 64 bytes of lo halves).  In the fp16x2 mode
+// (MN_DTYPE_F16X2) every tensor a convolution consumes is h2 and is split exactly once, here, by the kernel that produces
+// it: the normalised activations (bn_apply_h2, bn_relu_maxpool_h2) and d(conv output) (bn_bwd_apply_h2).  Their inputs
+// -- raw conv outputs, data gradients -- are fp32, as are the statistics / reduction kernels of elementwise.h, which this
+// mode uses unchanged.  A thread owns 8 consecutive channels of a row: two 16-byte fp32 pieces in, one 16-byte piece of hi
+// halves + one of lo halves out (same bytes per element as the fp32 kernels).
+#pragma once
+#include "elementwise.h"
+
+namespace mn {
+
+// 8 channels c .. c + 7 (c % 8 == 0) of row `row`: the hi piece sits at half index h2_index(row, C, c), the lo piece 32 halves on
+__device__ __forceinline__ void h2_store8(half* __restrict__ base, long row, int C, int c, const float (&x)[8]) {
+  PieceView<half> hi, lo;
+  split8_f16(x, hi.v, lo.v);
+  half* p = base + h2_index(row, C, c);
+  *reinterpret_cast<piece_t*>(p) = hi.p;
+  *reinterpret_cast<piece_t*>(p + 32) = lo.p;
+}
+__device__ __forceinline__ void h2_load8(const half* __restrict__ base, long row, int C, int c, float (&x)[8]) {
+  const half* p = base + h2_index(row, C, c);
+  PieceView<half> hi, lo;
+  hi.p = *reinterpret_cast<const piece_t*>(p);
+  lo.p = *reinterpret_cast<const piece_t*>(p + 32);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = (float)hi.e[e] + (float)lo.e[e];
+}
+
+// out(h2) = [relu]( y * scale[c] + shift[c] [+ res(h2)] );  bn_apply_kernel with 8 channels per thread
+static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
+                                                                 const half* __restrict__ res, half* __restrict__ out,
+                                                                 long nitems, int C, int relu) {
+  constexpr int VEC = 8;
+  const int cpr = C / VEC;
+  __shared__ floatx2 tab[512];  // [e][piece] -> (scale, shift)
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const floatx2 v = {coef[c], coef[C + c]};
+    tab[(c % VEC) * cpr + c / VEC] = v;
+  }
+  __syncthreads();
+  const int cp = (int)(threadIdx.x % cpr);  // loop invariant: the grid stride is a multiple of cpr (a power of two <= 64)
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const floatx2 v = tab[e * cpr + cp];
+    sc[e] = v[0];
+    sh[e] = v[1];
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nitems; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / cpr;
+    PieceView<float> v0, v1;
+    v0.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(y) + 2 * i);
+    v1.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(y) + 2 * i + 1);
+    float f[VEC] = {v0.e[0], v0.e[1], v0.e[2], v0.e[3], v1.e[0], v1.e[1], v1.e[2], v1.e[3]};
+    float r[VEC];
+    if (res) h2_load8(res, row, C, cp * VEC, r);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      f[e] = f[e] * sc[e] + sh[e];
+      if (res) f[e] += r[e];
+      if (relu) f[e] = fmaxf(f[e], 0.f);
+    }
+    h2_store8(out, row, C, cp * VEC, f);
+  }
+}
+
+// Stem: BatchNorm + ReLU + max-pool 3x3/2/1 in one pass, fp32 conv output in, h2 pooled activation + argmax bytes out.
+// The comparison is on the fp32 values (the oracle's), so the routing is the reference's.
+static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
+                                                                        half* __restrict__ out, unsigned char* __restrict__ idx,
+                                                                        int B, int H, int W, int C, int Po, int Qo) {
+  constexpr int VEC = 8;
+  const int cpr = C / VEC;
+  float s_scale[VEC], s_shift[VEC];
+  {
+    __shared__ floatx2 tab[512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const floatx2 v = {coef[c], coef[C + c]};
+      tab[(c % VEC) * cpr + c / VEC] = v;
+    }
+    __syncthreads();
+    const int cp = (int)(threadIdx.x % cpr);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const floatx2 v = tab[e * cpr + cp];
+      s_scale[e] = v[0];
+      s_shift[e] = v[1];
+    }
+  }
+  const long total = (long)B * Po * Qo * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cp = (int)(i % cpr);
+    long tmp = i / cpr;
+    const long orow = tmp;
+    const int qo = (int)(tmp % Qo);
+    tmp /= Qo;
+    const int po = (int)(tmp % Po);
+    const int b = (int)(tmp / Po);
+    float best[VEC];
+    unsigned char arg[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      best[e] = -INFINITY;
+      arg[e] = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = po * 2 - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int w = qo * 2 - 1 + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const piece_t* src = reinterpret_cast<const piece_t*>(y) + (((long)(b * H + h) * W + w) * cpr + cp) * 2;
+        PieceView<float> v0, v1;
+        v0.p = src[0];
+        v1.p = src[1];
+        const float raw[VEC] = {v0.e[0], v0.e[1], v0.e[2], v0.e[3], v1.e[0], v1.e[1], v1.e[2], v1.e[3]};
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float f = fmaxf(raw[e] * s_scale[e] + s_shift[e], 0.f);
+          if (f > best[e]) {  // strict: the first maximum wins
+            best[e] = f;
+            arg[e] = (unsigned char)(r * 3 + s);
+          }
+        }
+      }
+    }
+    h2_store8(out, orow, C, cp * VEC, best);
+    if (idx) {
+      unsigned long long packed = 0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) packed |= (unsigned long long)arg[e] << (8 * e);
+      reinterpret_cast<unsigned long long*>(idx)[i] = packed;
+    }
+  }
+}
+
+// gy(h2) = k1 * (gm - mg - xhat * mgx): bn_bwd_apply_kernel<float> with 8 channels per thread and an h2 store.  The ReLU gate,
+// where there is one, is this BatchNorm's own (recomputed from y): block-output gradients arrive already gated.
+static __global__ void __launch_bounds__(256) bn_bwd_apply_h2_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const float* __restrict__ coef, half* __restrict__ gy,
+                                                                     long nitems, int C, int self_gate) {
+  constexpr int VEC = 8;
+  const bool sg_beta = self_gate != 0;
+  const int cpr = C / VEC;
+  float k1[VEC], kb[VEC], kd[VEC], mu[VEC], sh[VEC];
+  {
+    __shared__ floatx4 tab[512];  // [e][piece] -> (k1, kb, kd, mean)
+    __shared__ float tab_sh[512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float a = coef[c];
+      const floatx4 v = {a, -a * coef[2 * C + c] * invstd[c], -a * coef[C + c], mean[c]};
+      const int at = (c % VEC) * cpr + c / VEC;
+      tab[at] = v;
+      tab_sh[at] = sg_beta ? coef[3 * C + c] : 0.f;
+    }
+    __syncthreads();
+    const int cp = (int)(threadIdx.x % cpr);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const floatx4 v = tab[e * cpr + cp];
+      k1[e] = v[0];
+      kb[e] = v[1];
+      kd[e] = v[2];
+      mu[e] = v[3];
+      sh[e] = tab_sh[e * cpr + cp];
+    }
+  }
+  const int cp = (int)(threadIdx.x % cpr);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nitems; i += (long)gridDim.x * blockDim.x) {
+    PieceView<float> g0, g1, y0, y1;
+    g0.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(g) + 2 * i);
+    g1.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(g) + 2 * i + 1);
+    y0.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(y) + 2 * i);
+    y1.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(y) + 2 * i + 1);
+    const float gv[VEC] = {g0.e[0], g0.e[1], g0.e[2], g0.e[3], g1.e[0], g1.e[1], g1.e[2], g1.e[3]};
+    const float yv[VEC] = {y0.e[0], y0.e[1], y0.e[2], y0.e[3], y1.e[0], y1.e[1], y1.e[2], y1.e[3]};
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float gg = gv[e];
+      if (sg_beta && !(yv[e] * k1[e] + sh[e] > 0.f)) gg = 0.f;
+      o[e] = k1[e] * gg + (kb[e] * (yv[e] - mu[e]) + kd[e]);
+    }
+    h2_store8(gy, i / cpr, C, cp * VEC, o);
+  }
+}
+
+// BatchNorm backward with an h2 d(conv output): elementwise.h's reduce + finalize on the fp32 tensors, then the apply above
+inline void launch_bn_bwd_h2(const float* g, const float* y, long M, int C, const float* gamma, const float* mean,
+                             const float* invstd, float* dgamma, float* dbeta, half* gy, double* accum, float* coef,
+                             float grad_unscale, hipStream_t s, const float* self_gate_beta, int accum_rows) {
+  launch_bn_bwd<float>(g, nullptr, y, M, C, gamma, mean, invstd, dgamma, dbeta, nullptr, accum, coef, grad_unscale, s,
+                       self_gate_beta, PoolGradSrc(), accum_rows, /*apply=*/false);
+  const long ni = M * C / 8;
+  hipLaunchKernelGGL(bn_bwd_apply_h2_kernel, dim3(ew_grid(ni)), dim3(256), 0, s, g, y, mean, invstd, (const float*)coef, gy, ni, C,
+                     self_gate_beta ? 1 : 0);
+}
+
+// global average pool of an h2 activation
+static __global__ void __launch_bounds__(256) avgpool_fwd_h2_kernel(const half* __restrict__ in, float* __restrict__ out, int B,
+                                                                    int HW, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int c = i % C, b = i / C;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) {
+    const half* q = in + h2_index((long)b * HW + p, C, c);
+    s += (float)q[0] + (float)q[32];
+  }
+  out[i] = s / (float)HW;
+}
+
+// g[b][p][c] = gp[b][c] / HW (fp32), zeroed where the pooled h2 activation is <= 0 (its hi half carries the sign)
+static __global__ void __launch_bounds__(256) avgpool_bwd_h2_kernel(const float* __restrict__ gp, float* __restrict__ g, int B,
+                                                                    int HW, int C, const half* __restrict__ gate) {
+  const long total = (long)B * HW * C;
+  const float inv = 1.f / (float)HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const int b = (int)(row / HW);
+    float v = gp[b * C + c] * inv;
+    if (gate && !((float)gate[h2_index(row, C, c)] > 0.f)) v = 0.f;
+    g[i] = v;
+  }
+}
+
+}  // namespace mn

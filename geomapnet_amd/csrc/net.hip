@@ -13,6 +13,7 @@
 #include "common.h"
 #include "criterion.h"
 #include "elementwise.h"
+#include "elementwise_h2.h"
 #include "head.h"
 #include "igemm.h"
 #include "dgrad.h"
@@ -386,8 +387,8 @@ struct Plan : PlanBase {
         if (!u) continue;
         unit_bufs(*u);
         size_t wn = (size_t)u->cp.cout * u->cp.cin * u->cp.k * u->cp.k;
-        if (DT == MN_F16)
-          u->wf = (T*)A(wn * sizeof(T));
+        if (DT == MN_F16 || h2)
+          u->wf = (T*)A(wn * sizeof(T));  // (h2: 4 bytes per element as well)
         else
           u->wf = base ? (T*)(params + u->cp.w) : nullptr;  // fp32: the OHWI master is the operand
         u->wd = (T*)A(wn * sizeof(T));
@@ -415,7 +416,7 @@ struct Plan : PlanBase {
     stem_colmap = (int*)A(224 * 4);
     repack_jobs = (RepackJob*)A(64 * sizeof(RepackJob));
     zero_page = (void*)A(256);
-    wgf_ws_floats = (DT == MN_F16 || mma_bwd == MMA_BF16X3) ? wgrad_fused_ws_floats(WGF_BLOCKS) : 0;  // (both fused forms)
+    wgf_ws_floats = (DT == MN_F16 || mma_bwd == MMA_BF16X3) ? wgrad_fused_ws_floats(WGF_BLOCKS) : 0;  // (all fused forms)
     if (deterministic && wgf_ws_floats < (16L << 20)) wgf_ws_floats = 16L << 20;  // split slices of the plain weight gradients
     wgf_ws = wgf_ws_floats ? (float*)A((size_t)wgf_ws_floats * 4) : nullptr;
     step_dev = (long long*)A(256);
@@ -450,14 +451,22 @@ struct Plan : PlanBase {
   // MN_DTYPE_F32X3 (Plan<float> only): fp32 tensors, contractions on the f16 / bf16 matrix pipe with split operands
   // (common.h MMA_*): forward f16x3, backward bf16x3; the fc / pose head stay on the exact fp32 MFMA
   int mma_fwd = MMA_NATIVE, mma_bwd = MMA_NATIVE;
+  // MN_DTYPE_F16X2 (Plan<float> only): every tensor a convolution consumes -- block inputs / outputs, a1, the projection
+  // output, d(conv output), both weight copies -- is an h2 tensor (fp16 hi + lo halves, 4 bytes per element: the arena is
+  // carved exactly as for fp32), written by the h2 element-wise kernels (elementwise_h2.h) and read by the h2 convolution
+  // kernels through LDS-DMA; raw conv outputs, data gradients, statistics, head, criterion and optimiser are fp32.  The stem
+  // (3 input channels: no 32-channel groups) stays on the fp32x3 kernels: fp32 xpad / stem.gy, f16x3 / bf16x3 contraction.
+  // Gradients live in fp16 pairs, so the mode scales the loss and guards against overflow exactly as the fp16 mode does.
+  bool h2 = false;
   Plan(const mn_config& c) {
     cfg = c;
     cur_scale = c.loss_scale;
-    if (c.dtype == MN_DTYPE_F32X3) {
+    h2 = DT == MN_F32 && c.dtype == MN_DTYPE_F16X2;
+    if (c.dtype == MN_DTYPE_F32X3 || h2) {
       mma_fwd = MMA_F16X3;
       mma_bwd = MMA_BF16X3;
     }
-    overflow_guard = DT == MN_F16 && !(getenv("MN_OVERFLOW_GUARD") && atoi(getenv("MN_OVERFLOW_GUARD")) == 0);
+    overflow_guard = (DT == MN_F16 || h2) && !(getenv("MN_OVERFLOW_GUARD") && atoi(getenv("MN_OVERFLOW_GUARD")) == 0);
     L = Layout(c.feat_dim);
     frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
     B = c.windows * frames;
@@ -562,7 +571,7 @@ struct Plan : PlanBase {
       for (Unit* u : us) {
         if (!u) continue;
         const ConvP& c = u->cp;
-        add(c.w, DT == MN_F16 ? (void*)u->wf : nullptr, u->wd, c.cout, c.k, c.k, c.cin, 0);
+        add(c.w, (DT == MN_F16 || h2) ? (void*)u->wf : nullptr, u->wd, c.cout, c.k, c.k, c.cin, 0);
       }
     }
     add(L.fc_w, fcT, nullptr, cfg.feat_dim, 1, 1, 512, 3);
@@ -576,14 +585,31 @@ struct Plan : PlanBase {
   void repack_head(hipStream_t s) {
     const int hj = repack_head_jobs > 0 ? repack_head_jobs : repack_njobs;
     const int hb = repack_head_jobs > 0 ? repack_head_blocks : repack_blocks;
+    if constexpr (DT == MN_F32) {
+      if (h2) {
+        hipLaunchKernelGGL((repack_all_kernel<float, true>), dim3(hb), dim3(256), 0, s, (const RepackJob*)repack_jobs, hj,
+                           (const float*)params, 0);
+        return;
+      }
+    }
     hipLaunchKernelGGL((repack_all_kernel<T>), dim3(hb), dim3(256), 0, s, (const RepackJob*)repack_jobs, hj,
                        (const float*)params, 0);
   }
   void repack_tail(hipStream_t s) {
     const int hb = repack_head_jobs > 0 ? repack_head_blocks : repack_blocks;
-    if (repack_blocks > hb)
-      hipLaunchKernelGGL((repack_all_kernel<T>), dim3(repack_blocks - hb), dim3(256), 0, s,
-                         (const RepackJob*)repack_jobs, repack_njobs, (const float*)params, hb);
+    if (repack_blocks > hb) {
+      bool done = false;
+      if constexpr (DT == MN_F32) {
+        if (h2) {
+          hipLaunchKernelGGL((repack_all_kernel<float, true>), dim3(repack_blocks - hb), dim3(256), 0, s,
+                             (const RepackJob*)repack_jobs, repack_njobs, (const float*)params, hb);
+          done = true;
+        }
+      }
+      if (!done)
+        hipLaunchKernelGGL((repack_all_kernel<T>), dim3(repack_blocks - hb), dim3(256), 0, s,
+                           (const RepackJob*)repack_jobs, repack_njobs, (const float*)params, hb);
+    }
     weights_dirty = false;
   }
 
@@ -610,7 +636,9 @@ struct Plan : PlanBase {
       ep.stats_rows = u.rows_f;
     }
     auto* tp = timer.begin(0, s);
-    if (&u == &stem && DT == MN_F16 && use_stem_kernel)  // weights in registers, input pairs read straight from LDS (stem.h)
+    if (h2 && &u != &stem)  // h2 activation and weights in, fp32 conv output + statistics out
+      launch_igemm_h2(u.gf, (const half*)x, (const half*)u.wf, ep, s, (const half*)zero_page);
+    else if (&u == &stem && DT == MN_F16 && use_stem_kernel)  // weights in registers, input pairs read straight from LDS (stem.h)
       launch_stem_conv((const half*)x, (const half*)u.wf, (half*)u.y, training ? u.accum_f : nullptr, u.rows_f, B, H, W, Wp, s);
     else if (halo_path(u.gf) && conv_halo_pp_applies(u.gf, ep))
       launch_conv_halo_pp(u.gf, (const half*)x, (const half*)u.wf, ep, s);
@@ -630,6 +658,12 @@ struct Plan : PlanBase {
   void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s) {
     long np = u.M * u.cp.cout / VEC;
     bn_finalize(u, s);
+    if (h2) {  // fp32 conv output in, h2 activation out (residual: an h2 activation)
+      const long ni = u.M * u.cp.cout / 8;
+      hipLaunchKernelGGL(bn_apply_h2_kernel, dim3(ew_grid(ni)), dim3(256), 0, s, (const float*)u.y, (const float*)u.coef_f,
+                         (const half*)res, (half*)out, ni, u.cp.cout, relu);
+      return;
+    }
     hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const float*)u.coef_f, res, out,
                        np, u.cp.cout, relu);
   }
@@ -662,7 +696,11 @@ struct Plan : PlanBase {
       if (zero_grads) launch_zero_fill(grads, L.param_floats, side);
     }
     conv_bn_stats(stem, xpad, training, s);
-    if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
+    if (h2) {  // (always the fused form: fp32 conv output in, h2 pooled activation out)
+      bn_finalize(stem, s);
+      hipLaunchKernelGGL(bn_relu_maxpool_h2_kernel, dim3(ew_grid((long)B * H1 * W1 * 64 / 8)), dim3(256), 0, s,
+                         (const float*)stem.y, (const float*)stem.coef_f, (half*)p0, pool_idx, B, H0, W0, 64, H1, W1);
+    } else if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
       bn_finalize(stem, s);
       hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
                          (const T*)stem.y, (const float*)stem.coef_f, p0, pool_idx, B, H0, W0, 64, H1, W1);
@@ -687,8 +725,12 @@ struct Plan : PlanBase {
     join_wgrad(s);
     const Block& last = blocks.back();
     int F = cfg.feat_dim;
-    hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(cdiv((long)B * 512, 256)), dim3(256), 0, s, (const T*)last.out, pooled,
-                       B, Hl * Wl, 512);
+    if (h2)
+      hipLaunchKernelGGL(avgpool_fwd_h2_kernel, dim3(cdiv((long)B * 512, 256)), dim3(256), 0, s, (const half*)last.out, pooled,
+                         B, Hl * Wl, 512);
+    else
+      hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(cdiv((long)B * 512, 256)), dim3(256), 0, s, (const T*)last.out, pooled,
+                         B, Hl * Wl, 512);
     // fc 512 -> feat_dim, bias, ReLU (models/posenet.py:46,65-66); dropout is the identity under the
     // reference's pinned torch 0.4.1 (F.dropout default training=False)
     GatherGeom g;
@@ -725,6 +767,12 @@ struct Plan : PlanBase {
   // ---- backward -------------------------------------------------------------------------------------
   // self_gate: `gate` is relu(bn_u(y)) itself (a1 of a block, a0 of the stem): recomputed from y, not read
   void bn_bwd(Unit& u, const T* g, const T* gate, hipStream_t s, bool self_gate = false) {
+    if (h2 && &u != &stem) {  // fp32 gradient and conv output in, h2 d(conv output) out; gates: none, or the unit's own ReLU
+      launch_bn_bwd_h2((const float*)g, (const float*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd,
+                       grads + u.bp.gamma, grads + u.bp.beta, (half*)u.gy, u.accum_b, u.coef_b, 1.f / cur_scale, s,
+                       self_gate ? params + u.bp.beta : nullptr, u.rows_b);
+      return;
+    }
     launch_bn_bwd<T>(g, gate, (const T*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
                      grads + u.bp.beta, u.gy, u.accum_b, u.coef_b, 1.f / cur_scale, s,
                      self_gate ? params + u.bp.beta : nullptr, PoolGradSrc(), u.rows_b);
@@ -748,6 +796,10 @@ struct Plan : PlanBase {
     // reduction splits (measured, tools/conv_bench.py): one round of 2 workgroups per CU for the wide layers (half
     // the atomic traffic of 1024), more for layer1 and the stem whose pixel dimension is 4-16x longer
     const int target = u.cp.cout >= 128 ? 512 : (u.M > 2000000 ? 2048 : 1024);
+    if (h2 && &u != &stem) {  // h2 d(conv output) and activation
+      a.g.mma = MMA_H2;
+      launch_wgrad<half>(a, target, ws, zero_page);
+    } else
     launch_wgrad<T>(a, target, ws, zero_page);
     timer.end(tp, ws);
   }
@@ -757,7 +809,9 @@ struct Plan : PlanBase {
     ep.out_gate = out_gate;
     ep.alpha = 1.f;
     auto* tp = timer.begin(0, s);
-    if (halo_path(u.dg.full) && conv_halo_pp_applies(u.dg.full, ep))
+    if (h2)  // h2 d(conv output) and weights in, fp32 gradient out (+ fp32 residual, h2 gate of the block below)
+      launch_conv_dgrad<half>(u.dg, (const half*)u.gy, (const half*)u.wd, ep, s, (const half*)zero_page, parity_dgrad, true);
+    else if (halo_path(u.dg.full) && conv_halo_pp_applies(u.dg.full, ep))
       launch_conv_halo_pp(u.dg.full, (const half*)u.gy, (const half*)u.wd, ep, s);
     else
       launch_conv_dgrad<T>(u.dg, (const T*)u.gy, (const T*)u.wd, ep, s, (const T*)zero_page, parity_dgrad);
@@ -854,8 +908,12 @@ struct Plan : PlanBase {
     ep.res_gate = nullptr; ep.alpha = 1.f;
     launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s, (const float*)zero_page);
     Block& last = blocks.back();
-    hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
-                       (const float*)dpooled, last.gout, B, Hl * Wl, 512, (const T*)last.out);
+    if (h2)
+      hipLaunchKernelGGL(avgpool_bwd_h2_kernel, dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s, (const float*)dpooled,
+                         (float*)last.gout, B, Hl * Wl, 512, (const half*)last.out);
+    else
+      hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
+                         (const float*)dpooled, last.gout, B, Hl * Wl, 512, (const T*)last.out);
   }
   // (MN_DETERMINISTIC: the stem's backward goes through bn_bwd + the split-slice weight gradient instead)
   bool use_stem_bwd = DT == MN_F16 && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
@@ -924,7 +982,8 @@ struct Plan : PlanBase {
     if (n == "xpad") return give(xpad, (long)B * Hp * Wp * 4, DT);
     if (n == "stem.y") return give(stem.y, n0, DT);
     if (n == "stem.gy") return give(stem.gy, n0, DT);
-    if (n == "p0") return give(p0, n1, DT);
+    const int AT = h2 ? MN_DTYPE_F16X2 : DT;  // dtype code of the tensors the convolutions consume (h2 in the fp16x2 mode)
+    if (n == "p0") return give(p0, n1, AT);
     if (n == "gp0") return give(gp0, n1, DT);
     if (n == "pooled") return give(pooled, (long)B * 512, MN_F32);
     if (n == "feat") return give(feat, (long)B * cfg.feat_dim, MN_F32);
@@ -941,16 +1000,16 @@ struct Plan : PlanBase {
           Block& k = blocks[bi];
           const long no = k.u2.M * k.u2.cp.cout;
           if (t == "y1") return give(k.u1.y, no, DT);
-          if (t == "a1") return give(k.a1, no, DT);
+          if (t == "a1") return give(k.a1, no, AT);
           if (t == "y2") return give(k.u2.y, no, DT);
-          if (t == "out") return give(k.out, no, DT);
-          if (t == "gy1") return give(k.u1.gy, no, DT);
+          if (t == "out") return give(k.out, no, AT);
+          if (t == "gy1") return give(k.u1.gy, no, AT);
           if (t == "ga1") return give(k.ga1, no, DT);
-          if (t == "gy2") return give(k.u2.gy, no, DT);
+          if (t == "gy2") return give(k.u2.gy, no, AT);
           if (t == "gout") return give(k.gout, no, DT);
           if (k.down && t == "yd") return give(k.ud.y, no, DT);
-          if (k.down && t == "zd") return give(k.zd, no, DT);
-          if (k.down && t == "gyd") return give(k.ud.gy, no, DT);
+          if (k.down && t == "zd") return give(k.zd, no, AT);
+          if (k.down && t == "gyd") return give(k.ud.gy, no, AT);
         }
       }
     }
@@ -1016,7 +1075,8 @@ struct mn_handle {
 static int validate(const mn_config* c) {
   if (!c) return fail("null config");
   if (c->mode < 0 || c->mode > 3) return fail("config: bad mode");
-  if (c->dtype != MN_DTYPE_F32 && c->dtype != MN_DTYPE_F16 && c->dtype != MN_DTYPE_F32X3) return fail("config: bad dtype");
+  if (c->dtype != MN_DTYPE_F32 && c->dtype != MN_DTYPE_F16 && c->dtype != MN_DTYPE_F32X3 && c->dtype != MN_DTYPE_F16X2)
+    return fail("config: bad dtype");
   if (c->windows < 1 || c->T < 1 || c->T > kMaxT) return fail("config: windows >= 1 and 1 <= T <= 8 required");
   if (c->mode == MN_MODE_POSENET && c->T != 1) return fail("config: PoseNet mode requires T = 1");
   if (c->mode >= MN_MODE_MAPNET && c->T < 2) return fail("config: MapNet modes require T >= 2");
@@ -1135,7 +1195,8 @@ extern "C" int64_t mn_stuck_overflow_steps(mn_handle* h) { return (h && h->plan)
 extern "C" int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval) {
   MN_H(h);
   if (!(scale > 0.f)) return fail("mn_set_loss_scale: scale must be positive");
-  if (P.cfg.dtype != MN_DTYPE_F16 && scale != 1.f) return fail("mn_set_loss_scale: fp32 plans do not scale the loss");
+  if (P.cfg.dtype != MN_DTYPE_F16 && P.cfg.dtype != MN_DTYPE_F16X2 && scale != 1.f)
+    return fail("mn_set_loss_scale: fp32 plans do not scale the loss");
   P.cur_scale = scale;
   P.scale_set_at = P.attempts;
   P.scale_growth_interval = growth_interval;

@@ -120,9 +120,11 @@ static int op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy
   a.g = to_geom(gg);
   int vec = dtype == MN_F16 ? 8 : 4;
   if (a.g.C % vec != 0 || a.g.N % vec != 0) return fail("wgrad: channel counts must be multiples of the piece");
+  if (dtype == MN_DTYPE_F16X2 && (a.g.C % 32 != 0 || ldy % 32 != 0)) return fail("wgrad: h2 operands need channel counts % 32 == 0");
   a.dY = dY; a.ldy = ldy; a.X = X; a.dW = dW; a.ldw = ldw; a.colmap = colmap; a.alpha = alpha; a.rows_per_split = 0;
   if (dtype == MN_DTYPE_F32X3) a.g.mma = MMA_BF16X3;  // fp32 tensors, bf16 matrix pipe with split operands
-  if (dtype == MN_F16)
+  if (dtype == MN_DTYPE_F16X2) a.g.mma = MMA_H2;      // h2 tensors (dY, X), fp32 dW
+  if (dtype == MN_F16 || dtype == MN_DTYPE_F16X2)
     launch_wgrad<half>(a, target_blocks, (hipStream_t)stream, zero_page);
   else
     launch_wgrad<float>(a, target_blocks, (hipStream_t)stream);

@@ -210,7 +210,16 @@ struct RepackJob {
   int blk0, nblk; // workgroup range; each workgroup covers 4096 elements
 };
 
-template <typename T>
+// one weight element -> its hi and lo halves at (row, c) of an h2 matrix with C columns (common.h)
+__device__ __forceinline__ void h2_put(void* base, long row, int C, int c, float v) {
+  half* p = reinterpret_cast<half*>(base) + h2_index(row, C, c);
+  const half hi = (half)v;
+  p[0] = hi;
+  p[32] = (half)(v - (float)hi);
+}
+// H2 (T = float): mode-0 destinations are h2 matrices -- the forward operand [O][R][S][I] split along I, the data-gradient
+// operand [I][R][S][O] along O (MN_DTYPE_F16X2); modes 2 and 3 (stem, fc) stay fp32
+template <typename T, bool H2 = false>
 static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob* __restrict__ jobs, int njobs,
                                                                 const float* __restrict__ params, int blk_base) {
   const int bid = (int)blockIdx.x + blk_base;  // a launch may cover a sub-range of the table's workgroups
@@ -236,7 +245,12 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
       const int row = k * 4 + row0;
       const long idx = ((long)(ot * 64 + row) * RS + rs) * I + it * 64 + col;
       const float v = src[idx];
-      if (job.mode == 0 && job.dst_a) reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
+      if (job.mode == 0 && job.dst_a) {
+        if constexpr (H2)
+          h2_put(job.dst_a, (long)(ot * 64 + row) * RS + rs, I, it * 64 + col, v);
+        else
+          reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
+      }
       tile[row][col] = v;
     }
     __syncthreads();
@@ -245,10 +259,14 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
       const int irow = k * 4 + row0;
       const float v = tile[col][irow];
       const long didx = ((long)(it * 64 + irow) * RS + rs) * O + ot * 64 + col;
-      if (job.mode == 0)
-        reinterpret_cast<T*>(job.dst_b)[didx] = (T)v;
-      else
+      if (job.mode == 0) {
+        if constexpr (H2)
+          h2_put(job.dst_b, (long)(it * 64 + irow) * RS + rs, O, ot * 64 + col, v);
+        else
+          reinterpret_cast<T*>(job.dst_b)[didx] = (T)v;
+      } else {
         reinterpret_cast<float*>(job.dst_a)[didx] = v;
+      }
     }
     return;
   }
@@ -258,7 +276,6 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
     if (idx >= total) break;
     if (job.mode == 0) {
       const float v = src[idx];
-      if (job.dst_a) reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
       // idx = ((o*R + r)*S + s)*I + i  ->  ((i*R + r)*S + s)*O + o
       const int i = (int)(idx % I);
       long t = idx / I;
@@ -266,7 +283,13 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
       t /= S;
       const int r = (int)(t % R);
       const int o = (int)(t / R);
-      reinterpret_cast<T*>(job.dst_b)[(((long)i * R + r) * S + s) * O + o] = (T)v;
+      if constexpr (H2) {
+        if (job.dst_a) h2_put(job.dst_a, idx / I, I, i, v);
+        h2_put(job.dst_b, ((long)i * R + r) * S + s, O, o, v);
+      } else {
+        if (job.dst_a) reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
+        reinterpret_cast<T*>(job.dst_b)[(((long)i * R + r) * S + s) * O + o] = (T)v;
+      }
     } else if (job.mode == 2) {
       const int e = (int)(idx % 8);
       long t = idx / 8;

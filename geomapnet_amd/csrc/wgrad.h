@@ -774,7 +774,8 @@ struct WgradDma<half> {
 // over the pixels (MN_WGRAD_FUSED=0 restores the plain GEMM form below for them)
 inline bool wgrad_fused_applies(const WgradArgs& a);
 inline bool wgrad_fused_x3_applies(const WgradArgs& a);
-inline void launch_wgrad_fused(const WgradArgs& a, int target_blocks, hipStream_t stream, bool x3);
+inline bool wgrad_fused_h2_applies(const WgradArgs& a);
+inline void launch_wgrad_fused(const WgradArgs& a, int target_blocks, hipStream_t stream, int form);
 
 // dW[i] += sum over the split slices, in split order (the slices already carry alpha)
 static __global__ void __launch_bounds__(256) wgrad_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
@@ -792,13 +793,18 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
   const GatherGeom& g = a.g;
   static const bool fused = !(getenv("MN_WGRAD_FUSED") && atoi(getenv("MN_WGRAD_FUSED")) == 0);
   if constexpr (ElemTraits<T>::DTYPE == MN_F16) {
-    if (fused && wgrad_fused_applies(a)) {
-      launch_wgrad_fused(a, target_blocks, stream, false);
+    if (g.mma == MMA_H2) {  // h2 tensors: the DMA-fed tap-fused kernel, or (stride-2 / 1x1 shapes) the generic loader
+      if (fused && wgrad_fused_h2_applies(a)) {
+        launch_wgrad_fused(a, target_blocks, stream, 2);
+        return;
+      }
+    } else if (fused && wgrad_fused_applies(a)) {
+      launch_wgrad_fused(a, target_blocks, stream, 0);
       return;
     }
   } else {
     if (fused && wgrad_fused_x3_applies(a)) {  // fp32 tensors, bf16x3 contraction
-      launch_wgrad_fused(a, target_blocks, stream, true);
+      launch_wgrad_fused(a, target_blocks, stream, 1);
       return;
     }
   }
@@ -825,7 +831,16 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
     a.split_stride = slice;
   }
   dim3 grid(cdiv(g.N, bmo), cdiv(g.K, bno), splits), block(256);
-  if (sizeof(T) == 4 && g.mma == MMA_BF16X3) {
+  if (sizeof(T) == 2 && g.mma == MMA_H2) {
+    if (bmo == 64 && bno == 64)
+      hipLaunchKernelGGL((wgrad_x3_kernel<64, 64, true>), grid, block, 0, stream, a);
+    else if (bmo == 64)
+      hipLaunchKernelGGL((wgrad_x3_kernel<64, 128, true>), grid, block, 0, stream, a);
+    else if (bno == 64)
+      hipLaunchKernelGGL((wgrad_x3_kernel<128, 64, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((wgrad_x3_kernel<128, 128, true>), grid, block, 0, stream, a);
+  } else if (sizeof(T) == 4 && g.mma == MMA_BF16X3) {
     if constexpr (sizeof(T) == 4) {
       if (bmo == 64 && bno == 64)
         hipLaunchKernelGGL((wgrad_x3_kernel<64, 64>), grid, block, 0, stream, a);

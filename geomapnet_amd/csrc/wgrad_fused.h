@@ -551,6 +551,203 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_x3_kernel(WgradFuse
   }
 }
 
+// transpose reads requested after item `it` by the time its MFMAs wait (wgrad_fused_h2_kernel): the request groups of the next
+// PD items, four reads each, eight for the first item of a K sub-step (its group carries the A fragments)
+constexpr int wgf_h2_reads_after(int it, int pd, int items) {
+  int n = 0;
+  for (int k = it + 1; k <= it + pd && k < items; ++k) n += (k % 5 == 0) ? 8 : 4;
+  return n;
+}
+// ---- h2 form (round 4): the same tap-fused pass for h2 tensors (common.h MMA_H2) ---------------------------------------------
+// dY and X arrive ALREADY split into fp16 hi / lo halves, so the four planes of a step (dY hi, dY lo, X hi, X lo: 64 pixels x
+// 128 B each) go HBM -> LDS by DMA like the fp16 kernel's two -- no staging registers, no conversion, no LDS stores -- and the
+// compute side is the fp32x3 kernel's: wave = (32-column block of the input channels) x (32-row block of the output channels) x
+// (taps 0-4 / 5-8), all 64 pixels of a step, an item = the four transpose reads of a tap's B fragment (hi, lo) + three
+// v_mfma_f32_32x32x16_f16 (lo*hi + hi*lo + hi*hi).  Transpose reads from inline assembly with counted lgkmcnt waits (the builtin
+// would drain the DMA queue in front of every read, wgrad.h): request groups (A fragments of a K sub-step + B fragments of an
+// item) run PD items ahead of the MFMAs.  One DMA step in flight (two dY tiles, ring of 2 x 64 + 2 Gpad rows + mirror, four
+// planes: 128 KB of LDS), issued behind item DPI of the step before.
+constexpr int WGF_H2_RING_MAX = 2 * 64 + 2 * 96;
+template <int ABL = 0, int PD = 2, int DPI = 3>
+static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFusedArgs a) {
+  constexpr int NW = 8, BKM = 8 * NW, ROWH = 64, NY = 2;
+  constexpr int TILE_Y = BKM * ROWH;                      // halves of one dY tile plane
+  constexpr int XPLANE = (WGF_H2_RING_MAX + BKM) * ROWH;  // ring + mirror of its first block
+  constexpr int YLO = NY * TILE_Y * 2, XLO = XPLANE * 2;  // byte distance hi plane -> lo plane
+  static_assert(XLO + (3 * 16 + 4) * ROWH * 2 < 65536, "ds offset field");
+  // ONE LDS object: [Y hi tiles][Y lo tiles][X hi ring + mirror][X lo ring + mirror]
+  __shared__ half smem[2 * NY * TILE_Y + 2 * XPLANE] __attribute__((aligned(16)));
+  half* const xh = smem + 2 * NY * TILE_Y;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wc = wave & 1, nb = (wave >> 1) & 1, tset = wave >> 2;
+  const int tap0 = tset * 5, ntap = tset == 0 ? 5 : 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int pairs = a.tiles_n * a.tiles_c;
+  const int ci = logical / pairs, pr = logical - ci * pairs;
+  const int n0 = (pr / a.tiles_c) * 64, c0 = (pr % a.tiles_c) * 64;
+  const int j0 = ci * a.chunk;
+  const int j1 = min(a.J, j0 + a.chunk);
+  const int nsteps = (j1 - j0 + BKM - 1) / BKM;
+  const int Gpad = a.Gpad, RING = a.ring;
+
+  // the h2 tensors as the DMA sees them: rows of 4 ldy / 4 C bytes
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dY, (long)a.B * a.P * a.Q * a.ldy * 4L);
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X, (long)a.B * a.P * a.Q * a.C * 4L);
+  // DMA role (the fp16 kernel's): row t/8 of a 64-row block, LDS slot t%8 = source piece slot ^ swz(row) = channels
+  // 8 piece .. 8 piece + 7 of the 64-channel tile; the lo halves of the same channels lie 64 bytes behind the hi halves
+  const int drow = t >> 3, dslot = t & 7;
+  const int dpiece = dslot ^ wg_swz<8>(drow);
+  const int ych = n0 + dpiece * 8, xch = c0 + dpiece * 8;
+  const unsigned ycol = (unsigned)(((ych >> 5) * 64 + (ych & 31)) * 2), xcol = (unsigned)(((xch >> 5) * 64 + (xch & 31)) * 2);
+  const bool y_ok = ych < a.N, x_ok = xch < a.C;
+  auto pixel_of = [&](int j) -> int {
+    if ((unsigned)j >= (unsigned)a.J) return -1;
+    const int r = fastdiv(j, a.dq), q = j - r * a.Qp;
+    const int b = fastdiv(r, a.dp), p = r - b * (a.P + 1);
+    return (q < a.Q && p < a.P) ? (b * a.P + p) * a.Q + q : -1;
+  };
+  // (an all-ones offset is outside the tensor whatever the scalar offset adds: the bounds check ignores soffset)
+  auto issue_y = [&](int step) {
+    const int j = j0 + step * BKM + drow;
+    const int m = j < j1 ? pixel_of(j) : -1;
+    const unsigned off = (m >= 0 && y_ok) ? (unsigned)m * (unsigned)(a.ldy * 4) + ycol : ~0u;
+    half* dst = &smem[(step % NY) * TILE_Y + wave * 64 * 8];
+    dma16(rsrc_y, off, 0u, dst);
+    dma16(rsrc_y, off, 64u, dst + NY * TILE_Y);
+  };
+  auto issue_x = [&](int u0) {
+    const int m = pixel_of(j0 - Gpad + u0 + drow);
+    const unsigned off = (m >= 0 && x_ok) ? (unsigned)m * (unsigned)(a.C * 4) + xcol : ~0u;
+    const int rr = u0 % RING;
+    half* dst = xh + rr * ROWH + wave * 64 * 8;
+    dma16(rsrc_x, off, 0u, dst);
+    dma16(rsrc_x, off, 64u, dst + XPLANE);
+    if (rr == 0) {  // block 0 also goes to the mirror behind the ring
+      dma16(rsrc_x, off, 0u, xh + RING * ROWH + wave * 64 * 8);
+      dma16(rsrc_x, off, 64u, xh + RING * ROWH + wave * 64 * 8 + XPLANE);
+    }
+  };
+
+  floatx16 acc[5];  // [tap slot: tap = tap0 + slot] of the output-channel block nb
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // transpose-read lane geometry (the fp16 kernel's); a wave walks all 64 rows of a step
+  const int gq = lane >> 4, i16 = lane & 15;
+  const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
+  const int lrow = (gq >> 1) * 8 + src_row;
+  const unsigned lds0 = lds_addr_of(smem);
+  const int colA = nb * 32 + src_chunk;
+  const unsigned aA = lds0 + (unsigned)((lrow * ROWH + (((colA >> 3) ^ wg_swz<8>(src_row)) * 8) + (colA & 7)) * 2);
+  const int colB = wc * 32 + src_chunk;
+  unsigned xoffB[5];
+  int rbB[5];
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    const int tp = tap0 + (sl < ntap ? sl : ntap - 1);
+    const int sh = Gpad + (tp / 3 - 1) * a.Qp + (tp % 3 - 1);  // in [0, 2 Gpad] < RING
+    const int key = (sh + src_row) & 3;
+    xoffB[sl] = lds0 + (unsigned)((2 * NY * TILE_Y + lrow * ROWH + ((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
+    rbB[sl] = sh * (ROWH * 2);
+  }
+  const int ring_bytes = RING * ROWH * 2;
+
+  // prologue: the halo rows [0, 2 Gpad), then step 0
+  for (int u0 = 0; u0 < 2 * Gpad; u0 += BKM) issue_x(u0);
+  if (nsteps > 0) {
+    issue_y(0);
+    issue_x(2 * Gpad);
+  }
+
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // step s visible to everyone; everyone is done with step s-1's reads
+    auto issue_step = [&]() {
+      if (s + 1 < nsteps && (ABL & 1) == 0) {  // into dY tile (s + 1) % 2 (read in step s - 1) and the ring rows behind the live window
+        issue_y(s + 1);
+        issue_x(2 * Gpad + BKM * (s + 1));
+      }
+    };
+    if constexpr (DPI < 0) issue_step();
+    const unsigned tyoff = (unsigned)((s % NY) * TILE_Y * 2);
+    constexpr int NKS = 4, ITEMS = NKS * 5, NB = PD + 1;
+    TrFrag fah[2], fal[2], fbh[NB], fbl[NB];
+    __builtin_amdgcn_sched_barrier(0);
+    // request group of item `it`: the A fragments of its K sub-step (with the sub-step's first item) + its B fragments
+    auto request = [&](auto I) {
+      constexpr int it = decltype(I)::value, ks = it / 5, sl = it % 5;
+      if constexpr (sl == 0) {
+        fah[ks & 1].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, aA + tyoff);
+        fah[ks & 1].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, aA + tyoff);
+        fal[ks & 1].h[0] = ds_read_tr16_at<YLO + (ks * 16) * ROWH * 2>(smem, aA + tyoff);
+        fal[ks & 1].h[1] = ds_read_tr16_at<YLO + (ks * 16 + 4) * ROWH * 2>(smem, aA + tyoff);
+      }
+      const unsigned ad = xoffB[sl] + (unsigned)rbB[sl];
+      fbh[it % NB].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, ad);
+      fbh[it % NB].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, ad);
+      fbl[it % NB].h[0] = ds_read_tr16_at<XLO + (ks * 16) * ROWH * 2>(smem, ad);
+      fbl[it % NB].h[1] = ds_read_tr16_at<XLO + (ks * 16 + 4) * ROWH * 2>(smem, ad);
+    };
+    static_for<(PD < ITEMS ? PD : ITEMS)>([&](auto I) { request(I); });
+    static_for<ITEMS>([&](auto I) {
+      constexpr int it = decltype(I)::value, ks = it / 5, sl = it % 5;
+      if constexpr (it + PD < ITEMS) request(StaticIndex<it + PD>{});
+      // LDS reads return in order: item `it` is in its registers once at most the reads requested AFTER it are outstanding
+      constexpr int later = wgf_h2_reads_after(it, PD, ITEMS);
+      static_assert(later <= 15, "lgkmcnt field");
+      wait_lgkmcnt_for<later>(fbh[it % NB]);
+      wait_lgkmcnt_for<later>(fbl[it % NB]);
+      if constexpr (sl == 0) {
+        wait_lgkmcnt_for<later>(fah[ks & 1]);
+        wait_lgkmcnt_for<later>(fal[ks & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (sl < 4 || tset == 0) {  // wave-uniform: slot 4 of the 4-tap half carries no MFMA
+        if constexpr ((ABL & 4) == 0) {
+          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ks & 1].v, fbh[it % NB].v, acc[sl], 0, 0, 0);
+          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks & 1].v, fbl[it % NB].v, acc[sl], 0, 0, 0);
+          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks & 1].v, fbh[it % NB].v, acc[sl], 0, 0, 0);
+        } else {
+          asm volatile("" ::"v"(fal[ks & 1].v), "v"(fah[ks & 1].v), "v"(fbh[it % NB].v), "v"(fbl[it % NB].v));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (it == DPI) {
+        issue_step();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+      rbB[sl] += BKM * ROWH * 2;
+      rbB[sl] -= rbB[sl] >= ring_bytes ? ring_bytes : 0;
+    }
+  }
+
+  // partial tile -> workspace slab of this pixel range, or fp32 atomics straight into dW[n][tap*C + c]
+  const int K9 = 9 * a.C;
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    if (sl >= ntap) continue;  // wave-uniform
+    const int tp = tap0 + sl;
+    const int c = c0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n < a.N && c < a.C) {
+        if (a.ws)
+          a.ws[((long)ci * a.N + n) * K9 + tp * a.C + c] = acc[sl][r];
+        else
+          unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[sl][r] * a.alpha);
+      }
+    }
+  }
+}
+
 // dW[n][k] += alpha * sum over chunks of ws[chunk][n][k], chunks added in index order.  blockIdx.y splits the chunk
 // range when there are few columns and many chunks (layer1: 36 864 columns x 512 chunks); with more than one group the
 // groups meet in dW through atomics, with one group (layers 3-4) the sum is a plain read-modify-write.
@@ -596,6 +793,15 @@ inline bool wgrad_fused_x3_applies(const WgradArgs& a) {
          (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
 }
 
+// the h2 form: h2 tensors (channel counts in whole 32-channel groups), otherwise the same shapes
+inline bool wgrad_fused_h2_applies(const WgradArgs& a) {
+  const GatherGeom& g = a.g;
+  return g.mma == MMA_H2 && g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.rsign == 1 && g.ssign == 1 &&
+         g.off_h == -1 && g.off_w == -1 && g.P == g.Hi && g.Q == g.Wi && g.C % 32 == 0 && g.N % 32 == 0 && a.ldy % 32 == 0 &&
+         a.colmap == nullptr && a.ldw >= 9 * g.C && ((g.Q + 2 + 31) / 32) * 32 <= 96 && (long)g.M * a.ldy * 4 < 0xfffffff0l &&
+         (long)g.M * g.C * 4 < 0xfffffff0l && (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
+}
+
 inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
   if (!a.ws) return;
   const int K9 = 9 * a.C;
@@ -614,7 +820,9 @@ inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
 inline long wgrad_fused_ws_floats(int blocks) { return (long)blocks * 64 * 9 * 64; }
 constexpr int WGF_BLOCKS = 512;  // workgroups per launch: two per CU (the register budget), i.e. one round of the chip
 
-inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream, bool x3 = false) {
+// form: 0 = fp16 tensors, 1 = fp32 tensors on the bf16 pipe (x3), 2 = h2 tensors
+inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream, int form = 0) {
+  const bool x3 = form == 1;
   const GatherGeom& g = w.g;
   constexpr int NW = 8, BKM = 8 * NW;  // (the 4-wave form -- two 256-thread workgroups per CU, twice the partial tiles -- is not launched)
   WgradFusedArgs a;
@@ -632,7 +840,7 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   a.Gpad = ((g.Q + 2 + 15) / 16) * 16;
   a.Gpad = ((a.Gpad + 31) / 32) * 32;  // 2 Gpad must be a multiple of the 64-row DMA block
   constexpr int D = 3;  // DMA steps in flight (the fp32x3 form stages one step ahead through registers)
-  a.ring = ((x3 ? 1 : D) + 1) * BKM + 2 * a.Gpad;
+  a.ring = ((form != 0 ? 1 : D) + 1) * BKM + 2 * a.Gpad;
   a.dq = make_fastdiv(a.Qp);
   a.dp = make_fastdiv(g.P + 1);
   a.alpha = w.alpha;
@@ -653,6 +861,17 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
     fprintf(stderr, "wgrad_fused<%d waves>: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows, ws %d\n", NW,
             a.B, a.P, a.Q, a.C, a.N, a.chunk, a.nchunks, pairs, a.ring, a.ws != nullptr);
   const dim3 grid(a.nchunks * pairs), block(NW * 64);
+  if (form == 2) {
+#ifdef MN_ABLATION_BUILD
+    static const int ablh = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
+    if (ablh == 1) { hipLaunchKernelGGL((wgrad_fused_h2_kernel<1>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return; }
+    if (ablh == 4) { hipLaunchKernelGGL((wgrad_fused_h2_kernel<4>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return; }
+    if (ablh == 5) { hipLaunchKernelGGL((wgrad_fused_h2_kernel<5>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return; }
+#endif
+    hipLaunchKernelGGL((wgrad_fused_h2_kernel<0>), grid, block, 0, stream, a);
+    wgrad_fused_reduce(a, stream);
+    return;
+  }
   if (x3) {
 #ifdef MN_ABLATION_BUILD
     static const int ablx = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;

@@ -15,16 +15,21 @@ from ._binding import Config, MapNetHipError, ptr
 MODE_POSENET, MODE_MAPNET, MODE_ONLINE, MODE_GPS = 0, 1, 2, 3
 # "fp32x3": fp32 tensors exactly as "fp32", every convolution contracted on the f16 / bf16 matrix pipe with operands
 # split into hi + lo halves in registers (three MFMAs per product; include/mapnet_hip.h MN_DTYPE_F32X3)
-DTYPES = {"fp32": 0, "fp16": 1, "fp32x3": 2}
+# "fp16x2": fp32-class values stored as fp16 PAIRS (hi + lo halves, 4 bytes per element) wherever a convolution consumes them,
+# split once by the producing kernel; the convolutions run three fp16 MFMAs per product on DMA-fed operands; conv outputs,
+# data gradients, BatchNorm, head, criterion and optimiser in fp32 (include/mapnet_hip.h MN_DTYPE_F16X2).  Gradients live in
+# fp16 pairs, so the mode uses the fp16 mode's loss scale and overflow guard.
+DTYPES = {"fp32": 0, "fp16": 1, "fp32x3": 2, "fp16x2": 3}
+SCALED_DTYPES = ("fp16", "fp16x2")  # modes whose gradients pass through fp16 halves
 
 _default_dtype = "fp16"
 _default_loss_scale = 1024.0
 
 
 def set_compute_dtype(name, loss_scale=None):
-    """'fp16' (fp16 tensors, fp32 accumulate; the benchmark configuration), 'fp32x3' (fp32 tensors, split-operand
-    contractions on the f16 / bf16 matrix pipe: the parity configuration) or 'fp32' (fp32 tensors on
-    v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain)."""
+    """'fp16' (fp16 tensors, fp32 accumulate; the benchmark configuration), 'fp16x2' (fp16-pair conv operands, fp32
+    everything else: the parity configuration), 'fp32x3' (fp32 tensors, operands split inside the convolution kernels) or
+    'fp32' (fp32 tensors on v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain)."""
     global _default_dtype, _default_loss_scale
     if name not in DTYPES:
         raise ValueError(name)
@@ -153,7 +158,7 @@ class Engine:
     def plan(self, mode, windows, T, H, W):
         self._check_device()
         dtype = self.dtype or _default_dtype
-        scale = self.loss_scale if self.loss_scale is not None else (_default_loss_scale if dtype == "fp16" else 1.0)
+        scale = self.loss_scale if self.loss_scale is not None else (_default_loss_scale if dtype in SCALED_DTYPES else 1.0)
         key = (mode, windows, T, H, W, dtype, scale, self.eps_mode)
         p = self.plans.get(key)
         if p is None:
@@ -299,7 +304,7 @@ class Engine:
 
     def _stepped(self, p):
         self.step_count += 1
-        if p.get("dtype") == "fp16" and self.step_count % 16 == 0:
+        if p.get("dtype") in SCALED_DTYPES and self.step_count % 16 == 0:
             self.check_overflow_progress(p)
         self.version += 1
         p["version"] = self.version  # this plan repacks by itself after its own optimiser step

@@ -35,7 +35,7 @@ def build_parser():
     parser.add_argument("--output_dir", type=str, default=None, help="Output directory")
     parser.add_argument("--pose_graph", action="store_true", help="Turn on Pose Graph Optimization")
     # additions
-    parser.add_argument("--dtype", choices=("fp16", "fp32x3", "fp32"), default="fp16")
+    parser.add_argument("--dtype", choices=("fp16", "fp16x2", "fp32x3", "fp32"), default="fp16")
     parser.add_argument("--synthetic_length", type=int, default=256)
     parser.add_argument("--u8_input", action="store_true", help="frames as uint8 [H,W,3]; ToTensor + Normalize run on the "
                         "device (model.set_input_u8)")

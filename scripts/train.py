@@ -42,7 +42,7 @@ def build_parser():
                         help="Resume optimization (only effective if a checkpoint is given")
     parser.add_argument("--suffix", type=str, default="", help="Experiment name suffix (as is)")
     # additions
-    parser.add_argument("--dtype", choices=("fp16", "fp32x3", "fp32"), default="fp16", help="compute precision of the HIP kernels")
+    parser.add_argument("--dtype", choices=("fp16", "fp16x2", "fp32x3", "fp32"), default="fp16", help="compute precision of the HIP kernels")
     parser.add_argument("--pretrained", choices=("auto", "yes", "no"), default="auto",
                         help="start from the torchvision ImageNet ResNet-34 ($TORCH_MODEL_ZOO/resnet34-333f7ec4.pth, as the "
                              "reference does: models.resnet34(pretrained=True), scripts/train.py:76) and re-initialise only the "

@@ -263,8 +263,9 @@ def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target
     td = TD[dtype]
     gen = torch.Generator().manual_seed(seed)
     g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, k, stride, pad)
-    gy = torch.randn(B, Cout, Ho, Wo, generator=gen).to(td).float()
-    x = torch.randn(B, Cin, H, W, generator=gen).to(td).float()
+    gy = q_op(torch.randn(B, Cout, Ho, Wo, generator=gen), dtype)
+    x = q_op(torch.randn(B, Cin, H, W, generator=gen), dtype)
+    gyn, xn = up_op(gy.permute(0, 2, 3, 1), dtype, dev), up_op(x.permute(0, 2, 3, 1), dtype, dev)
     w = torch.zeros(Cout, Cin, k, k, dtype=torch.double, requires_grad=True)
     F.conv2d(x.double(), w, stride=stride, padding=pad).backward(gy.double())
     ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)
@@ -274,13 +275,13 @@ def check_conv_wgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, target
         wbuf = torch.full((wsf,), float("nan"), device=dev)
         dW2 = torch.zeros_like(dW)
         for out in (dW, dW2):
-            lib.check(lib.op_wgrad_ws(dtype, C.byref(g), K(_nhwc(gy, td, dev)), Cout, K(_nhwc(x, td, dev)), K(out), k * k * Cin,
+            lib.check(lib.op_wgrad_ws(dtype, C.byref(g), K(gyn), Cout, K(xn), K(out), k * k * Cin,
                                       f32(0.5), K(wbuf), wsf, K(zero_page(dev)), None))
         dev_sync(dev)
-        if dtype in (1, 2) and k == 3 and stride == 1 and Cout * 9 * Cin // 4 >= 131072:
+        if dtype in (1, 2, 3) and k == 3 and stride == 1 and Cout * 9 * Cin // 4 >= 131072:
             assert torch.equal(dW, dW2)  # one reduction group: chunks are summed in index order, no atomics anywhere
     else:
-        lib.check(lib.op_wgrad(dtype, C.byref(g), K(_nhwc(gy, td, dev)), Cout, K(_nhwc(x, td, dev)), K(dW), k * k * Cin,
+        lib.check(lib.op_wgrad(dtype, C.byref(g), K(gyn), Cout, K(xn), K(dW), k * k * Cin,
                                None, f32(0.5), target_blocks, K(zero_page(dev)), None))
     dev_sync(dev)
     assert (dW.cpu().double() - 0.5 * ref).abs().max().item() <= 2e-5 * ref.abs().max().item() * max(1, (B * Ho * Wo) ** 0.5 / 8)
@@ -1253,7 +1254,7 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
     rec = {"mode": mode, "windows": N, "images": N * frames, "H": H, "W": W, "oracle_step_s": round(oracle_s, 1),
            "loss_oracle": lo, "pose_scale": po.abs().max().item()}
     del omodel, oopt
-    for dtype_name in ("fp32x3", "fp32", "fp16"):
+    for dtype_name in ("fp16x2", "fp32x3", "fp32", "fp16"):
         G.set_compute_dtype(dtype_name)
         net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, filter_nans=filter_nans, _binding=lib))
         net.load_state_dict(sd0)
@@ -1291,7 +1292,7 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
                            "pose_abs_rms": d.pow(2).mean().sqrt().item(),
                            "grad_l2_rel_all": (num / den) ** 0.5 if den > 0 else None, "grad_l2_rel_worst_tensor": worst}
         del net, model, opt, c
-    for name in ("fp32x3", "fp32"):
+    for name in ("fp16x2", "fp32x3", "fp32"):
         assert rec[name]["loss_rel"] <= fp32_loss_rtol, (name, rec)
         assert rec[name]["pose_abs_max"] <= fp32_pose_atol, (name, rec)
         if rec[name]["grad_l2_rel_all"] is not None:  # (gate flips: DESIGN.md section 6)

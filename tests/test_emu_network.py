@@ -24,6 +24,13 @@ def test_mapnet_train_step_fp32x3_parity(lib):
     assert rep[0][2] < 1e-3
 
 
+def test_mapnet_train_step_fp16x2_parity(lib):
+    """fp16-pair conv operands (h2 tensors split by their producers, DMA-fed three-MFMA contractions), fp32 everything else:
+    the whole step -- h2 element-wise kernels, h2 convolutions / data gradients / weight gradients, loss scale -- at the fp32 bar"""
+    rep = checks.check_train_step(lib, DEV, "fp16x2", mode="mapnet", N=2, H=64, W=85, steps=1)
+    assert rep[0][2] < 1e-3
+
+
 def test_eval_forward_fp32(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=2, H=40, W=53)
 

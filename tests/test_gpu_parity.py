@@ -23,7 +23,7 @@ def lib():
     return b
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1), (2, 9, 11, 64, 128, 3, 2, 1), (1, 8, 10, 64, 128, 1, 2, 0), (3, 5, 6, 128, 192, 3, 1, 1),
     (2, 64, 86, 64, 64, 3, 1, 1),      # layer1 geometry at 256x341
@@ -34,7 +34,7 @@ def test_conv_forward(lib, dtype, shape):
     checks.check_conv_fwd(lib, DEV, dtype, *shape)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1), (2, 9, 11, 64, 128, 3, 2, 1), (2, 8, 10, 64, 128, 1, 2, 0), (2, 7, 9, 64, 128, 1, 2, 0),
     (2, 64, 86, 64, 128, 3, 2, 1), (2, 16, 22, 256, 512, 1, 2, 0), (4, 8, 11, 512, 512, 3, 1, 1),
@@ -43,7 +43,7 @@ def test_conv_data_gradient(lib, dtype, shape):
     checks.check_conv_dgrad(lib, DEV, dtype, *shape)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape,mode", [
     ((2, 8, 11, 64, 128, 3, 2, 1), "plain"), ((2, 9, 10, 64, 128, 3, 2, 1), "out_gate"), ((1, 8, 12, 64, 128, 3, 2, 1), "res_gate"),
     ((2, 8, 11, 64, 128, 1, 2, 0), "inplace"), ((2, 9, 11, 64, 64, 3, 1, 1), "out_gate"),
@@ -57,7 +57,7 @@ def test_conv_data_gradient_op(lib, dtype, shape, mode, parity):
     checks.check_conv_dgrad_op(lib, DEV, dtype, *shape, parity=parity, mode=mode)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape,blocks", [
     ((2, 9, 11, 64, 64, 3, 1, 1), 8), ((3, 9, 11, 64, 128, 3, 2, 1), 8), ((2, 8, 10, 64, 128, 1, 2, 0), 1),
     ((5, 5, 6, 128, 128, 3, 1, 1), 40), ((2, 64, 86, 64, 64, 3, 1, 1), 1024), ((4, 8, 11, 512, 512, 3, 1, 1), 1024),
@@ -70,11 +70,13 @@ def test_conv_weight_gradient(lib, dtype, shape, blocks):
 @pytest.mark.parametrize("shape", [(2, 9, 11, 64, 64, 3, 1, 1), (3, 20, 22, 128, 64, 3, 1, 1), (2, 6, 7, 72, 80, 3, 1, 1),
                                    (6, 64, 86, 64, 64, 3, 1, 1), (12, 32, 43, 128, 128, 3, 1, 1), (24, 16, 22, 256, 256, 3, 1, 1),
                                    (48, 8, 11, 512, 512, 3, 1, 1)])
-@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("dtype", [1, 2, 3])
 def test_fused_weight_gradient_through_workspace(lib, dtype, shape):
-    """wgrad_fused.h (fp16 kernel / fp32x3 kernel) with partial tiles stored to a (NaN-filled) workspace and added up by the
-    reduce kernel, as the plan runs it (layer geometries included); bit-identical between two launches when one reduction
-    group covers the columns"""
+    """wgrad_fused.h (fp16 kernel / fp32x3 kernel / h2 kernel) with partial tiles stored to a (NaN-filled) workspace and added
+    up by the reduce kernel, as the plan runs it (layer geometries included); bit-identical between two launches when one
+    reduction group covers the columns"""
+    if dtype == 3 and shape[3] % 32:  # h2 tensors hold whole 32-channel groups
+        shape = shape[:3] + (96, 160) + shape[5:]
     checks.check_conv_wgrad(lib, DEV, dtype, *shape, ws=True)
 
 
@@ -147,6 +149,26 @@ def test_mapnet_train_step_fp32x3_parity_full_resolution(lib):
     fp32 build's 2e-2 per tensor"""
     checks.check_train_step(lib, DEV, "fp32x3", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3,
                             pose_abs=1e-3)
+
+
+def test_mapnet_train_step_fp16x2_parity_full_resolution(lib):
+    """the fp16-pair mode (h2 conv operands split once by their producers, three fp16 MFMAs per product on DMA-fed operands,
+    fp32 everything else): north-star tolerances as written, gradients to the fp32 build's 2e-2 per tensor"""
+    checks.check_train_step(lib, DEV, "fp16x2", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3,
+                            pose_abs=1e-3)
+
+
+def test_mapnet_train_step_fp16x2_two_steps_small(lib):
+    checks.check_train_step(lib, DEV, "fp16x2", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+
+
+def test_mapnet_online_train_step_fp16x2_parity_clip_and_nan_filter(lib):
+    checks.check_train_step(lib, DEV, "fp16x2", mode="mapnet++", N=2, H=64, W=85, steps=1, max_grad_norm=5.0, lr=1e-5, wd=0.0,
+                            filter_nans=True, grad_l2_rtol=None)
+
+
+def test_posenet_train_step_fp16x2(lib):
+    checks.check_train_step(lib, DEV, "fp16x2", mode="posenet", N=5, H=64, W=85, steps=1)
 
 
 def test_mapnet_train_step_fp32x3_two_steps_small(lib):
@@ -448,7 +470,14 @@ def test_chunk_resident_a_kernel_race_screen():
     _run_forced(env, True)
 
 
-@pytest.mark.parametrize("dtype_name", ["fp16", "fp32", "fp32x3"])
+def test_chunk_resident_a_kernel_h2_race_screen():
+    """igemm_halo.h with h2 operands (the 3x3 stride-1 convolutions of layers 2-4 in the fp16x2 mode): both tile shapes against
+    torch fp64, layer geometries repeated"""
+    _run_forced(dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256="0"), True)
+    _run_forced(dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256="1"), True)
+
+
+@pytest.mark.parametrize("dtype_name", ["fp16", "fp32", "fp32x3", "fp16x2"])
 def test_deterministic_mode_is_bit_reproducible(lib, dtype_name):
     """MN_DETERMINISTIC=1: three MapNet training steps (clipping on) twice from the same state -> identical bits; the
     default mode's atomics only differ from it by summation order"""

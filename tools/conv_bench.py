@@ -57,12 +57,8 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
     t_f = timeit(lambda: lib.op_igemm(dtype, C.byref(g), ptr(x), ptr(w), ptr(y), Co, ptr(st), None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_d = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, None, None, one, ptr(checks.zero_page("cuda")), None))
     t_r = timeit(lambda: lib.op_igemm(dtype, C.byref(gd), ptr(gy), ptr(wt), ptr(gx), Ci, None, None, 0, ptr(res), ptr(gate), one, ptr(checks.zero_page("cuda")), None))
-    if H2 and not hasattr(lib, "h2_wgrad"):  # (first h2 measurements: forward / data gradient only)
-        print("%-22s M=%8d N=%4d K=%5d  fwd %7.1f us %6.0f TF | dgrad %7.1f us %6.0f TF | +res %7.1f us"
-              % (name, g.M, Co, k * k * Ci, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6, t_r), flush=True)
-        return
     t_w = timeit(lambda: lib.op_wgrad(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, None, one, 1024, ptr(checks.zero_page("cuda")), None))
-    if dtype in (1, 2) and k == 3 and stride == 1:  # the plan's form: partial tiles through a workspace + reduce launch
+    if dtype in (1, 2, 3) and k == 3 and stride == 1:  # the plan's form: partial tiles through a workspace + reduce launch
         t_ws = timeit(lambda: lib.op_wgrad_ws(dtype, C.byref(g), ptr(gy), Co, ptr(x), ptr(gw), k * k * Ci, one, ptr(WS), WS.numel(), ptr(checks.zero_page("cuda")), None))
         print("%-22s wgrad through the workspace %7.1f us %6.0f TF" % (name, t_ws, flops / t_ws / 1e6), flush=True)
     if dtype == 1 and Ci == 64 and k == 3 and stride == 1:

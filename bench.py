@@ -10,8 +10,10 @@ path and the N > 1 code path are the same function.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): MapNet, ResNet-34, 256x341,
 window T=3, 64 windows = 192 images per GPU per step, fp16 operands / fp32 accumulate; the same run then times the
-parity mode (fp32x3: fp32 tensors, split-operand contractions on the f16 / bf16 matrix pipe -- the mode the north-star
-tolerance is met in) and reports it as `parity_mode`; --dtype fp32 times the exact-fp32 MFMA build.
+parity mode (fp16x2: every conv operand an fp16 PAIR, hi + lo halves split once by the producing kernel, three fp16 MFMAs per
+product on DMA-fed operands, fp32 everything else -- the mode the north-star tolerance is met in) and reports it as
+`parity_mode`; --dtype fp32x3 / fp32 time the round-3 parity mode (operands split inside the conv kernels) / the exact-fp32
+MFMA build.
 MapNetCriterion with learned beta/gamma, Adam lr 1e-4 wd 5e-4; synthetic inputs
 resident in HBM before the timed region; random-init weights.  One "step" = one call of
 geomapnet_amd.step_feedfwd(train=True) = forward + criterion + backward + Adam, including the blocking loss
@@ -23,7 +25,7 @@ Prints ONE JSON line on rank 0 with
   `cpu_baseline`  the oracle (a port of the reference path) timed on this host on a bounded sample;
   `parity`        loss / pose deviation of the TIMED dtype from the oracle on one step of the full workload
                   (identical batch and weights; the oracle is the checker, never the thing measured);
-  `parity_mode`   images/s, roofline and parity of the fp32x3 mode, timed by the same code in the same run.
+  `parity_mode`   images/s, roofline and parity of the fp16x2 mode, timed by the same code in the same run.
 """
 import argparse
 import json
@@ -40,7 +42,8 @@ GFLOP_PER_IMAGE_TRAIN = 39.06   # 3 x 13.02 GFLOP (fwd + dgrad +
 GFLOP_PER_IMAGE_EXECUTED = 38.65  # the stem's unused input gradient is not computed
 PEAK_F16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
+PARITY_MODE = "fp16x2"
 
 
 def cpu_model():
@@ -106,12 +109,14 @@ def cpu_baseline_and_parity(args, dev, binding=None, dtypes=("fp16",)):
             "dtype": d, "checker": "oracle (CPU fp32 port of the reference path), same batch, same initial weights, step 1",
             "config": "%d windows x T=3 = %d images %dx%d" % (n, n * 3, H, W),
             "loss": round(float(l), 6), "loss_oracle": round(float(lo), 6),
-            "loss_rel": float("%.3e" % (abs(l - lo) / max(1.0, abs(lo)))),
+            "loss_rel": float("%.3e" % (abs(l - lo) / max(1.0, abs(lo)))), "loss_abs": float("%.3e" % abs(l - lo)),
             "pose_abs_max": float("%.3e" % (p - po).abs().max().item()),
             "pose_abs_rms": float("%.3e" % (p - po).pow(2).mean().sqrt().item()),
             "pose_scale_max": float("%.3e" % po.abs().max().item()),
-            "bar": "north star: 1e-4 on loss (read as relative to max(1,|loss|)), 1e-3 on pose (max abs)",
-            "meets_bar": bool(abs(l - lo) / max(1.0, abs(lo)) <= 1e-4 and (p - po).abs().max().item() <= 1e-3)}
+            "bar": "north star: 1e-4 on loss, 1e-3 on pose (max abs over all predicted components); `meets_bar` reads the loss bar "
+                   "relative to max(1,|loss|), `meets_bar_abs` as an absolute 1e-4 on the loss value itself",
+            "meets_bar": bool(abs(l - lo) / max(1.0, abs(lo)) <= 1e-4 and (p - po).abs().max().item() <= 1e-3),
+            "meets_bar_abs": bool(abs(l - lo) <= 1e-4 and (p - po).abs().max().item() <= 1e-3)}
     del onet, ocrit, oopt, x, t
     # ---- (2) bounded timing sample
     sw, warm, timed = 5, 3, 10
@@ -270,7 +275,7 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=341)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline + parity)")
-    ap.add_argument("--no-parity-mode", action="store_true", help="skip the second timed pass in the parity mode (fp32x3)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the second timed pass in the parity mode (fp16x2)")
     ap.add_argument("--no-events", action="store_true", help="do not time conv launches with HIP events")
     ap.add_argument("--emu", action="store_true",
                     help="TEST ONLY: run the same code on the CPU SIMT-emulator build of the kernels over gloo "
@@ -316,12 +321,12 @@ def main():
 
     repeats = 1 if args.emu else max(1, args.repeats)
     main_rec = timed_mode(args, args.dtype, dev, binding, world, rank, repeats)
-    # The parity mode, timed by the same code in the same run: fp32 tensors with split-operand contractions on the f16 /
-    # bf16 matrix pipe (fp32x3) -- the mode that meets the north-star tolerance -- so that the throughput claim and the
-    # parity claim are one measurement (fewer regions: it is ~2-3x slower per step).
+    # The parity mode, timed by the same code in the same run: fp16-pair conv operands, three MFMAs per product, fp32 everything
+    # else (fp16x2) -- the mode that meets the north-star tolerance -- so that the throughput claim and the parity claim are one
+    # measurement (fewer regions: it is ~2x slower per step).
     pm_rec = None
     if args.dtype == "fp16" and not args.no_parity_mode and not args.emu:
-        pm_rec = timed_mode(args, "fp32x3", dev, binding, world, rank, min(repeats, 3))
+        pm_rec = timed_mode(args, PARITY_MODE, dev, binding, world, rank, min(repeats, 3))
 
     if rank == 0:
         n, T, H, W = args.windows, 3, args.height, args.width
@@ -352,7 +357,7 @@ def main():
                  "flops_per_step_G": round(flops_G, 1),
                  "whole_step_frac": round((3.0 if x3 else 1.0) * flops_G / ms_per_step / peak, 4)}
             if x3:
-                r["note"] = ("fp32x3 executes three v_mfma_f32_32x32x16_{f16,bf16} per fp32 product: `achieved` counts the "
+                r["note"] = ("fp16x2 / fp32x3 execute three v_mfma_f32_32x32x16_f16 (bf16) per fp32-class product: `achieved` counts the "
                              "reference's fp32 FLOPs once, `frac` = 3 x achieved / 2.5 PF is the matrix pipe's utilisation; the "
                              "exact-fp32 pipe peaks at 157.3 TF")
                 r["x_fp32_pipe_peak"] = round(ach / PEAK_F32_TFLOPS, 3)
@@ -380,7 +385,8 @@ def main():
         if pm_rec is not None:
             pms = median(pm_rec["region_ms_per_step"])
             out["parity_mode"] = {
-                "dtype": "f32 tensors, contractions as 3 x v_mfma_f32_32x32x16_{f16 (forward), bf16 (backward)} on split operands",
+                "dtype": "fp16x2: conv operands as fp16 pairs (hi + lo, split once by their producers), 3 x v_mfma_f32_32x32x16_f16 per "
+                         "product on DMA-fed operands; conv outputs, gradients, BatchNorm, head, criterion, optimiser f32",
                 "value": round(images_per_step / (pms / 1e3), 2), "unit": "images/s", "ms_per_step": round(pms, 3),
                 "region_ms_per_step": pm_rec["region_ms_per_step"], "comm_exposed_ms": pm_rec["comm_exposed_ms"],
                 "loss_first": pm_rec["loss_first"], "loss_last": pm_rec["loss_last"], "roofline": roofline(pm_rec, pms)}
@@ -388,12 +394,12 @@ def main():
             out["data"] = "synthetic (CPU emulator dry-run: NOT a measurement)"
         if world == 1 and not args.no_cpu_baseline:
             try:
-                dts = (args.dtype,) + (("fp32x3",) if pm_rec is not None else ())
+                dts = (args.dtype,) + ((PARITY_MODE,) if pm_rec is not None else ())
                 leg = cpu_baseline_and_parity(args, dev, binding, dts)
                 out["cpu_baseline"] = leg["cpu_baseline"]
                 out["parity"] = leg["parity"][args.dtype]
                 if pm_rec is not None:
-                    out["parity_mode"]["parity"] = leg["parity"]["fp32x3"]
+                    out["parity_mode"]["parity"] = leg["parity"][PARITY_MODE]
             except Exception as e:  # the oracle leg must never hide the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

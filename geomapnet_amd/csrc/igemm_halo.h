@@ -442,300 +442,13 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
   return -1;
 }
 
-// ---- layer1 in the fp16x2 mode: 64 -> 64 channels, h2 operands -----------------------------------------------------------------
-// The generic h2 kernel (igemm.h, 128x64 tiles) re-fetches the pixels for each of the nine taps: 24 KB of LDS-DMA per K-step
-// for 48 MFMAs, 330 us per launch at 192 images = exactly the ~20 B/clk/CU that path sustains (profiles/r04/c3_*).  Here a
-// 288-row tile keeps its WHOLE K extent of A resident -- both 32-channel groups, rows [m0 - (W+1), m0 + 288 + (W+1)) of the
-// flattened pixel order, 2 x 59 KB, fetched once -- and the nine K-steps (= taps) only stream the weights (16 KB each, two
-// slots).  12 waves = (channel group: split-K inside the workgroup) x (3 x 2 wave tiles of 96 x 32): wave group g reads its
-// fragments from image g and the g half of the weight slot; at the end group 1 hands its accumulators to group 0 through LDS.
-// DMA per 288 rows: 118 KB (A) + 147 KB (weights) instead of 972 KB.  Taps walk the image top to bottom, so the first K-step
-// only needs the first three 96-row passes of each image: the remaining passes are requested behind them and waited for
-// (counted vmcnt, in-order retirement) when the first tap that reads them comes up.
-// BP: where in K-step k the weights of K-step k + 1 are requested: 0 = right behind the barrier, 1 = behind the first half's MFMAs
-template <int ABL = 0, int BP = 0>
-static __global__ void __launch_bounds__(768, 3) igemm_halo64_h2_kernel(GatherGeom g, const half* __restrict__ A,
-                                                                        const half* __restrict__ Bw, Epilogue ep, RowDiv rd) {
-  constexpr int NP = 8, WM = 3, WN = 2, TM = 3, NT = 768, BM = 288, BN = 64, WTM = 96, WTN = 32;
-  constexpr int kAH = 464;                 // image rows: 288 + 2 (W + 1), W <= 87
-  constexpr int RPP = NT / NP;             // 96 rows per DMA pass
-  constexpr int A_PASSES = (kAH + RPP - 1) / RPP;  // 5 per image
-  constexpr int A_IMG = kAH * NP, B_SLOT = 2 * BN * NP;  // pieces: one image; one weight slot = [group][64 rows][8]
-  constexpr int RING = 2 * A_IMG + 2 * B_SLOT;
-  static_assert((RING + 1 + WM * BN / 2) * 16 <= 160 * 1024, "LDS");
-  static_assert(RING * 16 >= 6 * 64 * 48 * 4 + 96 * 64 * 4, "accumulator exchange + epilogue staging");
-  __shared__ piece_t smem[RING + 1 + WM * BN / 2];
-  float* red = reinterpret_cast<float*>(&smem[RING + 1]);  // [WM][BN][2]
-
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int kg = wave / 6, w6 = wave - kg * 6;  // channel group of this wave; its (wm, wn) tile
-  const int wm = w6 / WN, wn = w6 % WN;
-  const int tile_m = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = tile_m * BM;
-  const int W = g.Wi, halo = W + 1;
-  if (t == 0) smem[RING] = zero_piece();
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // (the store has reached LDS before this wave's first barrier, igemm_halo_kernel)
-
-  // g.C / g.K count the 2C = 128 fp16 "channels" of the pair layout: a pixel row is two 128-byte groups
-  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(A, (long)g.M * g.C * 2L);
-  const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(Bw, (long)g.N * g.K * 2L);
-  const int pc = t % NP, lrow = t / NP;
-  const int src_piece = pc ^ lds_swz<NP>(lrow);  // rows of one thread differ by multiples of 96: invisible to the swizzle
-
-  unsigned a_off[A_PASSES];
-#pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) {
-    const int pix = m0 - halo + lrow + i * RPP;
-    a_off[i] = (pix >= 0 && pix < g.M) ? (unsigned)pix * (unsigned)(g.C * 2) + (unsigned)src_piece * 16u : ~0u;
-  }
-  // weight slot of a tap: rows [group][n]; threads 0 .. 511 = group 0's 64 rows then the first of group 1's, a second pass
-  // (waves 0 .. 3) the rest: slot row sr = t / 8 + 96 pass, group sr / 64, n = sr % 64
-  unsigned b_off[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int sr = lrow + j * RPP;
-    const int n = sr & 63, grp = sr >> 6;
-    b_off[j] = (sr < 2 * BN && n < g.N) ? (unsigned)(n * g.K) * 2u + (unsigned)(grp * 128) + (unsigned)src_piece * 16u : ~0u;
-  }
-  auto issue_a = [&](int p) {  // pass p of both images (a wave whose rows lie past the image skips: wave-uniform)
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i)
-      if (i == p && wave * (64 / NP) + i * RPP < kAH) {
-        dma16(rsrc_a, a_off[i], 0u, &smem[i * RPP * NP + wave * 64]);
-        dma16(rsrc_a, a_off[i], 128u, &smem[A_IMG + i * RPP * NP + wave * 64]);
-      }
-  };
-  auto issue_b = [&](int tap, int slot) {  // both groups' weight rows of the tap: K offset tap * 128 fp16 channels
-    const unsigned soff = (unsigned)(tap * g.C * 2);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (wave * (64 / NP) + j * RPP < 2 * BN)
-        dma16(rsrc_b, b_off[j], soff, &smem[2 * A_IMG + slot * B_SLOT + j * RPP * NP + wave * 64]);
-  };
-  // fragment rows of this lane: validity mask (bit tap set = outside the image), 9 bits per row tile
-  const int l31 = lane & 31, hi = lane >> 5;
-  unsigned inv_mask = 0;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * WTM + i * 32 + l31;
-    unsigned inv = 0x1ffu;
-    if (m < g.M) {
-      const int tmp = fastdiv(m, rd.q), x = m - tmp * g.Q;
-      const int bb = fastdiv(tmp, rd.p), y = tmp - bb * g.P;
-      inv = 0;
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) {
-          const int yy = y + g.off_h + g.rsign * r, xx = x + g.off_w + g.ssign * s2;
-          const bool ok = (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi;
-          inv |= (ok ? 0u : 1u) << (r * 3 + s2);
-        }
-    }
-    inv_mask |= inv << (9 * i);
-  }
-
-  floatx16 acc[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-  // The taps are walked so that the image rows they read move DOWN the image -- tap order 0..8 for the forward gather
-  // (rsign = +1), 8..0 for the data gradient's transposed gather (rsign = -1): K-step k reads rows [shift_k, shift_k + 288) with
-  // shift_0 = 0 .. 2, so K-step 0 needs only the first three 96-row passes of each image.  Prologue: passes 0-2 + the first
-  // tap's weights; passes 3 and 4 are requested in K-step 0 (behind the second tap's weights), and K-step 1 -- which reads up to
-  // row 290, i.e. pass 3 -- waits with pass 4 (n_p4 instructions of this wave, the youngest in the in-order queue) still in flight.
-  const bool topdown = g.rsign > 0;
-  issue_a(0);
-  issue_a(1);
-  issue_a(2);
-  issue_b(topdown ? 0 : 8, 0);
-  const bool has_p4 = wave * 8 + 4 * RPP < kAH;  // (waves 10, 11 hold no rows of pass 4)
-  for (int k = 0; k < ((ABL & 2) ? 1 : 9); ++k) {
-    const int tap = topdown ? k : 8 - k;
-    const int tr = tap / 3, ts = tap - tr * 3;
-    if (k == 1 && has_p4)
-      wait_vmcnt<2>();
-    else
-      wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // this tap's weights and the image rows it reads landed for every wave; last tap's reads done
-    const piece_t* img = &smem[kg * A_IMG];
-    const piece_t* tb = &smem[2 * A_IMG + (k & 1) * B_SLOT + kg * BN * NP];
-    const int shift = halo + (g.off_h + g.rsign * tr) * W + g.off_w + g.ssign * ts;  // scalar
-    int arow[TM], aswz[TM];
-    bool ainv[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      arow[i] = wm * WTM + i * 32 + l31 + shift;
-      aswz[i] = lds_swz<NP>(arow[i]);
-      ainv[i] = ((inv_mask >> (9 * i + tap)) & 1u) != 0;
-    }
-    const int brow = wn * WTN + l31, bswz = lds_swz<NP>(l31);
-    auto issue_next = [&]() {
-      if constexpr ((ABL & 4) == 0) {
-        // next tap's weights into the other slot (last read in K-step k - 1); in K-step 0 also the lower image passes
-        if (k + 1 < 9) issue_b(topdown ? k + 1 : 7 - k, (k + 1) & 1);
-        if (k == 0) {
-          issue_a(3);
-          issue_a(4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    if constexpr (BP == 0) issue_next();
-    PieceView<half> xa[2][2][TM], xb[2][2];  // [16-k half of the group][plane]
-    auto load_h2 = [&](int h) {
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        const int piece = 4 * pl + 2 * h + hi;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const piece_t* p = ainv[i] ? &smem[RING] : img + arow[i] * NP + (piece ^ aswz[i]);
-          xa[h][pl][i].p = *p;
-        }
-        xb[h][pl].p = tb[brow * NP + (piece ^ bswz)];
-      }
-    };
-    load_h2(0);
-    load_h2(1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if constexpr ((ABL & 16) == 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          mma_piece<half>(xa[h][1][i], xb[h][0], acc[i]);
-          mma_piece<half>(xa[h][0][i], xb[h][1], acc[i]);
-          mma_piece<half>(xa[h][0][i], xb[h][0], acc[i]);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(xa[h][0][i].p), "v"(xa[h][1][i].p));
-        asm volatile("" ::"v"(xb[h][0].p), "v"(xb[h][1].p));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (BP == 1)
-        if (h == 0) issue_next();
-    }
-  }
-  __syncthreads();  // all fragment reads done before the ring is reused
-
-  // ---- split-K exchange: group 1 -> LDS -> group 0 ------------------------------------------------------------------------
-  float* xch = reinterpret_cast<float*>(&smem[0]);  // [6 waves][3][16][64 lanes]
-  if (kg == 1) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xch[((w6 * TM + i) * 16 + r) * 64 + lane] = acc[i][r];
-  }
-  __syncthreads();
-  if (kg == 0) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] += xch[((w6 * TM + i) * 16 + r) * 64 + lane];
-  }
-  if constexpr ((ABL & 1) != 0) {
-    float keep = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) keep += acc[i][0] + acc[i][15];
-    if (keep == 12345.678f) reinterpret_cast<float*>(ep.out)[0] = keep;
-    return;
-  }
-
-  // ---- epilogue: group 0 stages row tile i of its waves (96 rows x 64 columns fp32), all 768 threads store -------------------
-  float* out = reinterpret_cast<float*>(ep.out);
-  const float* res = reinterpret_cast<const float*>(ep.res);
-  const half* gate = reinterpret_cast<const half*>(ep.res_gate);
-  const half* ogate = reinterpret_cast<const half*>(ep.out_gate);
-  float* stage = xch + 6 * TM * 16 * 64;  // behind the exchange block
-  constexpr int CPR = BN / 4, PASSES = (WM * 32 * CPR) / NT;  // 16 pieces per row; 2 passes
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    if (kg == 0) {
-      const int lc = wn * WTN + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][r] * ep.alpha;
-        if (ep.relu & 1) v = fmaxf(v, 0.f);
-        s1 += v;
-        s2 += v * v;
-        const int lr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        stage[lr * BN + lc] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int id = t + ps * NT;
-      const int lr = id / CPR, cpc = id % CPR;
-      const int row = m0 + (lr >> 5) * WTM + i * 32 + (lr & 31);
-      const int col = cpc * 4;
-      if (row < g.M && col < g.N) {
-        const floatx4 f = *reinterpret_cast<const floatx4*>(&stage[lr * BN + col]);
-        float v[4] = {f[0], f[1], f[2], f[3]};
-        const long idx = (long)row * ep.ldc + col;
-        const long gidx = h2_index(row, ep.ldc, col);
-        if (res) {
-          PieceView<float> rv;
-          Half4View gv;
-          rv.p = *reinterpret_cast<const piece_t*>(res + idx);
-          if (gate) gv.p = *reinterpret_cast<const u32x2*>(gate + gidx);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = rv.e[e];
-            if (gate && !((float)gv.e[e] > 0.f)) x = 0.f;
-            v[e] += x;
-          }
-        }
-        if (ogate) {
-          Half4View ov;
-          ov.p = *reinterpret_cast<const u32x2*>(ogate + gidx);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (!((float)ov.e[e] > 0.f)) v[e] = 0.f;
-        }
-        PieceView<float> o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o.e[e] = v[e];
-        *reinterpret_cast<piece_t*>(out + idx) = o.p;
-      }
-    }
-    __syncthreads();
-  }
-  if (ep.stats || ep.stats_accum) {
-    if (kg == 0) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 32) {
-        const int lc = wn * WTN + lane;
-        red[(wm * BN + lc) * 2 + 0] = s1;
-        red[(wm * BN + lc) * 2 + 1] = s2;
-      }
-    }
-    __syncthreads();
-    if (t < BN && t < g.N) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        a += red[(w * BN + t) * 2 + 0];
-        b += red[(w * BN + t) * 2 + 1];
-      }
-      if (ep.stats_accum) {
-        double* row = ep.stats_accum + (long)(tile_m % ep.stats_rows) * 2 * g.N;
-        atomicAdd(row + t, (double)a);
-        atomicAdd(row + g.N + t, (double)b);
-      } else {
-        ep.stats[((long)tile_m * 2 + 0) * g.N + t] = a;
-        ep.stats[((long)tile_m * 2 + 1) * g.N + t] = b;
-      }
-    }
-  }
-}
-
+// (Measured and removed, round 4: a layer1 kernel for the fp16x2 mode with the WHOLE K extent of A resident -- both 32-channel
+// groups of rows [m0 - (W+1), m0 + 288 + (W+1)), 2 x 59 KB, nine K-steps that only stream 16 KB of weights, 12 waves = split-K
+// over the two groups x 3 x 2 wave tiles of 96 x 32, accumulators exchanged through LDS -- parity-green and exactly as fast as
+// the generic 128x64 kernel, 338 us per launch at 192 images.  Ablation (profiles/r04/c8_*): epilogue 95 us (270 MB of fp32
+// output with nothing to overlap it: 153 KB of LDS = one workgroup per CU), prologue + first K-step 73 us, the MFMAs 126 us
+// (= their floor) and 62 us of fragment reads / barriers, all ADDITIVE; 96 x 32 wave tiles need 0.9 ds_read_b128 per MFMA.
+// The generic kernel is DMA-bound at the same 330 us (24 KB of LDS-DMA per K-step of 48 MFMAs at ~20 B/clk/CU).)
 // h2 form: `g2` is the doubled geometry launch_igemm_h2 builds (g2.C = 2 x real channels); every 3x3 stride-1 shape the fp16
 // kernels cover, the 256-column shape when it fills the chip in one round (layer3), the 128-column shape otherwise
 inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream) {
@@ -753,26 +466,6 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   if (igemm_halo_applies(g2, ep, 128, 384)) {
     hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 128, rd);
-    return gm;
-  }
-  // layer1: 64 -> 64 channels (g2.C = 128 fp16 channels), the whole K extent of A resident (MN_H2_HALO64=0: the generic kernel)
-  static const bool halo64 = !(getenv("MN_H2_HALO64") && atoi(getenv("MN_H2_HALO64")) == 0);
-  static const bool trace = getenv("MN_TRACE_DISPATCH") != nullptr;
-  if (trace)
-    fprintf(stderr, "igemm_halo_h2: M %d N %d C %d K %d W %d halo64 %d applies %d\n", g2.M, g2.N, g2.C, g2.K, g2.Wi, (int)halo64,
-            (int)igemm_halo_applies(g2, ep, 64, 464));
-  if (halo64 && g2.N == 64 && g2.C == 128 && igemm_halo_applies(g2, ep, 64, 464)) {
-#ifdef MN_ABLATION_BUILD
-    static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
-    if (abl == 1) { hipLaunchKernelGGL((igemm_halo64_h2_kernel<1>), dim3(gm), dim3(768), 0, stream, g2, A, Bw, ep, rd); return gm; }
-    if (abl == 2) { hipLaunchKernelGGL((igemm_halo64_h2_kernel<2>), dim3(gm), dim3(768), 0, stream, g2, A, Bw, ep, rd); return gm; }
-    if (abl == 3) { hipLaunchKernelGGL((igemm_halo64_h2_kernel<3>), dim3(gm), dim3(768), 0, stream, g2, A, Bw, ep, rd); return gm; }
-    if (abl == 4) { hipLaunchKernelGGL((igemm_halo64_h2_kernel<4>), dim3(gm), dim3(768), 0, stream, g2, A, Bw, ep, rd); return gm; }
-    if (abl == 16) { hipLaunchKernelGGL((igemm_halo64_h2_kernel<16>), dim3(gm), dim3(768), 0, stream, g2, A, Bw, ep, rd); return gm; }
-    if (abl == 20) { hipLaunchKernelGGL((igemm_halo64_h2_kernel<20>), dim3(gm), dim3(768), 0, stream, g2, A, Bw, ep, rd); return gm; }
-    if (abl == 100) { hipLaunchKernelGGL((igemm_halo64_h2_kernel<0, 1>), dim3(gm), dim3(768), 0, stream, g2, A, Bw, ep, rd); return gm; }
-#endif
-    hipLaunchKernelGGL((igemm_halo64_h2_kernel<0>), dim3(gm), dim3(768), 0, stream, g2, A, Bw, ep, rd);
     return gm;
   }
   return -1;

@@ -936,7 +936,7 @@ struct Plan : PlanBase {
       timer.end(tp, s);
       return;
     }
-    if (fuse_stem_bwd) {
+    if (fuse_stem_bwd || h2) {  // (fp16x2: the stem's fp32 tensors make the materialised 1 GB gradient cost 0.5 ms per step)
       // the max-pool's input gradient is gathered from (argmax, pooled gradient) inside the BatchNorm backward
       // passes and the ReLU gate is recomputed from y: neither the activation nor its gradient exists in memory
       PoolGradSrc pg;

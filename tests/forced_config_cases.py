@@ -42,6 +42,10 @@ def main(backend):
         else:
             shapes = ((3, 9, 11, 64, 128, 3, 1, 1), (2, 12, 43, 128, 128, 3, 1, 1), (2, 7, 47, 64, 384, 3, 1, 1), (40, 3, 5, 64, 128, 3, 1, 1))
             dg = ((2, 12, 43, 128, 128, 3, 1, 1), (9, 8, 11, 512, 512, 3, 1, 1))
+        # layer1 geometry (64 -> 64 channels: the generic 128x64 kernel): wide rows, ragged tiles
+        for shape in ((2, 9, 11, 64, 64, 3, 1, 1), (1, 7, 87, 64, 64, 3, 1, 1), (40, 3, 5, 64, 64, 3, 1, 1)):
+            checks.check_conv_fwd(lib, dev, 3, *shape)
+        checks.check_conv_dgrad_op(lib, dev, 3, 2, 9, 43, 64, 64, 3, 1, 1, parity=1, mode="out_gate")
         for shape in shapes:
             checks.check_conv_fwd(lib, dev, 3, *shape)
         for mode in ("plain", "out_gate", "res_gate"):

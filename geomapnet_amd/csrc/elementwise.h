@@ -551,8 +551,12 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
   // (4 rows per thread per iteration in flight; 8 measured equal: 15.07 vs 14.99 ms per step)
+  static const int reduce_u = getenv("MN_BN_REDUCE_U") ? atoi(getenv("MN_BN_REDUCE_U")) : 4;  // (round-4 A/B: rows in flight per thread)
   if (pg.idx)
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
+                       rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
+  else if (reduce_u == 2)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false, 2>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   else
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,

@@ -552,10 +552,10 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_x3_kernel(WgradFuse
 }
 
 // transpose reads requested after item `it` by the time its MFMAs wait (wgrad_fused_h2_kernel): the request groups of the next
-// PD items, four reads each, eight for the first item of a K sub-step (its group carries the A fragments)
-constexpr int wgf_h2_reads_after(int it, int pd, int items) {
+// PD items, four reads each, plus the A reads for the first item of a K sub-step (its group carries the A fragments)
+constexpr int wgf_h2_reads_after(int it, int pd, int items, int a_reads, int b_reads) {
   int n = 0;
-  for (int k = it + 1; k <= it + pd && k < items; ++k) n += (k % 5 == 0) ? 8 : 4;
+  for (int k = it + 1; k <= it + pd && k < items; ++k) n += (k % 5 == 0) ? b_reads + a_reads : b_reads;
   return n;
 }
 // ---- h2 form (round 4): the same tap-fused pass for h2 tensors (common.h MMA_H2) ---------------------------------------------
@@ -568,20 +568,27 @@ constexpr int wgf_h2_reads_after(int it, int pd, int items) {
 // item) run PD items ahead of the MFMAs.  One DMA step in flight (two dY tiles, ring of 2 x 64 + 2 Gpad rows + mirror, four
 // planes: 128 KB of LDS), issued behind item DPI of the step before.
 constexpr int WGF_H2_RING_MAX = 2 * 64 + 2 * 96;
-template <int ABL = 0, int PD = 2, int DPI = 3>
+// BOTH = false (first form): wave = (column block) x (32-row block nb of the output channels) x (tap half), all 64 pixels of
+// a step: per K sub-step 4 A reads, per item 4 B reads + 3 MFMAs -- 1.6 transpose reads per MFMA, as much LDS time as MFMA time.
+// BOTH = true: the fp16 kernel's roles -- wave = (column block) x (pixel half of every step) x (tap half) and BOTH output-channel
+// blocks: a B fragment pair (hi, lo) feeds six MFMAs, 0.93 reads per MFMA; the two pixel halves meet through LDS at the end.
+// LO = false (the fp16 mode's default since round 4, MN_WGF_LIGHT): plain fp16 tensors through the same kernel -- no lo
+// planes, one MFMA per item -- i.e. the fp16 tap-fused weight gradient with ~110 instead of 219 registers per lane, so that the
+// BatchNorm kernels of the main stream can share its CUs' register files.
+template <int ABL = 0, int PD = 2, int DPI = 3, bool BOTH = true, bool LO = true>
 static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFusedArgs a) {
-  constexpr int NW = 8, BKM = 8 * NW, ROWH = 64, NY = 2;
+  constexpr int NW = 8, BKM = 8 * NW, ROWH = 64, NY = 2, NPL = LO ? 2 : 1, EB = LO ? 4 : 2;  // planes; bytes per tensor element
   constexpr int TILE_Y = BKM * ROWH;                      // halves of one dY tile plane
   constexpr int XPLANE = (WGF_H2_RING_MAX + BKM) * ROWH;  // ring + mirror of its first block
   constexpr int YLO = NY * TILE_Y * 2, XLO = XPLANE * 2;  // byte distance hi plane -> lo plane
   static_assert(XLO + (3 * 16 + 4) * ROWH * 2 < 65536, "ds offset field");
   // ONE LDS object: [Y hi tiles][Y lo tiles][X hi ring + mirror][X lo ring + mirror]
-  __shared__ half smem[2 * NY * TILE_Y + 2 * XPLANE] __attribute__((aligned(16)));
-  half* const xh = smem + 2 * NY * TILE_Y;
+  __shared__ half smem[NPL * NY * TILE_Y + NPL * XPLANE] __attribute__((aligned(16)));
+  half* const xh = smem + NPL * NY * TILE_Y;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wc = wave & 1, nb = (wave >> 1) & 1, tset = wave >> 2;
+  const int wc = wave & 1, sub = (wave >> 1) & 1, tset = wave >> 2;  // sub: output-channel block (!BOTH) or pixel half (BOTH)
   const int tap0 = tset * 5, ntap = tset == 0 ? 5 : 4;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int pairs = a.tiles_n * a.tiles_c;
@@ -593,14 +600,15 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFuse
   const int Gpad = a.Gpad, RING = a.ring;
 
   // the h2 tensors as the DMA sees them: rows of 4 ldy / 4 C bytes
-  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dY, (long)a.B * a.P * a.Q * a.ldy * 4L);
-  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X, (long)a.B * a.P * a.Q * a.C * 4L);
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dY, (long)a.B * a.P * a.Q * a.ldy * (long)EB);
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X, (long)a.B * a.P * a.Q * a.C * (long)EB);
   // DMA role (the fp16 kernel's): row t/8 of a 64-row block, LDS slot t%8 = source piece slot ^ swz(row) = channels
   // 8 piece .. 8 piece + 7 of the 64-channel tile; the lo halves of the same channels lie 64 bytes behind the hi halves
   const int drow = t >> 3, dslot = t & 7;
   const int dpiece = dslot ^ wg_swz<8>(drow);
   const int ych = n0 + dpiece * 8, xch = c0 + dpiece * 8;
-  const unsigned ycol = (unsigned)(((ych >> 5) * 64 + (ych & 31)) * 2), xcol = (unsigned)(((xch >> 5) * 64 + (xch & 31)) * 2);
+  const unsigned ycol = LO ? (unsigned)(((ych >> 5) * 64 + (ych & 31)) * 2) : (unsigned)(ych * 2);
+  const unsigned xcol = LO ? (unsigned)(((xch >> 5) * 64 + (xch & 31)) * 2) : (unsigned)(xch * 2);
   const bool y_ok = ych < a.N, x_ok = xch < a.C;
   auto pixel_of = [&](int j) -> int {
     if ((unsigned)j >= (unsigned)a.J) return -1;
@@ -612,37 +620,44 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFuse
   auto issue_y = [&](int step) {
     const int j = j0 + step * BKM + drow;
     const int m = j < j1 ? pixel_of(j) : -1;
-    const unsigned off = (m >= 0 && y_ok) ? (unsigned)m * (unsigned)(a.ldy * 4) + ycol : ~0u;
+    const unsigned off = (m >= 0 && y_ok) ? (unsigned)m * (unsigned)(a.ldy * EB) + ycol : ~0u;
     half* dst = &smem[(step % NY) * TILE_Y + wave * 64 * 8];
     dma16(rsrc_y, off, 0u, dst);
-    dma16(rsrc_y, off, 64u, dst + NY * TILE_Y);
+    if constexpr (LO) dma16(rsrc_y, off, 64u, dst + NY * TILE_Y);
   };
   auto issue_x = [&](int u0) {
     const int m = pixel_of(j0 - Gpad + u0 + drow);
-    const unsigned off = (m >= 0 && x_ok) ? (unsigned)m * (unsigned)(a.C * 4) + xcol : ~0u;
+    const unsigned off = (m >= 0 && x_ok) ? (unsigned)m * (unsigned)(a.C * EB) + xcol : ~0u;
     const int rr = u0 % RING;
     half* dst = xh + rr * ROWH + wave * 64 * 8;
     dma16(rsrc_x, off, 0u, dst);
-    dma16(rsrc_x, off, 64u, dst + XPLANE);
+    if constexpr (LO) dma16(rsrc_x, off, 64u, dst + XPLANE);
     if (rr == 0) {  // block 0 also goes to the mirror behind the ring
       dma16(rsrc_x, off, 0u, xh + RING * ROWH + wave * 64 * 8);
-      dma16(rsrc_x, off, 64u, xh + RING * ROWH + wave * 64 * 8 + XPLANE);
+      if constexpr (LO) dma16(rsrc_x, off, 64u, xh + RING * ROWH + wave * 64 * 8 + XPLANE);
     }
   };
 
-  floatx16 acc[5];  // [tap slot: tap = tap0 + slot] of the output-channel block nb
+  constexpr int NBK = BOTH ? 2 : 1;  // output-channel blocks a wave accumulates
+  floatx16 acc[NBK][5];              // [block][tap slot: tap = tap0 + slot]
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
+  for (int nbk = 0; nbk < NBK; ++nbk)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nbk][i][r] = 0.f;
 
-  // transpose-read lane geometry (the fp16 kernel's); a wave walks all 64 rows of a step
+  // transpose-read lane geometry (the fp16 kernel's)
   const int gq = lane >> 4, i16 = lane & 15;
   const int src_row = i16 >> 2, src_chunk = (i16 & 3) * 4 + (gq & 1) * 16;
-  const int lrow = (gq >> 1) * 8 + src_row;
+  const int lrow = (BOTH ? sub * 32 : 0) + (gq >> 1) * 8 + src_row;  // BOTH: this wave group's half of the step
   const unsigned lds0 = lds_addr_of(smem);
-  const int colA = nb * 32 + src_chunk;
-  const unsigned aA = lds0 + (unsigned)((lrow * ROWH + (((colA >> 3) ^ wg_swz<8>(src_row)) * 8) + (colA & 7)) * 2);
+  unsigned aA[NBK];
+#pragma unroll
+  for (int nbk = 0; nbk < NBK; ++nbk) {
+    const int colA = (BOTH ? nbk : sub) * 32 + src_chunk;
+    aA[nbk] = lds0 + (unsigned)((lrow * ROWH + (((colA >> 3) ^ wg_swz<8>(src_row)) * 8) + (colA & 7)) * 2);
+  }
   const int colB = wc * 32 + src_chunk;
   unsigned xoffB[5];
   int rbB[5];
@@ -651,7 +666,7 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFuse
     const int tp = tap0 + (sl < ntap ? sl : ntap - 1);
     const int sh = Gpad + (tp / 3 - 1) * a.Qp + (tp % 3 - 1);  // in [0, 2 Gpad] < RING
     const int key = (sh + src_row) & 3;
-    xoffB[sl] = lds0 + (unsigned)((2 * NY * TILE_Y + lrow * ROWH + ((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
+    xoffB[sl] = lds0 + (unsigned)((NPL * NY * TILE_Y + lrow * ROWH + ((colB >> 3) ^ (key << 1)) * 8 + (colB & 7)) * 2);
     rbB[sl] = sh * (ROWH * 2);
   }
   const int ring_bytes = RING * ROWH * 2;
@@ -674,45 +689,60 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFuse
     };
     if constexpr (DPI < 0) issue_step();
     const unsigned tyoff = (unsigned)((s % NY) * TILE_Y * 2);
-    constexpr int NKS = 4, ITEMS = NKS * 5, NB = PD + 1;
-    TrFrag fah[2], fal[2], fbh[NB], fbl[NB];
+    constexpr int NKS = BOTH ? 2 : 4, ITEMS = NKS * 5, NB = PD + 1, AR = 2 * NPL * NBK, BR = 2 * NPL;  // A / B reads of a group
+    TrFrag fah[2][NBK], fal[2][NBK], fbh[NB], fbl[NB];
     __builtin_amdgcn_sched_barrier(0);
     // request group of item `it`: the A fragments of its K sub-step (with the sub-step's first item) + its B fragments
     auto request = [&](auto I) {
       constexpr int it = decltype(I)::value, ks = it / 5, sl = it % 5;
       if constexpr (sl == 0) {
-        fah[ks & 1].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, aA + tyoff);
-        fah[ks & 1].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, aA + tyoff);
-        fal[ks & 1].h[0] = ds_read_tr16_at<YLO + (ks * 16) * ROWH * 2>(smem, aA + tyoff);
-        fal[ks & 1].h[1] = ds_read_tr16_at<YLO + (ks * 16 + 4) * ROWH * 2>(smem, aA + tyoff);
+        static_for<NBK>([&](auto NBk) {
+          constexpr int nbk = decltype(NBk)::value;
+          fah[ks & 1][nbk].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, aA[nbk] + tyoff);
+          fah[ks & 1][nbk].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, aA[nbk] + tyoff);
+          if constexpr (LO) {
+            fal[ks & 1][nbk].h[0] = ds_read_tr16_at<YLO + (ks * 16) * ROWH * 2>(smem, aA[nbk] + tyoff);
+            fal[ks & 1][nbk].h[1] = ds_read_tr16_at<YLO + (ks * 16 + 4) * ROWH * 2>(smem, aA[nbk] + tyoff);
+          }
+        });
       }
       const unsigned ad = xoffB[sl] + (unsigned)rbB[sl];
       fbh[it % NB].h[0] = ds_read_tr16_at<(ks * 16) * ROWH * 2>(smem, ad);
       fbh[it % NB].h[1] = ds_read_tr16_at<(ks * 16 + 4) * ROWH * 2>(smem, ad);
-      fbl[it % NB].h[0] = ds_read_tr16_at<XLO + (ks * 16) * ROWH * 2>(smem, ad);
-      fbl[it % NB].h[1] = ds_read_tr16_at<XLO + (ks * 16 + 4) * ROWH * 2>(smem, ad);
+      if constexpr (LO) {
+        fbl[it % NB].h[0] = ds_read_tr16_at<XLO + (ks * 16) * ROWH * 2>(smem, ad);
+        fbl[it % NB].h[1] = ds_read_tr16_at<XLO + (ks * 16 + 4) * ROWH * 2>(smem, ad);
+      }
     };
     static_for<(PD < ITEMS ? PD : ITEMS)>([&](auto I) { request(I); });
     static_for<ITEMS>([&](auto I) {
       constexpr int it = decltype(I)::value, ks = it / 5, sl = it % 5;
       if constexpr (it + PD < ITEMS) request(StaticIndex<it + PD>{});
       // LDS reads return in order: item `it` is in its registers once at most the reads requested AFTER it are outstanding
-      constexpr int later = wgf_h2_reads_after(it, PD, ITEMS);
-      static_assert(later <= 15, "lgkmcnt field");
+      // (capped at the counter field's 15: a smaller count only waits for more than it has to)
+      constexpr int later_all = wgf_h2_reads_after(it, PD, ITEMS, AR, BR), later = later_all > 15 ? 15 : later_all;
       wait_lgkmcnt_for<later>(fbh[it % NB]);
-      wait_lgkmcnt_for<later>(fbl[it % NB]);
+      if constexpr (LO) wait_lgkmcnt_for<later>(fbl[it % NB]);
       if constexpr (sl == 0) {
-        wait_lgkmcnt_for<later>(fah[ks & 1]);
-        wait_lgkmcnt_for<later>(fal[ks & 1]);
+        static_for<NBK>([&](auto NBk) {
+          constexpr int nbk = decltype(NBk)::value;
+          wait_lgkmcnt_for<later>(fah[ks & 1][nbk]);
+          if constexpr (LO) wait_lgkmcnt_for<later>(fal[ks & 1][nbk]);
+        });
       }
       __builtin_amdgcn_sched_barrier(0);
       if (sl < 4 || tset == 0) {  // wave-uniform: slot 4 of the 4-tap half carries no MFMA
         if constexpr ((ABL & 4) == 0) {
-          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ks & 1].v, fbh[it % NB].v, acc[sl], 0, 0, 0);
-          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks & 1].v, fbl[it % NB].v, acc[sl], 0, 0, 0);
-          acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks & 1].v, fbh[it % NB].v, acc[sl], 0, 0, 0);
+          static_for<NBK>([&](auto NBk) {
+            constexpr int nbk = decltype(NBk)::value;
+            if constexpr (LO) {
+              acc[nbk][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ks & 1][nbk].v, fbh[it % NB].v, acc[nbk][sl], 0, 0, 0);
+              acc[nbk][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks & 1][nbk].v, fbl[it % NB].v, acc[nbk][sl], 0, 0, 0);
+            }
+            acc[nbk][sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks & 1][nbk].v, fbh[it % NB].v, acc[nbk][sl], 0, 0, 0);
+          });
         } else {
-          asm volatile("" ::"v"(fal[ks & 1].v), "v"(fah[ks & 1].v), "v"(fbh[it % NB].v), "v"(fbl[it % NB].v));
+          asm volatile("" ::"v"(fah[ks & 1][0].v), "v"(fbh[it % NB].v));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -728,7 +758,44 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFuse
     }
   }
 
-  // partial tile -> workspace slab of this pixel range, or fp32 atomics straight into dW[n][tap*C + c]
+  if constexpr (BOTH) {
+    // the two pixel halves hold partial sums of the same tiles: half 1 hands its block-0 tiles to half 0, half 0 its block-1
+    // tiles to half 1 (through LDS, lane-contiguous), then each flushes the block it collected (the fp16 kernel's exchange)
+    float* xch = reinterpret_cast<float*>(smem);
+    static_assert((NPL * NY * TILE_Y + NPL * XPLANE) * 2 >= 4 * 5 * 16 * 64 * 4, "exchange buffer");
+    const int prw = wc + 2 * tset;
+    __syncthreads();  // every fragment read of the K loop is done
+    if (sub == 1) {
+#pragma unroll
+      for (int sl = 0; sl < 5; ++sl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[((prw * 5 + sl) * 16 + r) * 64 + lane] = acc[0][sl][r];
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int sl = 0; sl < 5; ++sl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][sl][r] += xch[((prw * 5 + sl) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int sl = 0; sl < 5; ++sl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[((prw * 5 + sl) * 16 + r) * 64 + lane] = acc[NBK - 1][sl][r];
+    }
+    __syncthreads();
+    if (sub == 1) {
+#pragma unroll
+      for (int sl = 0; sl < 5; ++sl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[NBK - 1][sl][r] += xch[((prw * 5 + sl) * 16 + r) * 64 + lane];
+    }
+  }
+
+  // partial tile -> workspace slab of this pixel range, or fp32 atomics straight into dW[n][tap*C + c]; this wave flushes the
+  // output-channel block `sub` (BOTH: the block it collected)
   const int K9 = 9 * a.C;
 #pragma unroll
   for (int sl = 0; sl < 5; ++sl) {
@@ -737,12 +804,13 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFuse
     const int c = c0 + wc * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int n = n0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float v = (BOTH && sub == 1) ? acc[NBK - 1][sl][r] : acc[0][sl][r];
       if (n < a.N && c < a.C) {
         if (a.ws)
-          a.ws[((long)ci * a.N + n) * K9 + tp * a.C + c] = acc[sl][r];
+          a.ws[((long)ci * a.N + n) * K9 + tp * a.C + c] = v;
         else
-          unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, acc[sl][r] * a.alpha);
+          unsafeAtomicAdd(a.dW + (long)n * a.ldw + tp * a.C + c, v * a.alpha);
       }
     }
   }
@@ -822,7 +890,6 @@ constexpr int WGF_BLOCKS = 512;  // workgroups per launch: two per CU (the regis
 
 // form: 0 = fp16 tensors, 1 = fp32 tensors on the bf16 pipe (x3), 2 = h2 tensors
 inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream, int form = 0) {
-  const bool x3 = form == 1;
   const GatherGeom& g = w.g;
   constexpr int NW = 8, BKM = 8 * NW;  // (the 4-wave form -- two 256-thread workgroups per CU, twice the partial tiles -- is not launched)
   WgradFusedArgs a;
@@ -840,6 +907,13 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   a.Gpad = ((g.Q + 2 + 15) / 16) * 16;
   a.Gpad = ((a.Gpad + 31) / 32) * 32;  // 2 Gpad must be a multiple of the 64-row DMA block
   constexpr int D = 3;  // DMA steps in flight (the fp32x3 form stages one step ahead through registers)
+  // fp16 tensors: the low-register form of the kernel (134 instead of 219 registers per lane, 64 instead of 96 KB of LDS) is the
+  // default since round 4: equal per launch (111 / 102 / 98 / 106 us against 106 / 105 / 101 / 108 at layers 1-4) and 0.17 ms
+  // faster per step, 13.57 vs 13.75 ms (same-box A/B, two interleaved repeats, profiles/r04/c10_*): two 224-register waves per
+  // SIMD left no room for a BatchNorm-backward wave (122 registers) of the main stream, so the two streams time-sliced the CUs.
+  // MN_WGF_LIGHT=0 restores wgrad_fused_kernel.
+  static const bool light = !(getenv("MN_WGF_LIGHT") && atoi(getenv("MN_WGF_LIGHT")) == 0);
+  if (form == 0 && light) form = 3;
   a.ring = ((form != 0 ? 1 : D) + 1) * BKM + 2 * a.Gpad;
   a.dq = make_fastdiv(a.Qp);
   a.dp = make_fastdiv(g.P + 1);
@@ -861,6 +935,12 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
     fprintf(stderr, "wgrad_fused<%d waves>: B %d P %d Q %d C %d N %d  chunk %d x %d chunks x %d pairs, ring %d rows, ws %d\n", NW,
             a.B, a.P, a.Q, a.C, a.N, a.chunk, a.nchunks, pairs, a.ring, a.ws != nullptr);
   const dim3 grid(a.nchunks * pairs), block(NW * 64);
+  const bool x3 = form == 1;
+  if (form == 3) {  // fp16 tensors through the low-register kernel
+    hipLaunchKernelGGL((wgrad_fused_h2_kernel<0, 3, 3, false, false>), grid, block, 0, stream, a);
+    wgrad_fused_reduce(a, stream);
+    return;
+  }
   if (form == 2) {
 #ifdef MN_ABLATION_BUILD
     static const int ablh = getenv("MN_WGF_ABLATE") ? atoi(getenv("MN_WGF_ABLATE")) : 0;
@@ -868,7 +948,16 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
     if (ablh == 4) { hipLaunchKernelGGL((wgrad_fused_h2_kernel<4>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return; }
     if (ablh == 5) { hipLaunchKernelGGL((wgrad_fused_h2_kernel<5>), grid, block, 0, stream, a); wgrad_fused_reduce(a, stream); return; }
 #endif
-    hipLaunchKernelGGL((wgrad_fused_h2_kernel<0>), grid, block, 0, stream, a);
+    // one output-channel block per wave (150 registers) by default: the both-blocks form is 5-10 % faster per launch (224 / 195 /
+    // 199 / 210 us against 236 / 220 / 226 / 223 at layers 1-4) and 0.7 ms SLOWER per step, 31.22 vs 30.52 ms: at 240 registers x 2
+    // waves per SIMD no BatchNorm wave of the main stream fits beside it (profiles/r04/c9_*)
+    static const int roles = getenv("MN_WGF_H2_ROLES") ? atoi(getenv("MN_WGF_H2_ROLES")) : 0;
+    if (roles == 0)
+      hipLaunchKernelGGL((wgrad_fused_h2_kernel<0, 2, 3, false>), grid, block, 0, stream, a);
+    else if (roles == 2)
+      hipLaunchKernelGGL((wgrad_fused_h2_kernel<0, 1, 3, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((wgrad_fused_h2_kernel<0, 2, 3, true>), grid, block, 0, stream, a);
     wgrad_fused_reduce(a, stream);
     return;
   }

@@ -551,7 +551,11 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   int rows_per_block = (int)rows;
   const int nblk = cdiv(M, rows_per_block);
   // (4 rows per thread per iteration in flight; 8 measured equal: 15.07 vs 14.99 ms per step)
-  static const int reduce_u = getenv("MN_BN_REDUCE_U") ? atoi(getenv("MN_BN_REDUCE_U")) : 4;  // (round-4 A/B: rows in flight per thread)
+  // rows in flight per thread: 2 for fp16 tensors (111 instead of 122 registers: one more wave fits beside the side stream's
+  // weight gradient; 14.01 -> 13.89 ms per step), 4 for fp32 tensors (2: 30.74 -> 30.88 ms in the fp16x2 mode); profiles/r04/c11_*
+  static const int reduce_u = getenv("MN_BN_REDUCE_U") ? atoi(getenv("MN_BN_REDUCE_U")) : (sizeof(T) == 2 ? 2 : 4);
+  // (s_setprio 3 in the backward kernels, so that their waves are not starved by the weight gradient's MFMA waves on the same
+  //  SIMD: no effect, 13.95 vs 14.00 ms fp16, 30.36 vs 30.38 ms fp16x2, profiles/r04/c12_*; removed)
   if (pg.idx)
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);

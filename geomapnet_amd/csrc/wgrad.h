@@ -808,7 +808,12 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
       return;
     }
   }
-  const bool narrow_n = g.N <= 64, narrow_k = g.K <= 64 || (g.K % 128 != 0 && g.K < 256);
+  static const bool stem_wide = !(getenv("MN_STEM_WGRAD_WIDE") && atoi(getenv("MN_STEM_WGRAD_WIDE")) == 0);
+  bool narrow_k = g.K <= 64 || (g.K % 128 != 0 && g.K < 256);
+  // the stem's weight gradient on fp32 tensors (K = 224 columns): two 128-column tiles read the 1 GB d(conv output) twice,
+  // four 64-column tiles four times
+  if (stem_wide && sizeof(T) == 4 && g.mma == MMA_BF16X3 && g.K > 128) narrow_k = false;
+  const bool narrow_n = g.N <= 64;
   int bmo = narrow_n ? 64 : 128, bno = narrow_k ? 64 : 128;
   int tiles = cdiv(g.N, bmo) * cdiv(g.K, bno);
   int splits = cdiv(target_blocks, tiles);

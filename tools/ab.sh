@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of environment knobs on the bench step: tools/ab.sh "VAR=a VAR2=b" "VAR=c" ...   (each arm run twice, interleaved)
+# A/B of environment knobs on the bench step: [DT=fp16x2] tools/ab.sh "VAR=a VAR2=b" "VAR=c" ...   (each arm run twice, interleaved)
 cd "$GRAFT_REPO_ROOT" || exit 1
 for rep in 1 2; do
   for arm in "$@"; do
-    v=$(env $arm python bench.py --no-cpu-baseline --no-events --steps 30 --warmup 8 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
-    echo "[$arm] $v"
+    v=$(env $arm python bench.py --dtype ${DT:-fp16} --no-cpu-baseline --no-events --no-parity-mode --steps ${STEPS:-30} --warmup 8 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    echo "[${DT:-fp16} $arm] $v"
   done
 done

@@ -41,17 +41,21 @@ namespace mn {
 // H2 (round 4): h2 operands (common.h MMA_H2) -- g.C / g.K count the 2C fp16 channels of the pair layout, a 64-"channel" chunk
 // is one 32-channel group (hi halves | lo halves), a K-step = three MFMAs per tile pair and 16-k half of the group, the output
 // (and the residual) fp32, the gates h2.  Same LDS-DMA traffic per K-step as the fp16 kernel for 1.5x its MFMAs.
-template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false>
-static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
+// WM x WN (round 4): the wave grid, wave tiles of 96 x (BN / WN).  3 x 4 = the 12-wave 288-row tile of rounds 1-3; 4 x 2 with BN =
+// 128 = an 8-wave 384-row tile of 96 x 64 wave tiles for the 128-column layers in the fp16x2 mode: 0.55 instead of 0.89 fragment
+// reads per MFMA and, at two waves per SIMD, registers for both halves' fragments.
+template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4>
+static __global__ void __launch_bounds__(WM* WN * 64, WM* WN / 4) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
-  constexpr int VEC = 8, NP = 8, WM = 3, WN = 4, TM = 3, TN = BN / 128, NT = 768;
-  constexpr int BM = 288, WTM = 96, WTN = BN / WN, RPP = NT / NP;  // 96 rows per DMA pass
-  static_assert(BN == 128 || BN == 256, "wave tiles of 96 x 32 or 96 x 64");
+  constexpr int VEC = 8, NP = 8, TM = 3, TN = BN / (WN * 32), NT = WM * WN * 64;
+  constexpr int BM = WM * 96, WTM = 96, WTN = BN / WN, RPP = NT / NP;  // rows per DMA pass
+  static_assert(TN == 1 || TN == 2, "wave tiles of 96 x 32 or 96 x 64");
   constexpr int NBS = 2, A_IMG = kAH * NP, B_SLOT = BN * NP, RING = 2 * A_IMG + NBS * B_SLOT;  // pieces
   static_assert((RING + 1 + WM * BN / 2) * 16 <= 160 * 1024, "LDS");
-  static_assert(RING * 16 >= 96 * 128 * 4, "epilogue staging (the ring is free by then)");
+  static_assert(RING * 16 >= WM * 32 * 128 * 4, "epilogue staging (the ring is free by then)");
   constexpr int A_PASSES = (kAH + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;   // 4, 3
+  static_assert(A_PASSES <= 9, "one image pass per K-step of the chunk before");
   __shared__ piece_t smem[RING + 1 + WM * BN / 2];
   float* red = reinterpret_cast<float*>(&smem[RING + 1]);  // [WM][BN][2]
 
@@ -71,7 +75,8 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(A, (long)g.M * g.C * 2L);
   const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(Bw, (long)g.N * g.K * 2L);
   const int pc = t % NP, lrow = t / NP;
-  const int src_piece = pc ^ lds_swz<NP>(lrow);  // rows of one thread differ by multiples of 96: invisible to the swizzle
+  const int src_piece = pc ^ lds_swz<NP>(lrow);  // rows of one thread differ by multiples of RPP (a multiple of 16): invisible to the swizzle
+  static_assert(RPP % 16 == 0, "swizzle");
 
   // DMA state: byte offset of this thread's row in every pass (all ones = outside the tensor: the bounds check returns 0)
   unsigned a_off[A_PASSES], b_off[B_PASSES];
@@ -166,7 +171,7 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
       // fragment (plane pl, 16-k half h of the group) = pieces 4 pl + 2 h + {0, 1}.  The 128-column shape (48 accumulator
       // registers) keeps both halves' fragments in registers -- the second half's reads fly under the first half's MFMAs --
       // the 256-column shape (96 accumulator registers of the 168 a wave may have) one half at a time.
-      constexpr int NS = BN == 128 ? 2 : 1;
+      constexpr int NS = (NT == 768 && TN == 2) ? 1 : 2;
       PieceView<half> xa[NS][2][TM], xb[NS][2][TN];  // [slot][plane]
       auto load_h2 = [&](int h, int slot) {
 #pragma unroll
@@ -267,7 +272,7 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
   const OT* res = reinterpret_cast<const OT*>(ep.res);
   const half* gate = reinterpret_cast<const half*>(ep.res_gate);
   const half* ogate = reinterpret_cast<const half*>(ep.out_gate);
-  float* stage = reinterpret_cast<float*>(&smem[0]);  // [96][128] fp32
+  float* stage = reinterpret_cast<float*>(&smem[0]);  // [WM * 32][128] fp32
   constexpr int SC = 128, CPR = SC / OVEC, PASSES = (WM * 32 * CPR + NT - 1) / NT;  // 2 (h2: 4)
   float s1[TN], s2[TN];
 #pragma unroll
@@ -395,10 +400,10 @@ static __global__ void __launch_bounds__(768, 3) igemm_halo_kernel(GatherGeom g,
 }
 
 // the launches the kernels cover: fp16 3x3, stride 1, same size, 64-channel chunks
-inline bool igemm_halo_applies(const GatherGeom& g, const Epilogue& ep, int bn, int ah) {
+inline bool igemm_halo_applies(const GatherGeom& g, const Epilogue& ep, int bn, int ah, int bm = 288) {
   return g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&
          g.C % 64 == 0 && g.N % bn == 0 && g.K == 9 * g.C && !g.bt_on && (g.ldb == 0 || g.ldb == g.K) &&
-         (g.rsign == 1 || g.rsign == -1) && g.rsign == g.ssign && 288 + 2 * (g.Wi + 1) <= ah && g.M == g.B * g.P * g.Q &&
+         (g.rsign == 1 || g.rsign == -1) && g.rsign == g.ssign && bm + 2 * (g.Wi + 1) <= ah && g.M == g.B * g.P * g.Q &&
          (long)g.M * g.C * 2 < 0xfffffff0l && (long)g.N * g.K * 2 < 0xfffffff0l && !ep.om_on;
 }
 
@@ -462,6 +467,19 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 256, rd);
     return gm;
+  }
+  // 128-column layers: the 8-wave 384-row tile where it fills the chip's rounds about as well as the 288-row tile does (layer2 at
+  // 192 images: 688 tiles = 2.69 rounds against 918 = 3.59; layer4: 176 tiles = 0.69 of a round against 236 = 0.92 -> 288 rows)
+  static const int bm384 = getenv("MN_H2_HALO384") ? atoi(getenv("MN_H2_HALO384")) : 1;  // 0: never, 1: by tile count, 2: always
+  if (bm384 > 0 && igemm_halo_applies(g2, ep, 128, 480, 384)) {
+    const long t384 = (long)cdiv(g2.M, 384) * (g2.N / 128), t288 = (long)gm * (g2.N / 128);
+    const int cus = device_cus();
+    const double e384 = (double)t384 / ((double)cdiv(t384, cus) * cus), e288 = (double)t288 / ((double)cdiv(t288, cus) * cus);
+    if (bm384 == 2 || e384 >= e288 - 0.03) {
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 480, 0, 1, true, 4, 2>), dim3(cdiv(g2.M, 384) * (g2.N / 128)), dim3(512), 0, stream, g2,
+                         A, Bw, ep, g2.N / 128, rd);
+      return cdiv(g2.M, 384);
+    }
   }
   if (igemm_halo_applies(g2, ep, 128, 384)) {
     hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,

@@ -44,18 +44,23 @@ namespace mn {
 // WM x WN (round 4): the wave grid, wave tiles of 96 x (BN / WN).  3 x 4 = the 12-wave 288-row tile of rounds 1-3; 4 x 2 with BN =
 // 128 = an 8-wave 384-row tile of 96 x 64 wave tiles for the 128-column layers in the fp16x2 mode: 0.55 instead of 0.89 fragment
 // reads per MFMA and, at two waves per SIMD, registers for both halves' fragments.
-template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4>
-static __global__ void __launch_bounds__(WM* WN * 64, WM* WN / 4) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
+// A1 (round 4, layer1 in the fp16x2 mode: 64 columns, rows of 86 pixels): ONE A image instead of two -- the next chunk's image is
+// requested when the last K-step of the current chunk has been read (one barrier, its latency exposed once per chunk) -- so that
+// a 192-row tile of 4 waves needs 63 KB of LDS and TWO workgroups share a CU: each one's prologue, image reload and epilogue run
+// under the other's MFMAs.
+template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4, bool A1 = false>
+static __global__ void __launch_bounds__(WM* WN * 64, (A1 ? 2 : 1) * WM* WN / 4) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
   constexpr int VEC = 8, NP = 8, TM = 3, TN = BN / (WN * 32), NT = WM * WN * 64;
   constexpr int BM = WM * 96, WTM = 96, WTN = BN / WN, RPP = NT / NP;  // rows per DMA pass
   static_assert(TN == 1 || TN == 2, "wave tiles of 96 x 32 or 96 x 64");
-  constexpr int NBS = 2, A_IMG = kAH * NP, B_SLOT = BN * NP, RING = 2 * A_IMG + NBS * B_SLOT;  // pieces
-  static_assert((RING + 1 + WM * BN / 2) * 16 <= 160 * 1024, "LDS");
-  static_assert(RING * 16 >= WM * 32 * 128 * 4, "epilogue staging (the ring is free by then)");
+  constexpr int NBS = 2, NIMG = A1 ? 1 : 2, A_IMG = kAH * NP, B_SLOT = BN * NP, RING = NIMG * A_IMG + NBS * B_SLOT;  // pieces
+  constexpr int SC = BN < 128 ? BN : 128;  // columns staged per epilogue round
+  static_assert((RING + 1 + WM * BN / 2) * 16 <= (A1 ? 80 : 160) * 1024, "LDS");
+  static_assert(RING * 16 >= WM * 32 * SC * 4, "epilogue staging (the ring is free by then)");
   constexpr int A_PASSES = (kAH + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;   // 4, 3
-  static_assert(A_PASSES <= 9, "one image pass per K-step of the chunk before");
+  static_assert(A1 || A_PASSES <= 9, "one image pass per K-step of the chunk before");
   __shared__ piece_t smem[RING + 1 + WM * BN / 2];
   float* red = reinterpret_cast<float*>(&smem[RING + 1]);  // [WM][BN][2]
 
@@ -95,7 +100,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, WM* WN / 4) igemm_halo_ker
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
       if (i == p && wave * (64 / NP) + i * RPP < kAH)
-        dma16(rsrc_a, a_off[i], (unsigned)(chunk * 128), &smem[(chunk & 1) * A_IMG + i * RPP * NP + wave * 64]);
+        dma16(rsrc_a, a_off[i], (unsigned)(chunk * 128), &smem[(A1 ? 0 : (chunk & 1)) * A_IMG + i * RPP * NP + wave * 64]);
   };
   auto issue_b = [&](int kt) {
     const int chunk = kt / 9, tap = kt - chunk * 9;
@@ -103,7 +108,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, WM* WN / 4) igemm_halo_ker
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j)
       if (wave * (64 / NP) + j * RPP < BN)
-        dma16(rsrc_b, b_off[j], soff, &smem[2 * A_IMG + (kt % NBS) * B_SLOT + j * RPP * NP + wave * 64]);
+        dma16(rsrc_b, b_off[j], soff, &smem[NIMG * A_IMG + (kt % NBS) * B_SLOT + j * RPP * NP + wave * 64]);
   };
   // Fragment rows of this lane: tile-local row, its validity mask (bit tap set = outside the image, 9 bits per row tile)
   const int l31 = lane & 31, hi = lane >> 5;
@@ -150,12 +155,13 @@ static __global__ void __launch_bounds__(WM* WN * 64, WM* WN / 4) igemm_halo_ker
     auto issue_step = [&]() {
       if constexpr ((ABL & 4) == 0) {
         if (kt + NBS - 1 < KT) issue_b(kt + NBS - 1);
-        if (tap < A_PASSES && chunk + 1 < NCH) issue_a(chunk + 1, tap);
+        if constexpr (!A1)
+          if (tap < A_PASSES && chunk + 1 < NCH) issue_a(chunk + 1, tap);
       }
     };
     if constexpr (DP == 0) issue_step();
-    const piece_t* img = &smem[(chunk & 1) * A_IMG];
-    const piece_t* tb = &smem[2 * A_IMG + (kt % NBS) * B_SLOT];
+    const piece_t* img = &smem[(A1 ? 0 : (chunk & 1)) * A_IMG];
+    const piece_t* tb = &smem[NIMG * A_IMG + (kt % NBS) * B_SLOT];
     const int shift = halo + (g.off_h + g.rsign * tr) * W + g.off_w + g.ssign * ts;  // scalar
     // per row tile: LDS row of this lane for this tap, its swizzle, and whether the lane reads the zero slot instead
     int arow[TM], aswz[TM];
@@ -244,6 +250,13 @@ static __global__ void __launch_bounds__(WM* WN * 64, WM* WN / 4) igemm_halo_ker
         }
     }
     }  // fp16 / h2
+    if constexpr (A1) {  // the chunk's last K-step has been read by this wave: once every wave is here the image may be replaced
+      if (tap == 8 && chunk + 1 < NCH && (ABL & 4) == 0) {
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) issue_a(chunk + 1, p);
+      }
+    }
     if (++ts == 3) {
       ts = 0;
       ++tr;
@@ -272,8 +285,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, WM* WN / 4) igemm_halo_ker
   const OT* res = reinterpret_cast<const OT*>(ep.res);
   const half* gate = reinterpret_cast<const half*>(ep.res_gate);
   const half* ogate = reinterpret_cast<const half*>(ep.out_gate);
-  float* stage = reinterpret_cast<float*>(&smem[0]);  // [WM * 32][128] fp32
-  constexpr int SC = 128, CPR = SC / OVEC, PASSES = (WM * 32 * CPR + NT - 1) / NT;  // 2 (h2: 4)
+  float* stage = reinterpret_cast<float*>(&smem[0]);  // [WM * 32][SC] fp32
+  constexpr int CPR = SC / OVEC, PASSES = (WM * 32 * CPR + NT - 1) / NT;  // 2 (h2: 4)
   float s1[TN], s2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
@@ -467,6 +480,15 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 256, rd);
     return gm;
+  }
+  // layer1 (64 -> 64 channels, rows of up to 87 pixels): 192-row tiles of 4 waves, one A image, two workgroups per CU
+  static const bool halo64 = !(getenv("MN_H2_HALO64") && atoi(getenv("MN_H2_HALO64")) == 0);
+  // (measured: 338 -> 304 us forward, 356 -> 326 data gradient, step 29.69 -> 29.52 ms; 288-row tiles of 6 waves at two workgroups
+  //  per CU -- 27 % less DMA per row -- 409 us: six waves do not spread over four SIMDs; profiles/r04/c15_*, c16_*)
+  if (halo64 && g2.N == 64 && igemm_halo_applies(g2, ep, 64, 368, 192)) {
+    hipLaunchKernelGGL((igemm_halo_kernel<64, 368, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192)), dim3(256), 0, stream, g2, A, Bw, ep, 1,
+                       rd);
+    return cdiv(g2.M, 192);
   }
   // 128-column layers: the 8-wave 384-row tile where it fills the chip's rounds about as well as the 288-row tile does (layer2 at
   // 192 images: 688 tiles = 2.69 rounds against 918 = 3.59; layer4: 176 tiles = 0.69 of a round against 236 = 0.92 -> 288 rows)

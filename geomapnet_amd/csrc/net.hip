@@ -333,7 +333,7 @@ struct Plan : PlanBase {
       // finalize kernels add the rows in a fixed order.  Forward producers: the stem kernel's persistent workgroups, the
       // layer1 kernel's persistent workgroups (halo_pp.h: at most one per 16x16-pixel tile), M-tiles of >= 128 rows elsewhere.
       if (is_stem)
-        u.rows_f = use_stem_kernel && DT == MN_F16 ? 1024 : cdiv((int)u.M, 128);
+        u.rows_f = use_stem_kernel && (DT == MN_F16 || mma_fwd == MMA_F16X3) ? 1024 : cdiv((int)u.M, 128);
       else if (halo_path(u.gf))
         u.rows_f = u.gf.B * cdiv(u.gf.P, kHaloTH) * cdiv(u.gf.Q, kHaloTW);
       else
@@ -638,6 +638,8 @@ struct Plan : PlanBase {
     auto* tp = timer.begin(0, s);
     if (h2 && &u != &stem)  // h2 activation and weights in, fp32 conv output + statistics out
       launch_igemm_h2(u.gf, (const half*)x, (const half*)u.wf, ep, s, (const half*)zero_page);
+    else if (&u == &stem && DT == MN_F32 && mma_fwd == MMA_F16X3 && use_stem_kernel)  // the split-operand form of the stem kernel
+      launch_stem_conv_x3((const float*)x, (const float*)u.wf, (float*)u.y, training ? u.accum_f : nullptr, u.rows_f, B, H, W, Wp, s);
     else if (&u == &stem && DT == MN_F16 && use_stem_kernel)  // weights in registers, input pairs read straight from LDS (stem.h)
       launch_stem_conv((const half*)x, (const half*)u.wf, (half*)u.y, training ? u.accum_f : nullptr, u.rows_f, B, H, W, Wp, s);
     else if (halo_path(u.gf) && conv_halo_pp_applies(u.gf, ep))

@@ -140,6 +140,14 @@ extern "C" int mn_op_stem_conv(const void* xpad, const void* wf, void* y, double
   return check_launch("stem_conv");
 }
 
+extern "C" int mn_op_stem_conv_x3(const float* xpad, const float* wf, float* y, double* stats_accum, int stats_rows, int B, int H,
+                                  int W, int Wp, void* stream) {
+  begin_call();
+  if (Wp % 2 != 0 || Wp < W + 7) return fail("stem_conv_x3: Wp must be even and >= W + 7");
+  launch_stem_conv_x3(xpad, wf, y, stats_accum, stats_rows, B, H, W, Wp, (hipStream_t)stream);
+  return check_launch("stem_conv_x3");
+}
+
 extern "C" int mn_op_stem_bwd(const void* y, const unsigned char* idx, const void* gp, const float* gamma, const float* beta,
                               const float* mean, const float* invstd, const void* xpad, float* dW, int ldw, const int32_t* colmap,
                               float* dgamma, float* dbeta, float* coef_scratch, double* accum_scratch, int B, int H, int W, int Wp,

@@ -243,6 +243,10 @@ int mn_op_conv_dgrad(int dtype, int B, int Hin, int Win, int Cin, int Cout, int 
  * sums (sum, sum of squares), added to atomically. */
 int mn_op_stem_conv(const void* xpad, const void* wf, void* y, double* stats_accum, int stats_rows, int B, int H, int W, int Wp,
                     void* stream);
+/* the same kernel shape for fp32 tensors (fp32x3 / fp16x2 modes): fp32 padded input and pair-layout weights in, operands split
+ * into fp16 hi + lo halves on the way into LDS / registers, three MFMAs per product, fp32 output */
+int mn_op_stem_conv_x3(const float* xpad, const float* wf, float* y, double* stats_accum, int stats_rows, int B, int H, int W,
+                       int Wp, void* stream);
 /* Stem backward (fp16) below maxpool(relu(bn1(conv1(x)))) in two launches (csrc/stem_bwd.h): BatchNorm sums with the
  * max-pool's input gradient gathered on the fly from (idx, gp), then conv1's weight gradient with d(conv output) computed
  * tile by tile in LDS.  y: raw conv output [B][H0][W0][64]; idx / gp: argmax bytes and gradient of the pooled activation

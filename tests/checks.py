@@ -328,6 +328,18 @@ def check_stem(lib, dev, dtype, B, H, W, seed=3):
         s1, s2 = acc[:, 0].sum(0).cpu(), acc[:, 1].sum(0).cpu()
         assert (s1 - rd.sum((0, 2, 3))).abs().max().item() <= 1e-4 * rd.abs().max().item() * n ** 0.5 + 1e-4
         assert ((s2 - (rd ** 2).sum((0, 2, 3))).abs() / (rd ** 2).sum((0, 2, 3))).max().item() <= 1e-4
+    if dtype == 2:  # the split-operand form of the stem kernel (fp32 tensors, the fp32x3 / fp16x2 modes' stem) + its sums
+        out2 = torch.full((B, H0, W0, 64), float("nan"), device=dev)
+        acc = torch.zeros(3, 2, 64, dtype=torch.float64, device=dev)
+        lib.check(lib.op_stem_conv_x3(K(xp.to(dev)), K(wc.reshape(64, 224).to(dev)), K(out2), K(acc), 3, B, H, W, Wp, None))
+        dev_sync(dev)
+        o2 = out2.cpu().double().permute(0, 3, 1, 2)
+        assert (o2 - ref).abs().max().item() <= OUT_TOL[dtype] * ref.abs().max().item()
+        n = B * H0 * W0
+        rd = ref.detach()
+        s1, s2 = acc[:, 0].sum(0).cpu(), acc[:, 1].sum(0).cpu()
+        assert (s1 - rd.sum((0, 2, 3))).abs().max().item() <= 1e-4 * rd.abs().max().item() * n ** 0.5 + 1e-4
+        assert ((s2 - (rd ** 2).sum((0, 2, 3))).abs() / (rd ** 2).sum((0, 2, 3))).max().item() <= 1e-4
     gy = torch.randn(B, 64, H0, W0, generator=gen).to(td).float()
     ref.backward(gy.double())
     cm = torch.full((224,), -1, dtype=torch.int32)

@@ -55,6 +55,7 @@ _PROTOS = {
     "mn_set_loss_scale": (c_i, [c_void, c_f, c_i]),
     "mn_get_loss_scale": (c_i, [c_void, C.POINTER(c_f), C.POINTER(c_i64)]),
     "mn_debug_tensor": (c_i, [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(c_i64), C.POINTER(C.c_int32)]),
+    "mn_set_dropout": (c_i, [c_void, c_f, C.c_uint64]),
     "mn_set_input_u8": (c_i, [c_void, c_i, C.POINTER(c_f), C.POINTER(c_f)]),
     "mn_forward": (c_i, [c_void, c_void, c_void, c_i, c_void]),
     "mn_loss": (c_i, [c_void, c_void, c_void, c_void, c_void]),

@@ -25,12 +25,49 @@ static __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __res
 
 __device__ __forceinline__ float nan_to_zero(float v) { return (v != v) ? 0.f : v; }
 
+// ---- dropout on the feature vector (models/posenet.py:68-69: F.dropout(x, p=droprate) between the ReLU and the pose heads) ----
+// Philox4x32-10 (Salmon et al. 2011), counter = (element / 4, call, 0, 0), key = seed: element i of call c always draws the
+// same number whatever the launch shape, so a mask can be reproduced from (seed, c) alone.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// feat[i] *= mask[i], mask[i] = (u_i >= p) / (1 - p): inverted dropout as torch.nn.functional.dropout; the mask (0 or 1/(1-p))
+// is kept for the backward pass and for inspection (mn_debug_tensor "dropmask")
+static __global__ void __launch_bounds__(256) dropout_fwd_kernel(float* __restrict__ feat, float* __restrict__ mask, long n, float p,
+                                                                 unsigned seed_lo, unsigned seed_hi, unsigned call) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;  // four elements per thread: one Philox block
+  if (q * 4 >= n) return;
+  unsigned r[4];
+  philox4x32_10((unsigned)q, call, 0u, 0u, seed_lo, seed_hi, r);
+  const float keep = 1.f / (1.f - p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long i = q * 4 + e;
+    if (i >= n) break;
+    const float u = (float)(r[e] >> 8) * (1.f / 16777216.f);  // 24 random bits -> [0, 1)
+    const float m = u >= p ? keep : 0.f;
+    mask[i] = m;
+    feat[i] *= m;
+  }
+}
+
 // dz[b][k] = (feat[b][k] > 0) * ( sum_o dp[b][o] Wx[o][k]  +  filt( sum_o dp[b][3+o] Wq[o][k] ) )
 // (feat is the post-ReLU feature, so the gate is the ReLU derivative of posenet.py:66)
 static __global__ void __launch_bounds__(256) head_bwd_input_kernel(const float* __restrict__ dposes,
                                                               const float* __restrict__ feat,
                                                               const float* __restrict__ Wx, const float* __restrict__ Wq,
-                                                              float* __restrict__ dz, int B, int K, int filter_nans) {
+                                                              float* __restrict__ dz, int B, int K, int filter_nans,
+                                                              const float* __restrict__ dropmask = nullptr) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * K) return;
   int k = (int)(i % K), b = (int)(i / K);
@@ -39,6 +76,9 @@ static __global__ void __launch_bounds__(256) head_bwd_input_kernel(const float*
   float gq = (dp[3] * Wq[k] + dp[4] * Wq[K + k]) + dp[5] * Wq[2 * K + k];
   if (filter_nans) gq = nan_to_zero(gq);
   float g = gx + gq;
+  // with dropout `feat` is the dropped vector: a dropped element is 0 (gate closed), a kept one keeps its sign, and the
+  // gradient w.r.t. the vector before the dropout is g * mask
+  if (dropmask) g *= dropmask[i];
   dz[i] = (feat[i] > 0.f) ? g : 0.f;
 }
 

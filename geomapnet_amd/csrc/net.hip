@@ -184,6 +184,11 @@ struct PlanBase {
   virtual int sync_step_to_device(hipStream_t s) = 0;
   virtual int64_t applied_steps() = 0;  // the device's count of optimiser steps that were applied (waits for the device)
   virtual int forward(const void* images, float* poses_out, int training, hipStream_t s) = 0;
+  // dropout between the feature vector's ReLU and the pose heads (mn_set_dropout): probability, Philox key, calls so far
+  float drop_p = 0.f;
+  unsigned long long drop_seed = 0;
+  unsigned drop_calls = 0;
+  bool drop_this_step = false;  // the forward pass of the step being built applied a mask (the backward pass must, too)
   bool input_u8 = false;  // images are uint8 NHWC, normalised on the device (mn_set_input_u8)
   InputNorm input_norm{{1.f, 1.f, 1.f}, {0.f, 0.f, 0.f}};
   virtual int loss_only(const float* pred, const float* targ, float* loss_out, hipStream_t s) = 0;
@@ -204,7 +209,8 @@ struct PlanBase {
   long long skipped_seen = 0;
   int64_t attempts = 0;           // optimiser steps enqueued on this plan (skipped ones included)
   int64_t scale_set_at = 0;       // `attempts` when the loss scale last changed: later attempts ran under cur_scale
-  int64_t stuck_skips = 0;        // skips seen while the scale already was 1 (nothing left to lower)
+  int64_t stuck_skips = 0;        // CONSECUTIVE skips seen while the scale already was 1 (nothing left to lower); any clean
+                                  // step, a scale growth or mn_set_loss_scale resets it
   int clean_steps = 0;
   int scale_growth_interval = getenv("MN_SCALE_GROWTH") ? atoi(getenv("MN_SCALE_GROWTH")) : 2000;
   void poll_overflow() {
@@ -225,11 +231,15 @@ struct PlanBase {
       }
       skipped_seen = seen;
       clean_steps = 0;
-    } else if (scale_growth_interval > 0 && ++clean_steps >= scale_growth_interval) {
-      clean_steps = 0;
-      if (cur_scale < 65536.f) {
-        cur_scale *= 2.f;
-        scale_set_at = attempts;
+    } else {
+      // no new skip since the last poll: training is progressing (isolated non-finite batches at scale 1 are not "stuck")
+      stuck_skips = 0;
+      if (scale_growth_interval > 0 && ++clean_steps >= scale_growth_interval) {
+        clean_steps = 0;
+        if (cur_scale < 65536.f) {
+          cur_scale *= 2.f;
+          scale_set_at = attempts;
+        }
       }
     }
   }
@@ -289,7 +299,7 @@ struct Plan : PlanBase {
   int H0, W0, H1, W1;  // stem conv output, pooled output
   std::vector<Block> blocks;
   int Hl, Wl;  // last feature map
-  float *pooled, *feat, *poses, *dposes, *dz, *dpooled, *fcT, *loss_dev;
+  float *pooled, *feat, *poses, *dposes, *dz, *dpooled, *fcT, *loss_dev, *dropmask;
   // BatchNorm sums are accumulated with fp64 atomics straight from the producing kernels (conv epilogue, backward
   // reduction) into ACC_ROWS rows per unit (row = producer block % ACC_ROWS, to spread same-address contention);
   // the consuming apply kernels add the rows in their prologue.  No separate partial-reduction launches.
@@ -408,6 +418,7 @@ struct Plan : PlanBase {
     poses = (float*)A((size_t)B * 6 * 4);
     dposes = (float*)A((size_t)B * 6 * 4);
     dz = (float*)A((size_t)B * F * 4);
+    dropmask = (float*)A((size_t)B * F * 4);
     dpooled = (float*)A((size_t)B * 512 * 4);
     fcT = (float*)A((size_t)512 * F * 4);
     loss_dev = (float*)A(256);
@@ -742,6 +753,15 @@ struct Plan : PlanBase {
     ep.out = feat; ep.ldc = F; ep.stats = nullptr; ep.bias = params + L.fc_b; ep.relu = 1; ep.res = nullptr;
     ep.res_gate = nullptr; ep.alpha = 1.f;
     launch_igemm<float>(g, (const float*)pooled, (const float*)(params + L.fc_w), ep, s, (const float*)zero_page);
+    // F.dropout(x, p=droprate) (models/posenet.py:68-69), in training mode only (mn_set_dropout explains the reference's two
+    // readings): a fresh Philox mask per training forward pass, kept for the backward pass
+    drop_this_step = training && drop_p > 0.f;
+    if (drop_this_step) {
+      const long n = (long)B * F;
+      hipLaunchKernelGGL(dropout_fwd_kernel, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, feat, dropmask, n, drop_p,
+                         (unsigned)(drop_seed & 0xffffffffu), (unsigned)(drop_seed >> 32), drop_calls);
+      drop_calls += 1;
+    }
     hipLaunchKernelGGL(head_fwd_kernel, dim3(cdiv((long)B * 6 * 64, 256)), dim3(256), 0, s, (const float*)feat,
                        (const float*)(params + L.xyz_w), (const float*)(params + L.xyz_b),
                        (const float*)(params + L.wpqr_w), (const float*)(params + L.wpqr_b), poses, B, F);
@@ -890,7 +910,7 @@ struct Plan : PlanBase {
     post_loss(cur_loss, s);
     hipLaunchKernelGGL(head_bwd_input_kernel, dim3(cdiv((long)B * F, 256)), dim3(256), 0, s, (const float*)dposes,
                        (const float*)feat, (const float*)(params + L.xyz_w), (const float*)(params + L.wpqr_w), dz, B, F,
-                       cfg.filter_nans);
+                       cfg.filter_nans, drop_this_step ? (const float*)dropmask : (const float*)nullptr);
     hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(cdiv(6L * (F + 1), 256)), dim3(256), 0, s, (const float*)dposes,
                        (const float*)feat, grads + L.xyz_w, grads + L.xyz_b, grads + L.wpqr_w, grads + L.wpqr_b, B, F,
                        unscale, cfg.filter_nans);
@@ -993,6 +1013,7 @@ struct Plan : PlanBase {
     if (n == "dposes") return give(dposes, (long)B * 6, MN_F32);
     if (n == "dz") return give(dz, (long)B * cfg.feat_dim, MN_F32);
     if (n == "dpooled") return give(dpooled, (long)B * 512, MN_F32);
+    if (n == "dropmask") return give(dropmask, (long)B * cfg.feat_dim, MN_F32);
     if (n.size() > 2 && n[0] == 'b') {  // "b<block>.<tensor>", blocks numbered 0..15 in network order
       const size_t dot = n.find('.');
       if (dot != std::string::npos) {
@@ -1161,6 +1182,9 @@ extern "C" int mn_set_optim_method(mn_handle* h, int method, int nesterov) {
 }
 extern "C" int mn_set_step_count(mn_handle* h, int64_t step) {
   MN_H(h);
+  // steps still in flight on the caller's (non-blocking) stream increment the device counter in adam_prep_kernel: let them
+  // finish before the counter is overwritten through the NULL stream
+  if (hipDeviceSynchronize() != hipSuccess) return check_launch("set_step_count");
   P.step = step;
   return P.sync_step_to_device(nullptr);
 }
@@ -1203,10 +1227,19 @@ extern "C" int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval)
   P.scale_set_at = P.attempts;
   P.scale_growth_interval = growth_interval;
   P.clean_steps = 0;
+  P.stuck_skips = 0;
   if (P.overflow_host) {  // skips of steps still in flight belong to the old scale: do not halve the new one for them
     hipDeviceSynchronize();
     P.skipped_seen = *(volatile long long*)(P.overflow_host + 1);
   }
+  return 0;
+}
+extern "C" int mn_set_dropout(mn_handle* h, float p, uint64_t seed) {
+  MN_H(h);
+  if (!(p >= 0.f && p < 1.f)) return fail("mn_set_dropout: 0 <= p < 1 required");
+  P.drop_p = p;
+  P.drop_seed = seed;
+  P.drop_calls = 0;
   return 0;
 }
 extern "C" int mn_set_input_u8(mn_handle* h, int enable, const float* mean, const float* std) {

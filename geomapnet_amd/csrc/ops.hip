@@ -292,10 +292,21 @@ static int bn_train_fwd_t(const void* y, int64_t M, int C, const float* gamma, c
   return check_launch("bn_train_fwd");
 }
 
+// the apply kernels keep a thread's per-channel coefficients in registers: its channel piece must be the same in every
+// grid-stride iteration, i.e. C / VEC pieces per row must be a power of two that divides the 256-thread workgroup
+static int check_bn_channels(int dtype, int C) {
+  const int vec = dtype == MN_F16 ? 8 : 4;
+  const int cpr = C / vec;
+  if (C <= 0 || C % vec != 0 || C > 512 || cpr > 256 || (cpr & (cpr - 1)) != 0)
+    return fail("bn: C must be a power of two times the 16-byte piece (8 halves / 4 floats), at most 512");
+  return 0;
+}
+
 extern "C" int mn_op_bn_train_fwd(int dtype, const void* y, int64_t M, int C, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, float* mean, float* invstd, const void* res,
                                   int relu, void* out, float eps, float momentum, double* accum_scratch, void* stream) {
   begin_call();
+  if (int e = check_bn_channels(dtype, C)) return e;
   if (dtype == MN_F16)
     return bn_train_fwd_t<half>(y, M, C, gamma, beta, running_mean, running_var, mean, invstd, res, relu, out, eps,
                                 momentum, accum_scratch, (hipStream_t)stream);
@@ -318,6 +329,7 @@ extern "C" int mn_op_bn_bwd(int dtype, const void* g, const void* gate, const vo
                             const float* mean, const float* invstd, float* dgamma, float* dbeta, void* gy,
                             float* coef_scratch, double* accum_scratch, float grad_unscale, void* stream) {
   begin_call();
+  if (int e = check_bn_channels(dtype, C)) return e;
   hipMemsetAsync(accum_scratch, 0, 2 * C * sizeof(double), (hipStream_t)stream);
   if (dtype == MN_F16)
     return bn_bwd_t<half>(g, gate, y, M, C, gamma, mean, invstd, dgamma, dbeta, gy, coef_scratch, accum_scratch,

@@ -88,6 +88,7 @@ class Engine:
         self.loss_scale = None
         self.eps_mode = 0
         self.input_u8 = None  # (mean[3], std[3]) when images arrive as uint8 NHWC and are normalised on the device
+        self.dropout = (0.0, 0)  # (p, Philox seed) of the device dropout on the feature vector (mn_set_dropout); p = 0: identity
 
     # -- arenas ---------------------------------------------------------------------------------
     @property
@@ -187,6 +188,9 @@ class Engine:
                 mean, std = ((C.c_float * 3)(*[float(v) for v in vals]) for vals in self.input_u8)
                 self.lib.check(self.lib.set_input_u8(p["handle"], 1, mean, std))
             p["input_u8"] = self.input_u8
+        if p.get("dropout", (0.0, 0)) != self.dropout:
+            self.lib.check(self.lib.set_dropout(p["handle"], C.c_float(self.dropout[0]), C.c_uint64(self.dropout[1])))
+            p["dropout"] = self.dropout
         self._own_step(p)
         return p
 
@@ -217,7 +221,7 @@ class Engine:
         forward pass that overflowed); the device skips them forever.  Raise instead of printing losses that train nothing."""
         stuck = int(self.lib.stuck_overflow_steps(p["handle"]))
         if stuck >= limit:
-            raise MapNetHipError("%d training steps were skipped with non-finite gradients at loss scale 1: the inputs or "
+            raise MapNetHipError("%d consecutive training steps were skipped with non-finite gradients at loss scale 1: the inputs or "
                                  "the forward pass are not finite (fp16 range?); no parameter has been updated since" % stuck)
 
     def debug_tensor(self, plan, name):
@@ -231,6 +235,24 @@ class Engine:
         return work[off: off + n.value * es].view(torch.float16 if dt.value == 1 else torch.float32)
 
     # -- calls --------------------------------------------------------------------------------------
+    def set_dropout(self, p, seed=0):
+        """device dropout on the feature vector in training forward passes (include/mapnet_hip.h mn_set_dropout); p = 0 disables"""
+        self.dropout = (float(p), int(seed))
+
+    def dropout_mask(self, plan):
+        """[images, feat_dim] mask (0 or 1/(1-p)) the last training forward pass of `plan` applied (parity tooling)"""
+        ptr_, n, dt = C.c_void_p(), C.c_int64(), C.c_int32()
+        self.lib.check(self.lib.debug_tensor(plan["handle"], b"dropmask", C.byref(ptr_), C.byref(n), C.byref(dt)))
+        if self.params.is_cuda:
+            torch.cuda.synchronize(self.device)
+        buf = (C.c_float * n.value).from_address(ptr_.value) if not self.params.is_cuda else None
+        if buf is not None:
+            return torch.frombuffer(buf, dtype=torch.float32).clone().view(plan["images"], self.feat_dim)
+        out = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        off = ptr_.value - plan["work"].data_ptr()
+        out.copy_(plan["work"][off:off + 4 * n.value].view(torch.float32))
+        return out.view(plan["images"], self.feat_dim)
+
     def set_input_u8(self, mean=None, std=None):
         """images become uint8 [.., H, W, 3]; (x/255 - mean)/std runs on the device.  mean=None: back to fp32 NCHW."""
         self.input_u8 = None if mean is None else (tuple(float(v) for v in mean), tuple(float(v) for v in std))

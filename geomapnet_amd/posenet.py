@@ -162,12 +162,26 @@ def resnet34(pretrained=False, _binding=None):
 
 class PoseNet(_ArenaModule):
     def __init__(self, feature_extractor, droprate=0.5, pretrained=True, feat_dim=2048, filter_nans=False,
-                 _binding=None):
+                 dropout_active=False, dropout_seed=0, _binding=None):
+        """droprate / dropout_active: the reference calls `F.dropout(x, p=self.droprate)` without `training=`
+        (models/posenet.py:68-69).  Under its pinned PyTorch 0.4.1 that default is training=False: an IDENTITY in train() and
+        eval() alike -- which is what `dropout_active=False` (default) reproduces, with a warning when droprate > 0 because
+        the shipped configs ask for 0.5 and get none.  `dropout_active=True` runs the operator on the device in train()
+        (Philox mask keyed by `dropout_seed`, inverted scaling; never in eval()), i.e. nn.Dropout semantics."""
         super().__init__()
         self.droprate = droprate
+        self.dropout_active = bool(dropout_active)
+        if droprate > 0 and not self.dropout_active:
+            import warnings
+            warnings.warn("PoseNet(droprate=%g): dropout is an IDENTITY here, as under the reference's pinned PyTorch 0.4.1 "
+                          "(F.dropout default training=False, models/posenet.py:68-69); pass dropout_active=True "
+                          "(scripts: --dropout_active) to drop features on the device in training mode" % droprate,
+                          stacklevel=2)
         if _binding is None:
             _binding = getattr(feature_extractor, "_binding", None)
         eng = Engine(feat_dim, binding=_binding, filter_nans=filter_nans)
+        if self.dropout_active and droprate > 0:
+            eng.set_dropout(droprate, dropout_seed)
         self._build_tree(eng)
         # adopt the trunk weights and buffers
         src = feature_extractor.state_dict()
@@ -210,8 +224,8 @@ class PoseNet(_ArenaModule):
         if x.device != self._engine.device:
             raise RuntimeError("input on %s but model on %s" % (x.device, self._engine.device))
         x = x.contiguous() if u8 else x.float().contiguous()
-        # dropout: identity, as under the reference's pinned PyTorch 0.4.1 (F.dropout default
-        # training=False at models/posenet.py:68-69)
+        # dropout: the engine applies it in training mode when PoseNet(dropout_active=True); otherwise an identity, as under
+        # the reference's pinned PyTorch 0.4.1 (F.dropout default training=False at models/posenet.py:68-69)
         return self._engine.forward(x, self.training)
 
 

@@ -138,6 +138,16 @@ int64_t mn_get_step_count(mn_handle* h);
  * stats (model.train()), else running statistics (model.eval()). */
 int mn_forward(mn_handle* h, const void* images, float* poses_out, int training, void* stream);
 
+/* Dropout on the feature vector, between its ReLU and the two pose heads: replaces `F.dropout(x, p=self.droprate)`
+ * (models/posenet.py:68-69).  The reference calls it WITHOUT `training=`: under its pinned PyTorch 0.4.1 the default is
+ * training=False, i.e. an identity in train() and eval() alike; under PyTorch >= 1.0 the default is True, i.e. dropout is always
+ * on.  The library implements the operator; which reading a model uses is the host's choice: p = 0 (default) is the pinned
+ * identity, p > 0 drops in TRAINING forward passes (mn_train_step / mn_train_forward_loss / mn_forward with training != 0) and
+ * never at inference.  The mask is inverted dropout (kept values scaled by 1 / (1 - p)) drawn from Philox4x32-10 with key `seed`
+ * and counter (element / 4, number of training forward passes since this call): reproducible, independent of launch shapes, and
+ * readable after a step as mn_debug_tensor "dropmask" ([images][feat_dim] floats, 0 or 1 / (1 - p)). */
+int mn_set_dropout(mn_handle* h, float p, uint64_t seed);
+
 /* Device-side input pipeline (replaces torchvision's ToTensor + Normalize of the reference's transforms,
  * scripts/train.py:120-128): with enable != 0 the `images` argument of mn_forward / mn_train_step /
  * mn_train_forward_loss is uint8 NHWC [windows*frames][H][W][3] (decoded image bytes) and
@@ -172,15 +182,17 @@ int mn_optim_step(mn_handle* h, float grad_mul, void* stream);
  * count). */
 int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval);
 int mn_get_loss_scale(mn_handle* h, float* scale, int64_t* skipped_steps);
-/* Steps that were skipped although the loss scale already was 1 (as seen by the host so far): non-finite values no loss
- * scale can remove -- a NaN input or a forward pass that overflowed.  Training makes no progress while this number grows;
- * the Python mirror raises after a few of them (the reference, in fp32, would print NaN losses). */
+/* CONSECUTIVE steps that were skipped although the loss scale already was 1 (as seen by the host so far): non-finite values no
+ * loss scale can remove -- a NaN input or a forward pass that overflowed.  Any step that is applied, a scale growth or
+ * mn_set_loss_scale resets the count to 0 (isolated bad batches do not accumulate); training makes no progress while it grows
+ * and the Python mirror raises after a few of them (the reference, in fp32, would print NaN losses). */
 int64_t mn_stuck_overflow_steps(mn_handle* h);
 
 /* Inspection for parity tooling (tests/, tools/layer_error.py): device pointer, element count and MN_DTYPE_* of a named
  * tensor of the work arena as the last step left it.  Names: "xpad", "stem.y", "stem.gy", "p0", "gp0", "pooled", "feat",
- * "poses", "dposes", "dz", "dpooled", and per residual block i = 0..15 "b<i>.y1 | a1 | y2 | out | gy1 | ga1 | gy2 | gout"
- * (+ "yd", "zd", "gyd" for blocks with a projection); NHWC.  Read-only for the caller. */
+ * "poses", "dposes", "dz", "dpooled", "dropmask", and per residual block i = 0..15 "b<i>.y1 | a1 | y2 | out | gy1 | ga1 | gy2 | gout"
+ * (+ "yd", "zd", "gyd" for blocks with a projection); NHWC.  In the fp16x2 mode the tensors the convolutions consume ("p0",
+ * "a1", "out", "zd", "gy1", "gy2", "gyd") are h2 tensors and report dtype MN_DTYPE_F16X2.  Read-only for the caller. */
 int mn_debug_tensor(mn_handle* h, const char* name, void** ptr, int64_t* numel, int32_t* dtype);
 
 /* parameters changed behind the library's back (load_state_dict): refresh compute copies */

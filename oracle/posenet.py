@@ -8,7 +8,8 @@ Follows /root/reference/models/posenet.py:
   * MapNet.forward    (:87-97)  -- fold the T frames of each window into the batch.
   * filter_hook       (:28-34)  -- zero NaNs in the gradients flowing out of fc_wpqr.
 
-Dropout: the reference calls F.dropout(x, p) without `training=` (:68-69).  Under its pinned
+Dropout: the reference calls F.dropout(x, p) without `training=` (:68-69).  (`dropout_mask`, an attribute set by the
+parity tests, replaces the random draw by a given mask.)  Under its pinned
 PyTorch 0.4.1 that default is training=False, i.e. identity; under torch>=1.0 it is always
 active.  `dropout_active=False` (default) reproduces the pinned behaviour; parity runs use
 droprate=0 where both readings coincide.
@@ -44,7 +45,11 @@ class PoseNet(nn.Module):
 
     def forward(self, x):
         feat = F.relu(self.feature_extractor(x))
-        if self.droprate > 0 and self.dropout_active:
+        if getattr(self, "dropout_mask", None) is not None:
+            # explicit mask (0 or 1/(1-p) per element): what F.dropout computes for ONE draw -- the parity tests hand the
+            # oracle the mask the device drew (mn_debug_tensor "dropmask"), since two generators cannot agree on a draw
+            feat = feat * self.dropout_mask
+        elif self.droprate > 0 and self.dropout_active:
             feat = F.dropout(feat, p=self.droprate, training=True)
         if self.filter_nans:
             # reference: register_backward_hook(filter_hook) on fc_wpqr (:50-51).  The legacy

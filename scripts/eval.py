@@ -35,6 +35,9 @@ def build_parser():
     parser.add_argument("--output_dir", type=str, default=None, help="Output directory")
     parser.add_argument("--pose_graph", action="store_true", help="Turn on Pose Graph Optimization")
     # additions
+    parser.add_argument("--dropout_active", action="store_true",
+                        help="apply the config's dropout on the device in training mode (default: identity, the reference's "
+                             "behaviour under its pinned PyTorch 0.4.1)")
     parser.add_argument("--dtype", choices=("fp16", "fp16x2", "fp32x3", "fp32"), default="fp16")
     parser.add_argument("--synthetic_length", type=int, default=256)
     parser.add_argument("--u8_input", action="store_true", help="frames as uint8 [H,W,3]; ToTensor + Normalize run on the "
@@ -78,7 +81,7 @@ def run(args, dataset=None, pose_stats=None, _binding=None, log=print):
 
     # model
     feature_extractor = G.resnet34(pretrained=False, **kw)
-    posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=False, **kw)
+    posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=False, dropout_active=args.dropout_active, **kw)
     if args.model.find("mapnet") >= 0:
         model = G.MapNet(mapnet=posenet)
     else:

@@ -42,6 +42,9 @@ def build_parser():
                         help="Resume optimization (only effective if a checkpoint is given")
     parser.add_argument("--suffix", type=str, default="", help="Experiment name suffix (as is)")
     # additions
+    parser.add_argument("--dropout_active", action="store_true",
+                        help="apply the config's dropout on the device in training mode (default: identity, the reference's "
+                             "behaviour under its pinned PyTorch 0.4.1)")
     parser.add_argument("--dtype", choices=("fp16", "fp16x2", "fp32x3", "fp32"), default="fp16", help="compute precision of the HIP kernels")
     parser.add_argument("--pretrained", choices=("auto", "yes", "no"), default="auto",
                         help="start from the torchvision ImageNet ResNet-34 ($TORCH_MODEL_ZOO/resnet34-333f7ec4.pth, as the "
@@ -126,7 +129,8 @@ def run(args, datasets=None, _binding=None, log=print):
     pretrained = args.pretrained == "yes" or (args.pretrained == "auto" and os.path.isfile(zoo_file))
     print("ResNet-34 weights: %s" % ("ImageNet (%s)" % zoo_file if pretrained else "random initialisation"))
     feature_extractor = G.resnet34(pretrained=pretrained, **kw)
-    posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=pretrained, filter_nans=(args.model == "mapnet++"), **kw)
+    posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=pretrained, filter_nans=(args.model == "mapnet++"),
+                        dropout_active=args.dropout_active, dropout_seed=seed, **kw)
     model = posenet if args.model == "posenet" else G.MapNet(mapnet=posenet)
 
     if args.u8_input:  # the DataLoader ships decoded frames; normalisation happens in the input-conversion kernel

@@ -752,6 +752,88 @@ def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps
     return report
 
 
+def check_dropout(lib, dev, dtype_name="fp32", N=2, H=64, W=85, p_drop=0.5, seed=1234, loss_rtol=1e-4, pose_atol=1e-3,
+                  grad_l2_rtol=2e-2):
+    """F.dropout(x, p) between the feature ReLU and the pose heads (models/posenet.py:68-69) on the device: one MapNet training
+    step with PoseNet(droprate=0.5, dropout_active=True) against the oracle applying THE SAME mask (read back from the device);
+    the mask itself (values, keep rate, a fresh draw per step, reproducible from the seed); eval() does not drop"""
+    _fresh()
+    import geomapnet_amd as G
+    G.set_compute_dtype(dtype_name)
+    torch.manual_seed(7)
+    onet = oracle.MapNet(oracle.PoseNet(oracle.resnet34(), droprate=p_drop, pretrained=False))
+    sd0 = {k: v.clone() for k, v in onet.state_dict().items()}
+
+    def hip_net():
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")  # dropout_active=True must not trigger the identity warning
+            net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=p_drop, pretrained=False, dropout_active=True,
+                                     dropout_seed=seed, _binding=lib))
+        net.load_state_dict(sd0)
+        if torch.device(dev).type == "cuda":
+            net.cuda()
+        return net
+
+    net = hip_net()
+    x, t = oracle.make_batch("mapnet", N, H, W, seed=7)
+    oc = oracle.MapNetCriterion(0.0, -3.0, 0.0, -3.0, True, True)
+    c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+    oopt = oracle.Optimizer([{"params": onet.parameters()}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}], "adam",
+                            base_lr=1e-4, weight_decay=5e-4)
+    opt = G.Optimizer([{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}], "adam",
+                      base_lr=1e-4, weight_decay=5e-4)
+    onet.train()
+    net.train()
+    l, p = G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True, 0.0)
+    eng = net.mapnet._engine
+    plan = next(iter(eng.plans.values()))
+    mask = eng.dropout_mask(plan).cpu()
+    keep = 1.0 / (1.0 - p_drop)
+    assert mask.shape == (N * 3, 2048)
+    assert bool(((mask == 0) | ((mask - keep).abs() < 1e-6)).all()), "mask values must be 0 or 1/(1-p)"
+    frac = (mask == 0).float().mean().item()
+    assert abs(frac - p_drop) < 5.0 * (p_drop * (1 - p_drop) / mask.numel()) ** 0.5 + 1e-3, frac
+    # the oracle with the device's mask
+    onet.mapnet.dropout_mask = mask
+    lo, po = oracle.step_feedfwd(x, onet, False, t, oc, oopt, True, 0.0)
+    assert abs(l - lo) <= loss_rtol * max(1.0, abs(lo)), (l, lo)
+    assert (p.cpu() - po.detach()).abs().max().item() <= pose_atol, (p.cpu() - po.detach()).abs().max().item()
+    og_ = dict(onet.named_parameters())
+    worst = 0.0
+    for e in eng.entries:
+        if e.is_buffer:
+            continue
+        g = _view(eng.grads(), e).cpu().double()
+        r = og_["mapnet." + e.name.decode()].grad.double()
+        if r.norm() > 1e-8:
+            worst = max(worst, ((g - r).norm() / r.norm()).item())
+    assert worst <= grad_l2_rtol, worst
+    # a second training step draws a different mask; a model built from the same seed draws the same first mask
+    G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True, 0.0)
+    mask2 = eng.dropout_mask(plan).cpu()
+    assert not torch.equal(mask, mask2)
+    net_b = hip_net()
+    net_b.train()
+    cb = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+    optb = G.Optimizer([{"params": net_b.parameters()}, {"params": [cb.sax, cb.saq]}, {"params": [cb.srx, cb.srq]}], "adam",
+                       base_lr=1e-4, weight_decay=5e-4)
+    G.step_feedfwd(x.to(dev), net_b, dev != "cpu", t.to(dev), cb, optb, True, 0.0)
+    eb = net_b.mapnet._engine
+    assert torch.equal(eb.dropout_mask(next(iter(eb.plans.values()))).cpu(), mask)
+    # eval(): no dropout (nn.Dropout semantics) -- the forward pass equals the oracle's without a mask
+    onet2 = oracle.MapNet(oracle.PoseNet(oracle.resnet34(), droprate=p_drop, pretrained=False))
+    onet2.load_state_dict(sd0)
+    onet2.eval()
+    net_c = hip_net()
+    net_c.eval()
+    with torch.no_grad():
+        ref = onet2(x)
+    out = net_c(x.to(dev))
+    assert (out.cpu() - ref).abs().max().item() <= pose_atol * max(1.0, ref.abs().max().item())
+    return {"loss": l, "loss_oracle": lo, "dropped_fraction": frac, "grad_worst": worst}
+
+
 def check_eval_forward(lib, dev, dtype_name, B=3, H=64, W=85, atol=1e-3):
     _fresh()
     import geomapnet_amd as G

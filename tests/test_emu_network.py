@@ -31,6 +31,10 @@ def test_mapnet_train_step_fp16x2_parity(lib):
     assert rep[0][2] < 1e-3
 
 
+def test_dropout_on_the_device_with_the_oracle_applying_the_same_mask(lib):
+    checks.check_dropout(lib, DEV, "fp32", N=1, H=32, W=40)
+
+
 def test_eval_forward_fp32(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=2, H=40, W=53)
 

@@ -57,6 +57,27 @@ def test_conv_data_gradient_op(lib, dtype, shape, mode, parity):
     checks.check_conv_dgrad_op(lib, DEV, dtype, *shape, parity=parity, mode=mode)
 
 
+@pytest.mark.parametrize("wgs", [0, 7, 64])
+@pytest.mark.parametrize("mode", ["plain", "res_gate", "out_gate"])
+def test_conv_halo_pp(lib, mode, wgs):
+    """halo_pp.h, the persistent two-wave-group kernel that is layer1's only forward / data-gradient path in the fp16 mode, as
+    an operator on the hardware: layer1 geometry (rows of 86 pixels, several images), ragged small shapes, every epilogue
+    variant, several persistent-workgroup counts (0 = the launcher's choice; 7 and 64 = tiles per workgroup that do / do not
+    divide evenly), forward with BatchNorm sums and data gradient"""
+    for (B, H, W) in ((2, 64, 86), (3, 9, 11), (1, 33, 70)):
+        checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=False, mode="plain", seed=H * 100 + W, pp_wgs=wgs)
+        checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=True, mode=mode, seed=H * 100 + W + 1, pp_wgs=wgs)
+
+
+def test_conv_halo_pp_race_screen(lib):
+    """the same kernel at a size with hundreds of concurrent persistent workgroups, repeated: its DMA / two-group hand-over has
+    no other detector on the hardware (the emulator runs workgroups one at a time)"""
+    for rep in range(4):
+        checks.check_conv_halo(lib, DEV, 24, 64, 86, Cout=64, dgrad=False, mode="plain", seed=300 + rep)
+        checks.check_conv_halo(lib, DEV, 24, 64, 86, Cout=64, dgrad=True, mode="out_gate", seed=400 + rep)
+        checks.check_conv_halo(lib, DEV, 24, 64, 86, Cout=64, dgrad=True, mode="res_gate", seed=500 + rep, pp_wgs=100)
+
+
 @pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape,blocks", [
     ((2, 9, 11, 64, 64, 3, 1, 1), 8), ((3, 9, 11, 64, 128, 3, 2, 1), 8), ((2, 8, 10, 64, 128, 1, 2, 0), 1),
@@ -223,6 +244,12 @@ def test_nan_filter_with_a_nan_cotangent(lib, dtype):
     """filter_hook (models/posenet.py:28-34,50-51) fed a real NaN d(pred) through head_bwd_*: d(input), d(weight), d(bias)
     vs the oracle's autograd + hooks; without the filter NaN reaches the same parameters"""
     checks.check_nan_filter(lib, DEV, dtype, N=2, H=64, W=85)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16x2"])
+def test_dropout_on_the_device_with_the_oracle_applying_the_same_mask(lib, dtype):
+    """models/posenet.py:68-69 with droprate = 0.5 (what every shipped config asks for): device Philox mask, oracle fed the same mask"""
+    checks.check_dropout(lib, DEV, dtype, N=2, H=64, W=85)
 
 
 def test_fp16_overflow_skips_the_step_and_lowers_the_scale(lib):

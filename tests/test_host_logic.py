@@ -76,6 +76,23 @@ def test_state_dict_surface_matches_reference_layout():
     assert float(pn.fc_xyz.bias.abs().max()) == 0.0
 
 
+def test_dropout_identity_warns_and_active_dropout_does_not():
+    """PoseNet(droprate > 0) is an identity (the reference under its pinned PyTorch 0.4.1) and says so loudly;
+    dropout_active=True arms the device operator instead (mn_set_dropout) and is silent"""
+    import warnings
+    import emu_lib
+    import geomapnet_amd as G
+    lib = emu_lib.load()
+    with pytest.warns(UserWarning, match="IDENTITY"):
+        net = G.PoseNet(G.resnet34(_binding=lib), droprate=0.5, pretrained=False, _binding=lib)
+    assert net._engine.dropout == (0.0, 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        net = G.PoseNet(G.resnet34(_binding=lib), droprate=0.5, pretrained=False, dropout_active=True, dropout_seed=5, _binding=lib)
+        G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, _binding=lib)
+    assert net._engine.dropout == (0.5, 5)
+
+
 def test_criterion_facade_surface():
     import geomapnet_amd as G
     c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=False)
@@ -176,8 +193,9 @@ def test_shipped_k_loops_have_no_scratch_access_and_asm_reads_skip_the_dma_wait(
                            r"igemm_kernelIDF16_Li2ELi2ELi2ELi2ELi8ELi2ELi2ELb1ELb0ELi0ELi0E|"
                            r"igemm_kernelIDF16_Li2ELi2ELi4ELi2ELi4ELi3ELi2ELb1ELb0ELi0ELi0E|"
                            r"wgrad_dma_kernelILi\d+ELi\d+ELi32ELi\dELb1ELb1E|"
-                           r"igemm_halo_kernelILi\d+ELi\d+ELi0ELi1E")  # igemm_halo_kernel<BN, kAH, ABL = 0, DP = 1>: two shapes
-    assert len(hot) == 9, sorted(hot)
+                           r"igemm_halo_kernelILi\d+ELi\d+ELi0ELi1E")  # igemm_halo_kernel<BN, kAH, ABL = 0, DP = 1, H2, WM, WN, A1>:
+    # two fp16 shapes + the four h2 shapes of the fp16x2 mode (256 columns, 128 columns at 288 / 384 rows, layer1's 64 columns)
+    assert len(hot) == 13, sorted(hot)
     for name, (_, _, sig) in hot.items():
         assert "S!" not in sig, (name, sig)
     asm = {n: s for n, (_, _, s) in hot.items() if "wgrad_dma" in n and n.split("ELb1ELb")[1].startswith("1")}

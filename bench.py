@@ -277,6 +277,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline + parity)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the second timed pass in the parity mode (fp16x2)")
     ap.add_argument("--no-events", action="store_true", help="do not time conv launches with HIP events")
+    ap.add_argument("--no-eval-metric", action="store_true",
+                    help="skip the accuracy leg (BASELINE's 'median t/q err': a learnable synthetic scene trained and evaluated "
+                         "through scripts/train.py -> scripts/eval.py in the timed dtype and in the parity mode, ~15 s each)")
     ap.add_argument("--emu", action="store_true",
                     help="TEST ONLY: run the same code on the CPU SIMT-emulator build of the kernels over gloo "
                          "(tests/test_bench_launch.py); never a measurement")
@@ -402,6 +405,25 @@ def main():
                     out["parity_mode"]["parity"] = leg["parity"][PARITY_MODE]
             except Exception as e:  # the oracle leg must never hide the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and not args.no_eval_metric and not args.emu:
+            # BASELINE.json's metric also names "median t/q err": train a LEARNABLE synthetic scene (data.RenderedFrames: the
+            # picture is a smooth function of the camera pose) for 1280 steps at 64x85 through the reference's command-line flow
+            # (scripts/train.py run -> checkpoint -> scripts/eval.py run) in the timed dtype and in the parity mode, identical seeds,
+            # and report the reference's evaluation metric on held-out frames of the scene
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import accuracy_eval
+                em = {"what": "median translation / rotation (deg) error on 128 held-out frames of a synthetic scene after 1280 "
+                              "training steps (16 windows x T=3, 64x85, Adam lr 1e-3, random init), scripts/train.py -> scripts/eval.py; "
+                              "single runs of this task spread by about +-40 % (atomics make a run irreproducible): "
+                              "profiles/r04/c23_accuracy_fp16_vs_fp16x2_three_seeds.txt has three seeds per mode"}
+                for d in (args.dtype,) + ((PARITY_MODE,) if args.dtype != PARITY_MODE else ()):
+                    res, base = accuracy_eval.train_and_eval(d, 40, 512, 128, 64, 85, 16, 1e-3)
+                    em[d] = {k: round(v, 4) for k, v in res.items()}
+                    em["baseline_predict_mean"] = {k: round(v, 4) for k, v in base.items()}
+                out["eval_metric"] = em
+            except Exception as e:
+                out["eval_metric"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

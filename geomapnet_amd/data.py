@@ -207,3 +207,55 @@ class SyntheticFrames(torch.utils.data.Dataset):
             _, H, W = self.shape
             return torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8), self.poses[int(i)]
         return torch.randn(*self.shape, generator=g), self.poses[int(i)]
+
+
+class RenderedFrames(torch.utils.data.Dataset):
+    """a LEARNABLE synthetic scene (SyntheticFrames' pixels say nothing about the pose): a frame is a smooth function of its
+    camera pose -- K fixed gratings (orientation, spatial frequency) whose per-colour AMPLITUDES are smooth monotone functions of
+    the 6-DoF pose, drawn with a random phase per frame, plus pixel noise --
+
+        image[c, y, x] = sum_k A[k, c](pose) * sin(2 pi u[k] . (x / W, y / H) + phase[frame, k]) + noise * N(0, 1)
+        A[k, c](pose)  = 0.6 + 0.4 tanh(M[k, c] . pose / scale)
+
+    The pose is encoded in translation-invariant statistics (the energy per grating and colour), which a convolutional network
+    with global average pooling can read, so a few hundred training steps regress it and the reference's evaluation metric
+    (median translation / rotation error, scripts/eval.py:193-205) measures how well a training run did.  `scene_seed` fixes the
+    scene (u, M) and the pose curve; `seed` the sample positions on the curve, the phases and the noise: a training set and a
+    held-out set of the SAME scene use one scene_seed and two seeds.  Poses are (translation, log-quaternion) along a closed
+    smooth curve, consecutive frames consecutive on it (windows of frames `skip` apart have small relative poses); `gt_idx` =
+    identity.  All frames are rendered once, at construction."""
+
+    def __init__(self, length, H=64, W=85, seed=7, scene_seed=1, K=6, noise=0.05):
+        g = torch.Generator().manual_seed(seed)
+        sg = torch.Generator().manual_seed(1000 + scene_seed)
+        self.shape, self.seed, self.length = (3, H, W), seed, length
+        # the pose curve (scene property) sampled at `length` consecutive positions with a per-set offset (seed)
+        ph = 6.283185307 * torch.rand(5, generator=sg)
+        s = (torch.arange(length, dtype=torch.float32) + torch.rand(1, generator=g)) / length * 6.283185307
+        t = torch.stack((torch.sin(s + ph[0]), 0.8 * torch.sin(2 * s + ph[1]), 0.6 * torch.sin(3 * s + ph[2])), dim=1)
+        axis0 = torch.nn.functional.normalize(torch.randn(3, generator=sg), dim=0)
+        wob = torch.stack((torch.sin(s + ph[4]), torch.cos(2 * s + ph[4]), torch.sin(3 * s)), dim=1)
+        axis = torch.nn.functional.normalize(axis0[None, :] + 0.8 * wob, dim=1)  # the rotation axis wanders around axis0
+        ang = 0.8 + 0.5 * torch.sin(2 * s + ph[3])                               # 0.3 .. 1.3 rad
+        self.poses = torch.cat((t, axis * (ang[:, None] / 2)), dim=1)
+        self.gt_idx = np.arange(length)
+        freq = (torch.rand(K, 2, generator=sg) * 4.0 + 2.0) * torch.sign(torch.randn(K, 2, generator=sg))  # cycles per image
+        mix = torch.randn(K, 3, 6, generator=sg)
+        scale = torch.tensor([1.0, 0.8, 0.6, 0.4, 0.4, 0.4])
+        amp = 0.6 + 0.4 * torch.tanh(torch.einsum("kcj,nj->nkc", mix, self.poses / scale) * 0.7)  # [N, K, 3]
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32) / H, torch.arange(W, dtype=torch.float32) / W, indexing="ij")
+        plane = 6.283185307 * (freq[:, 0, None, None] * xs[None] + freq[:, 1, None, None] * ys[None])  # [K, H, W]
+        phase = 6.283185307 * torch.rand(length, K, generator=g)
+        self.images = torch.empty(length, 3, H, W)
+        for n0 in range(0, length, 64):  # (chunks: the [n, K, H, W] intermediate stays small)
+            sl = slice(n0, min(length, n0 + 64))
+            waves = torch.sin(plane[None] + phase[sl, :, None, None])
+            self.images[sl] = torch.einsum("nkc,nkhw->nchw", amp[sl], waves) / K ** 0.5 * 1.5
+        if noise > 0:
+            self.images += noise * torch.randn(self.images.shape, generator=g)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        return self.images[int(i)], self.poses[int(i)]

@@ -2,7 +2,9 @@
 ABI on a real MI355X, at small sizes against the oracle / torch fp64 and at BASELINE.json's full
 sizes through size-independent properties (adjoint identities, finite decreasing loss)."""
 import ctypes as C
+import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +14,7 @@ import checks
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -250,6 +253,27 @@ def test_nan_filter_with_a_nan_cotangent(lib, dtype):
 def test_dropout_on_the_device_with_the_oracle_applying_the_same_mask(lib, dtype):
     """models/posenet.py:68-69 with droprate = 0.5 (what every shipped config asks for): device Philox mask, oracle fed the same mask"""
     checks.check_dropout(lib, DEV, dtype, N=2, H=64, W=85)
+
+
+def test_fp16_trains_to_the_accuracy_of_the_parity_mode():
+    """BASELINE's metric names "median t/q err": a learnable synthetic scene (data.RenderedFrames) trained for 1280 steps through
+    scripts/train.py -> scripts/eval.py in fp16 and in fp16x2 from identical seeds; both must learn (errors below half of what
+    predicting the mean training pose scores) and fp16 must stay within 2.5x of the parity mode on both numbers.  (Single runs
+    spread by ~ +-40 %: the step is not bit-reproducible and Adam at lr 1e-3 amplifies that; measured over three seeds the two
+    modes are indistinguishable, 0.19 / 7.9 deg against 0.17 / 8.2 deg, profiles/r04/c23_*.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import accuracy_eval
+    res = {}
+    for d in ("fp16", "fp16x2"):
+        res[d], base = accuracy_eval.train_and_eval(d, 40, 512, 128, 64, 85, 16, 1e-3)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "accuracy_fp16_vs_fp16x2.json"), "w") as f:
+            json.dump({"fp16": res["fp16"], "fp16x2": res["fp16x2"], "baseline_predict_mean": base}, f)
+    for d in res:
+        assert res[d]["median_t"] < 0.5 * base["median_t"] and res[d]["median_q"] < 0.5 * base["median_q"], (d, res[d], base)
+    assert res["fp16"]["median_t"] <= 2.5 * res["fp16x2"]["median_t"], res
+    assert res["fp16"]["median_q"] <= 2.5 * res["fp16x2"]["median_q"], res
 
 
 def test_fp16_overflow_skips_the_step_and_lowers_the_scale(lib):

@@ -42,6 +42,7 @@ GFLOP_PER_IMAGE_TRAIN = 39.06   # 3 x 13.02 GFLOP (fwd + dgrad +
 GFLOP_PER_IMAGE_EXECUTED = 38.65  # the stem's unused input gradient is not computed
 PEAK_F16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_BYTES_PER_S = 8.0e12   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PROFILE_ROUND = "r04"
 PARITY_MODE = "fp16x2"
 
@@ -229,6 +230,9 @@ def timed_mode(args, dtype_name, dev, binding, world, rank, repeats):
             G.step_feedfwd(images, net, True, targets, crit, opt, True)
         sync()
         ex = sorted(dp.exposed_comm_ms())
+        tl = dp.bucket_timeline_ms()
+        if tl and rank == 0:  # one step's per-bucket record: {stage: (bucket ready, stream past its all-reduce)} in ms after backward began
+            rec["bucket_timeline_ms"] = {str(k): v for k, v in tl[len(tl) // 2].items()}
         dp.set_profiling(False)
         ex_t = torch.tensor([ex[len(ex) // 2]], device=dev, dtype=torch.float64)
         dist.all_reduce(ex_t, op=dist.ReduceOp.MAX)
@@ -342,13 +346,15 @@ def main():
             x3 = rec["dtype"] in ("fp32x3", "fp16x2")
             peak = PEAK_F32_TFLOPS if rec["dtype"] == "fp32" else PEAK_F16_TFLOPS
             ach = flops_G / rec["conv_ms_per_step"]  # GFLOP / ms = TFLOP/s per GPU; fp32x3: fp32-EQUIVALENT flops
-            traffic, src = None, None  # HBM bytes of the same launches: separate rocprofv3 --pmc passes (profiles/), static
+            traffic, src, whole_bytes = None, None, 0  # HBM bytes of the same launches: separate rocprofv3 --pmc passes (profiles/), static
             if rec["dtype"] == "fp16" and n == 64:
-                for rnd in (PROFILE_ROUND, "r02", "r01"):
+                for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
                     path = os.path.join(ROOT, "profiles", rnd, "pmc_conv_traffic.json")
                     if os.path.exists(path):
                         with open(path) as f:
-                            traffic = json.load(f)["hbm_bytes_per_step"]
+                            pj = json.load(f)
+                        traffic = pj["hbm_bytes_per_step"]
+                        whole_bytes = pj.get("whole_step_fetch_bytes", 0) + pj.get("whole_step_write_bytes", 0)
                         src = "profiles/%s/pmc_conv_traffic.json (static: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of " \
                               "this workload, not measured in this run)" % rnd
                         break
@@ -359,6 +365,9 @@ def main():
                  "conv_ms_per_step": round(rec["conv_ms_per_step"], 3), "eager_profiled_ms_per_step": rec["eager_profiled_ms_per_step"],
                  "flops_per_step_G": round(flops_G, 1),
                  "whole_step_frac": round((3.0 if x3 else 1.0) * flops_G / ms_per_step / peak, 4)}
+            if whole_bytes:  # every kernel of the step (same PMC passes): bytes, and that traffic over this run's step time vs 8 TB/s
+                r["whole_step_traffic"] = whole_bytes
+                r["whole_step_hbm_frac"] = round(whole_bytes / (ms_per_step * 1e-3) / PEAK_HBM_BYTES_PER_S, 4)
             if x3:
                 r["note"] = ("fp16x2 / fp32x3 execute three v_mfma_f32_32x32x16_f16 (bf16) per fp32-class product: `achieved` counts the "
                              "reference's fp32 FLOPs once, `frac` = 3 x achieved / 2.5 PF is the matrix pipe's utilisation; the "
@@ -382,6 +391,7 @@ def main():
                           "region_ms_per_step": main_rec["region_ms_per_step"],
                           "rank_min_ms_per_step": main_rec["rank_min_ms_per_step"],
                           "comm_exposed_ms": main_rec["comm_exposed_ms"],
+                          "bucket_timeline_ms": main_rec.get("bucket_timeline_ms"),
                           "loss_first": main_rec["loss_first"], "loss_last": main_rec["loss_last"],
                           "gflop_per_image": GFLOP_PER_IMAGE_TRAIN, "gflop_per_image_executed": GFLOP_PER_IMAGE_EXECUTED},
                "roofline": roofline(main_rec, ms_per_step)}

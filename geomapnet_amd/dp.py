@@ -28,12 +28,26 @@ def world_size():
 # Measurement hook (bench.py): with profiling on, every staged step brackets its wait for the gradient all-reduces with two
 # timed events on the compute stream.  Their distance is the EXPOSED communication time of the step: how long the optimiser
 # was held back by collectives that backward did not hide (0 when every bucket had landed before the last stage ended).
-_profile = {"on": False, "pairs": []}
+# It also records a per-bucket timeline (bucket_timeline_ms): when each backward stage had finished on the compute stream
+# (= the moment its bucket's all-reduce could start) and when the compute stream got past the wait for that bucket, both
+# relative to the start of the backward pass -- a bucket whose `passed` is later than the last stage's `ready` was exposed.
+_profile = {"on": False, "pairs": [], "timelines": []}
 
 
 def set_profiling(on):
     _profile["on"] = bool(on)
     _profile["pairs"] = []
+    _profile["timelines"] = []
+
+
+def bucket_timeline_ms():
+    """-> per profiled step {stage: (ready_ms, passed_ms)} relative to the start of the backward pass; synchronises"""
+    out = []
+    for t0, ready, passed in _profile["timelines"]:
+        passed[-1][1].synchronize()
+        out.append({st: (round(t0.elapsed_time(ev), 3), round(t0.elapsed_time(dict(passed)[st]), 3)) for st, ev in ready})
+    _profile["timelines"] = []
+    return out
 
 
 def exposed_comm_ms():
@@ -75,23 +89,37 @@ def _staged_step(engine, plan, images, targets, lib, h, s):
     grads = engine.grads()
     works = []
     multi = world_size() > 1 or (dist.is_available() and dist.is_initialized())
+    timed = _profile["on"] and s is not None
+    if timed:
+        t0 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        ready, passed = [], []
     for stage in (3, 2, 1, 0):
         lib.check(lib.train_backward_stage(h, stage, s))
+        if timed:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ready.append((stage, e))
         off, cnt = C.c_int64(), C.c_int64()
         lib.check(lib.grad_bucket(h, stage, C.byref(off), C.byref(cnt)))
         bucket = grads[off.value: off.value + cnt.value]
         # async: RCCL runs on its own stream, ordered after the kernels enqueued so far
         if multi:
             works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
-    timed = _profile["on"] and s is not None
     if timed:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    for w in works:
+    for i, w in enumerate(works):
         w.wait()  # stream-level wait on CUDA/HIP; blocking on gloo
+        if timed:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            passed.append((ready[i][0], e))
     if timed:
         ev[1].record()
         _profile["pairs"].append(ev)
+        if passed:
+            _profile["timelines"].append((t0, ready, passed))
     lib.check(lib.optim_step(h, 1.0 / world_size(), s))
     engine._stepped(plan)
     # reported loss = mean of the rank losses (one scalar all-reduce)

@@ -17,7 +17,8 @@ What is executed unmodified:
     PoseGraphFC, optimize_poses) and :1146-1169 (`pgo_test_poses1`, the reference's own PGO fixture), exec'd as
     `pgo` with `xrange = range`, `slin = scipy.linalg`, the Python-2 print statement at :799 written as a call,
     and `txq` / `txe` bound to restatements of the transforms3d functions they use (oracle/pgo.py `txq`;
-    `euler2mat` in its default static-xyz convention R = Rz(ak) Ry(aj) Rx(ai); `mat2quat` from geomapnet_amd.data);
+    `euler2mat` in its default static-xyz convention R = Rz(ak) Ry(aj) Rx(ai); `mat2quat` restated below, in this file, from transforms3d's published eigenvector method -- nothing under oracle/ imports
+    the product package);
     `skew` receives its 3x1 argument flattened (numpy >= 1.24 rejects the ragged nest the 2018 numpy accepted).
 `MapNetOnlineCriterion.forward` divides with `/` at :150 (Python-2 integer division); a
 subclass re-evaluates the same source with `//`.

@@ -321,7 +321,18 @@ def test_mapnet_staged_step_fp32_parity_with_rccl(lib, monkeypatch):
                                 device_id=torch.device("cuda", 0))
         started = True
     try:
+        import geomapnet_amd.dp as dp
+        dp.set_profiling(True)
         checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+        # the measurement hooks bench.py --gpus N reports: exposed communication per step and the per-bucket timeline
+        assert len(dp.exposed_comm_ms()) == 2
+        tl = dp.bucket_timeline_ms()
+        assert len(tl) == 2 and sorted(tl[0]) == [0, 1, 2, 3]
+        for st in (3, 2, 1, 0):
+            ready, passed = tl[0][st]
+            assert 0.0 <= ready <= passed
+        assert tl[0][3][0] <= tl[0][2][0] <= tl[0][1][0] <= tl[0][0][0]  # buckets become ready in backward order
+        dp.set_profiling(False)
     finally:
         if started:
             dist.destroy_process_group()

@@ -447,6 +447,19 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
     return gm;
   }
+  // (round-4 A/B, MN_HALO384=1: the 8-wave 384-row tile of 96 x 64 wave tiles -- what the fp16x2 mode uses for layer2 -- on fp16
+  //  tensors, where it fills the chip's rounds as well as the 288-row tile does)
+  static const int bm384 = getenv("MN_HALO384") ? atoi(getenv("MN_HALO384")) : 0;
+  if (level >= 2 && bm384 > 0 && igemm_halo_applies(g, ep, 128, 480, 384)) {
+    const long t384 = (long)cdiv(g.M, 384) * (g.N / 128), t288 = (long)gm * (g.N / 128);
+    const int cus = device_cus();
+    const double e384 = (double)t384 / ((double)cdiv(t384, cus) * cus), e288 = (double)t288 / ((double)cdiv(t288, cus) * cus);
+    if (bm384 == 2 || e384 >= e288 - 0.03) {
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 480, 0, 1, false, 4, 2>), dim3(cdiv(g.M, 384) * (g.N / 128)), dim3(512), 0, stream, g, A,
+                         Bw, ep, g.N / 128, rd);
+      return cdiv(g.M, 384);
+    }
+  }
   if (level >= 2 && igemm_halo_applies(g, ep, 128, 384)) {
 #ifdef MN_ABLATION_BUILD
     MN_HALO_ABL(128, 384, 1) MN_HALO_ABL(128, 384, 2) MN_HALO_ABL(128, 384, 3) MN_HALO_ABL(128, 384, 4)

@@ -447,9 +447,10 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
     return gm;
   }
-  // (round-4 A/B, MN_HALO384=1: the 8-wave 384-row tile of 96 x 64 wave tiles -- what the fp16x2 mode uses for layer2 -- on fp16
-  //  tensors, where it fills the chip's rounds as well as the 288-row tile does)
-  static const int bm384 = getenv("MN_HALO384") ? atoi(getenv("MN_HALO384")) : 0;
+  // the 8-wave 384-row tile of 96 x 64 wave tiles where it fills the chip's rounds as well as the 288-row tile does (layer2 at 192
+  // images: 688 tiles = 2.69 rounds against 918 = 3.59): 0.55 instead of 0.89 fragment reads per MFMA; layer2 forward 99.3 -> 92.7
+  // us, data gradient 97.2 -> 90.5, whole step 13.95 -> 13.79 ms (round 4, profiles/r04/c28_*).  MN_HALO384: 0 never, 2 always.
+  static const int bm384 = getenv("MN_HALO384") ? atoi(getenv("MN_HALO384")) : 1;
   if (level >= 2 && bm384 > 0 && igemm_halo_applies(g, ep, 128, 480, 384)) {
     const long t384 = (long)cdiv(g.M, 384) * (g.N / 128), t288 = (long)gm * (g.N / 128);
     const int cus = device_cus();

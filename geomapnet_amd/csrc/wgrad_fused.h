@@ -872,6 +872,10 @@ inline bool wgrad_fused_h2_applies(const WgradArgs& a) {
 
 inline void wgrad_fused_reduce(const WgradFusedArgs& a, hipStream_t stream) {
   if (!a.ws) return;
+#ifdef MN_ABLATION_BUILD
+  static const bool skip = getenv("MN_WGF_SKIP_REDUCE") != nullptr;  // timing experiment: what the reduce launches cost a step
+  if (skip) return;
+#endif
   const int K9 = 9 * a.C;
   const long quads = (long)a.N * K9 / 4;
   // enough threads to pull the slabs at full bandwidth: split the chunk range over blockIdx.y while columns are few

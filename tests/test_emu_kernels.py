@@ -201,8 +201,10 @@ def test_experimental_chunk_resident_a_kernel():
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1")  # the 256-column shape (layer3)
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
-    env = dict(os.environ, MN_IGEMM_HALO="2")                        # the 128-column shape (layers 2 and 4)
+    env = dict(os.environ, MN_IGEMM_HALO="2", MN_HALO384="0")        # the 128-column shape (layers 2 and 4), 288-row tiles
     env.pop("MN_IGEMM_CONFIG", None)
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
+    env["MN_HALO384"] = "2"                                          # ... and the 8-wave 384-row tile (layer2)
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
 
 

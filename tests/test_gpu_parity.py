@@ -527,9 +527,10 @@ def test_chunk_resident_a_kernel_race_screen():
     """igemm_halo.h (the default for the 3x3 stride-1 convolutions of layers 2-4) against torch fp64, plus layer2-4
     geometries repeated, in a process of its own: both tile shapes"""
     _run_forced(dict(os.environ, MN_IGEMM_CONFIG="12", MN_IGEMM_HALO="1"), True)  # the 256-column shape (layer3)
-    env = dict(os.environ, MN_IGEMM_HALO="2")                                     # the 128-column shape (layers 2 and 4)
+    env = dict(os.environ, MN_IGEMM_HALO="2", MN_HALO384="0")                      # the 128-column shape (layers 2 and 4), 288 rows
     env.pop("MN_IGEMM_CONFIG", None)
     _run_forced(env, True)
+    _run_forced(dict(env, MN_HALO384="2"), True)                                  # ... and its 8-wave 384-row form (layer2)
 
 
 def test_chunk_resident_a_kernel_h2_race_screen():

@@ -753,7 +753,7 @@ def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps
 
 
 def check_dropout(lib, dev, dtype_name="fp32", N=2, H=64, W=85, p_drop=0.5, seed=1234, loss_rtol=1e-4, pose_atol=1e-3,
-                  grad_l2_rtol=2e-2):
+                  grad_l2_rtol=2e-2, wiring=True):
     """F.dropout(x, p) between the feature ReLU and the pose heads (models/posenet.py:68-69) on the device: one MapNet training
     step with PoseNet(droprate=0.5, dropout_active=True) against the oracle applying THE SAME mask (read back from the device);
     the mask itself (values, keep rate, a fresh draw per step, reproducible from the seed); eval() does not drop"""
@@ -809,6 +809,9 @@ def check_dropout(lib, dev, dtype_name="fp32", N=2, H=64, W=85, p_drop=0.5, seed
         if r.norm() > 1e-8:
             worst = max(worst, ((g - r).norm() / r.norm()).item())
     assert worst <= grad_l2_rtol, worst
+    res = {"loss": l, "loss_oracle": lo, "dropped_fraction": frac, "grad_worst": worst}
+    if not wiring:  # (the emulator suite stops here: what follows re-runs the step to test host-side wiring)
+        return res
     # a second training step draws a different mask; a model built from the same seed draws the same first mask
     G.step_feedfwd(x.to(dev), net, dev != "cpu", t.to(dev), c, opt, True, 0.0)
     mask2 = eng.dropout_mask(plan).cpu()
@@ -831,7 +834,7 @@ def check_dropout(lib, dev, dtype_name="fp32", N=2, H=64, W=85, p_drop=0.5, seed
         ref = onet2(x)
     out = net_c(x.to(dev))
     assert (out.cpu() - ref).abs().max().item() <= pose_atol * max(1.0, ref.abs().max().item())
-    return {"loss": l, "loss_oracle": lo, "dropped_fraction": frac, "grad_worst": worst}
+    return res
 
 
 def check_eval_forward(lib, dev, dtype_name, B=3, H=64, W=85, atol=1e-3):

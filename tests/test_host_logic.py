@@ -195,7 +195,9 @@ def test_shipped_k_loops_have_no_scratch_access_and_asm_reads_skip_the_dma_wait(
                            r"wgrad_dma_kernelILi\d+ELi\d+ELi32ELi\dELb1ELb1E|"
                            r"igemm_halo_kernelILi\d+ELi\d+ELi0ELi1E")  # igemm_halo_kernel<BN, kAH, ABL = 0, DP = 1, H2, WM, WN, A1>:
     # two fp16 shapes + the four h2 shapes of the fp16x2 mode (256 columns, 128 columns at 288 / 384 rows, layer1's 64 columns)
-    assert len(hot) == 13, sorted(hot)
+    # (igemm.h: 3, wgrad_dma: 4, igemm_halo: the fp16 shapes 256 / 128 x 288 / 128 x 384 + the four h2 shapes; every shape that
+    # is added joins the audit below by matching the pattern)
+    assert len(hot) >= 14, sorted(hot)
     for name, (_, _, sig) in hot.items():
         assert "S!" not in sig, (name, sig)
     asm = {n: s for n, (_, _, s) in hot.items() if "wgrad_dma" in n and n.split("ELb1ELb")[1].startswith("1")}

@@ -432,6 +432,7 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
 #endif
+  static const int a1 = getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1;
   if (level >= 1 && tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) {
 #ifdef MN_ABLATION_BUILD
 #define MN_HALO_ABL(BN_, AH_, V_)                                                                                          \
@@ -446,6 +447,19 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
 #endif
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
     return gm;
+  }
+  // 192-row tiles of 4 waves (2 x 2 of 96 x 64) with ONE A image (the next chunk's image requested after the chunk's last K-step):
+  // 70 KB of LDS, so two workgroups share a CU and each one's prologue / image reload / epilogue runs under the other's MFMAs --
+  // for the 128-column layers with at least two rounds of such tiles (layer2 at 192 images: 1376 tiles).  Round 4, same-box A/B
+  // against the 8-wave 384-row tile below: fp16 forward 90.8 -> 90.1 us, data gradient 87.5 -> 84.2, with residual 110.9 -> 105.8,
+  // step 13.22 -> 13.16 ms; fp16x2 224 -> 202, 218 -> 199, 282 -> 250 us, step 28.82 -> 28.55 ms (profiles/r04/c30_*).
+  // For layers 3 and 4 (704 / 352 such tiles: 1.4 / 0.7 rounds) it loses to their one-round shapes: fp16 76 -> 85 and 81 -> 88 us,
+  // fp16x2 191 -> 207 and 223 -> 234 us (call 31).  MN_HALO_A1: 0 off, 2 always (parity tests)
+  if (level >= 2 && a1 > 0 && (a1 == 2 || (long)cdiv(g.M, 192) * (g.N / 128) >= 2L * device_cus()) &&
+      igemm_halo_applies(g, ep, 128, 288, 192)) {
+    hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, false, 2, 2, true>), dim3(cdiv(g.M, 192) * (g.N / 128)), dim3(256), 0, stream, g,
+                       A, Bw, ep, g.N / 128, rd);
+    return cdiv(g.M, 192);
   }
   // the 8-wave 384-row tile of 96 x 64 wave tiles where it fills the chip's rounds as well as the 288-row tile does (layer2 at 192
   // images: 688 tiles = 2.69 rounds against 918 = 3.59): 0.55 instead of 0.89 fragment reads per MFMA; layer2 forward 99.3 -> 92.7
@@ -490,6 +504,7 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   rd.p = make_fastdiv(g2.P);
   const long tiles288 = (long)gm * (g2.N / 256);
   static const bool force256 = getenv("MN_H2_HALO256") && atoi(getenv("MN_H2_HALO256")) != 0;  // (parity tests on small problems)
+  static const int a1 = getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1;  // (see launch_igemm_halo)
   if (g2.N % 256 == 0 && ((tiles288 > 192 && tiles288 <= device_cus()) || force256) && igemm_halo_applies(g2, ep, 256, 352)) {
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 256, rd);
@@ -502,6 +517,13 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   if (halo64 && g2.N == 64 && igemm_halo_applies(g2, ep, 64, 368, 192)) {
     hipLaunchKernelGGL((igemm_halo_kernel<64, 368, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192)), dim3(256), 0, stream, g2, A, Bw, ep, 1,
                        rd);
+    return cdiv(g2.M, 192);
+  }
+  // layer1's two-workgroup shape for the 128-column layers with at least two rounds of 192-row tiles (layer2): see launch_igemm_halo
+  if (a1 > 0 && g2.N % 128 == 0 && (a1 == 2 || (long)cdiv(g2.M, 192) * (g2.N / 128) >= 2L * device_cus()) &&
+      igemm_halo_applies(g2, ep, 128, 288, 192)) {
+    hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192) * (g2.N / 128)), dim3(256), 0, stream,
+                       g2, A, Bw, ep, g2.N / 128, rd);
     return cdiv(g2.M, 192);
   }
   // 128-column layers: the 8-wave 384-row tile where it fills the chip's rounds about as well as the 288-row tile does (layer2 at

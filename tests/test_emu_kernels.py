@@ -204,7 +204,9 @@ def test_experimental_chunk_resident_a_kernel():
     env = dict(os.environ, MN_IGEMM_HALO="2", MN_HALO384="0")        # the 128-column shape (layers 2 and 4), 288-row tiles
     env.pop("MN_IGEMM_CONFIG", None)
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
-    env["MN_HALO384"] = "2"                                          # ... and the 8-wave 384-row tile (layer2)
+    env["MN_HALO384"] = "2"                                          # ... and the 8-wave 384-row tile
+    subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
+    env["MN_HALO_A1"] = "2"                                          # ... and layer2's two-workgroup single-image shape
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=900)
 
 
@@ -216,5 +218,8 @@ def test_chunk_resident_a_kernel_h2(force256):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256=force256)
+    env = dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256=force256, MN_HALO_A1="0")
     subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=env, timeout=1500)
+    if force256 == "0":  # the 128-column launches again through layer2's two-workgroup single-image shape
+        subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=dict(env, MN_HALO_A1="2"),
+                       timeout=1500)

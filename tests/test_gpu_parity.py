@@ -530,13 +530,15 @@ def test_chunk_resident_a_kernel_race_screen():
     env = dict(os.environ, MN_IGEMM_HALO="2", MN_HALO384="0")                      # the 128-column shape (layers 2 and 4), 288 rows
     env.pop("MN_IGEMM_CONFIG", None)
     _run_forced(env, True)
-    _run_forced(dict(env, MN_HALO384="2"), True)                                  # ... and its 8-wave 384-row form (layer2)
+    _run_forced(dict(env, MN_HALO384="2"), True)                                  # ... its 8-wave 384-row form
+    _run_forced(dict(env, MN_HALO_A1="2"), True)                                  # ... and layer2's two-workgroup single-image shape
 
 
 def test_chunk_resident_a_kernel_h2_race_screen():
     """igemm_halo.h with h2 operands (the 3x3 stride-1 convolutions of layers 2-4 in the fp16x2 mode): both tile shapes against
     torch fp64, layer geometries repeated"""
-    _run_forced(dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256="0"), True)
+    _run_forced(dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256="0", MN_HALO_A1="0"), True)
+    _run_forced(dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256="0", MN_HALO_A1="2"), True)
     _run_forced(dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256="1"), True)
 
 

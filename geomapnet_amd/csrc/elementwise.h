@@ -392,6 +392,72 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
   }
 }
 
+// The same sums when the gradient is the max-pool's input gradient (stem, fp32 tensors), walked in the order of the POOLED WINDOWS
+// (round 4; stem_bwd.h does this for fp16 tensors through LDS tiles): a window's gradient goes to exactly one pixel, its recorded
+// argmax, so  sum(gm) = sum over windows of gp * gate(y at the argmax)  and  sum(gm * xhat)  likewise -- one 4-byte load of y per
+// (window, channel) over a quarter of the elements, instead of four windows' argmax bytes compared per conv-output element
+// (bn_bwd_reduce_kernel<float, true>: 616 us at 192 images, VALU-bound on pool_grad_piece).
+static __global__ void __launch_bounds__(256) bn_bwd_reduce_pool_windows_kernel(const float* __restrict__ gp,
+                                                                                const unsigned char* __restrict__ idx,
+                                                                                const float* __restrict__ y,
+                                                                                const float* __restrict__ mean,
+                                                                                const float* __restrict__ invstd,
+                                                                                const float* __restrict__ sg_gamma,
+                                                                                const float* __restrict__ sg_beta, int B, int H,
+                                                                                int W, int Po, int Qo, int C, double* __restrict__ accum,
+                                                                                int rows_per_block, int accum_rows) {
+  constexpr int VEC = 4;
+  __shared__ float red[2][256][VEC];
+  const int cpr = C / VEC, rlanes = 256 / cpr;
+  const int cp = threadIdx.x % cpr, rl = threadIdx.x / cpr, c0 = cp * VEC;
+  float mu[VEC], is[VEC], sc[VEC], sh[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    mu[e] = mean[c0 + e];
+    is[e] = invstd[c0 + e];
+    sc[e] = sg_gamma[c0 + e] * is[e];
+    sh[e] = sg_beta[c0 + e] - mu[e] * sc[e];
+    s1[e] = s2[e] = 0.f;
+  }
+  const long nwin = (long)B * Po * Qo;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < nwin ? r0 + rows_per_block : nwin;
+  for (long r = r0 + rl; r < r1; r += rlanes) {
+    PieceView<float> g;
+    g.p = reinterpret_cast<const piece_t*>(gp)[r * cpr + cp];
+    const unsigned taps = reinterpret_cast<const unsigned*>(idx)[r * cpr + cp];
+    const int qo = (int)(r % Qo);
+    const long t2 = r / Qo;
+    const int po = (int)(t2 % Po), b = (int)(t2 / Po);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int tap = (int)((taps >> (8 * e)) & 0xffu);
+      const int h = po * 2 - 1 + tap / 3, w = qo * 2 - 1 + tap % 3;  // inside the image: the forward pass only records valid taps
+      const float yv = y[((long)(b * H + h) * W + w) * C + c0 + e];
+      const float gv = (yv * sc[e] + sh[e] > 0.f) ? g.e[e] : 0.f;    // the stem's own ReLU, recomputed
+      s1[e] += gv;
+      s2[e] += gv * (yv - mu[e]) * is[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[0][threadIdx.x][e] = s1[e];
+    red[1][threadIdx.x][e] = s2[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    const int p = i / VEC, e = i % VEC;
+    double a = 0, bsum = 0;
+    for (int l = 0; l < rlanes; ++l) {
+      a += red[0][l * cpr + p][e];
+      bsum += red[1][l * cpr + p][e];
+    }
+    double* row = accum + (long)((int)blockIdx.x % accum_rows) * 2 * C;
+    atomicAdd(row + i, a);
+    atomicAdd(row + C + i, bsum);
+  }
+}
+
 // finalize (one small launch between reduce and apply): coef[0][c] = k1 = gamma*invstd, coef[1][c] = mg = sum(gm)/M,
 // coef[2][c] = mgx = sum(gm*xhat)/M, coef[3][c] = shift of the self-gate (only with sg_beta), from the fp64 accumulator
 // rows; adds dgamma / dbeta (times grad_unscale = 1/loss_scale) into the gradient arena.
@@ -553,6 +619,15 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   // (4 rows per thread per iteration in flight; 8 measured equal: 15.07 vs 14.99 ms per step)
   // rows in flight per thread: 2 for fp16 tensors (111 instead of 122 registers: one more wave fits beside the side stream's
   // weight gradient; 14.01 -> 13.89 ms per step), 4 for fp32 tensors (2: 30.74 -> 30.88 ms in the fp16x2 mode); profiles/r04/c11_*
+  static const bool pool_windows = !(getenv("MN_POOL_WINDOWS") && atoi(getenv("MN_POOL_WINDOWS")) == 0);
+  if (pg.idx && sizeof(T) == 4 && self_gate_beta && pool_windows) {  // the stem on fp32 tensors: sums in pooled-window order
+    const long nwin = (long)(M / ((long)pg.H * pg.W)) * pg.Po * pg.Qo;
+    long wrows = (nwin + target - 1) / target;
+    wrows = ((wrows + rlanes - 1) / rlanes) * rlanes;
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_windows_kernel, dim3(cdiv(nwin, wrows)), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(pg.gout), pg.idx, reinterpret_cast<const float*>(y), mean, invstd, sg_gamma,
+                       self_gate_beta, (int)(M / ((long)pg.H * pg.W)), pg.H, pg.W, pg.Po, pg.Qo, C, accum, (int)wrows, accum_rows);
+  } else {
   static const int reduce_u = getenv("MN_BN_REDUCE_U") ? atoi(getenv("MN_BN_REDUCE_U")) : (sizeof(T) == 2 ? 2 : 4);
   // (s_setprio 3 in the backward kernels, so that their waves are not starved by the weight gradient's MFMA waves on the same
   //  SIMD: no effect, 13.95 vs 14.00 ms fp16, 30.36 vs 30.38 ms fp16x2, profiles/r04/c12_*; removed)
@@ -565,6 +640,7 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   else
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
+  }
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)accum, (double)M, gamma, mean,
                      invstd, dgamma, dbeta, grad_unscale, self_gate_beta, coef, C, accum_rows);
   if (!apply) return;

@@ -812,6 +812,8 @@ inline void launch_wgrad(WgradArgs a, int target_blocks, hipStream_t stream, con
   bool narrow_k = g.K <= 64 || (g.K % 128 != 0 && g.K < 256);
   // the stem's weight gradient on fp32 tensors (K = 224 columns): two 128-column tiles read the 1 GB d(conv output) twice,
   // four 64-column tiles four times
+  // (ONE 256-column tile, d(conv output) read once: 29.55 vs 29.57 ms per step -- the launch runs on the side stream, which is not
+  //  the critical path; measured and not kept, round 4 call 33)
   if (stem_wide && sizeof(T) == 4 && g.mma == MMA_BF16X3 && g.K > 128) narrow_k = false;
   const bool narrow_n = g.N <= 64;
   int bmo = narrow_n ? 64 : 128, bno = narrow_k ? 64 : 128;

@@ -461,6 +461,8 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
                        A, Bw, ep, g.N / 128, rd);
     return cdiv(g.M, 192);
   }
+  // (layer1 in fp16 on this shape with 64 columns, measured and removed: 132.5 us forward / 134.8 data gradient against 112.8 / 111.1
+  //  for halo_pp.h's persistent kernel with resident weights; whole step 13.32 -> 13.63 ms, profiles/r04/c34_*)
   // the 8-wave 384-row tile of 96 x 64 wave tiles where it fills the chip's rounds as well as the 288-row tile does (layer2 at 192
   // images: 688 tiles = 2.69 rounds against 918 = 3.59): 0.55 instead of 0.89 fragment reads per MFMA; layer2 forward 99.3 -> 92.7
   // us, data gradient 97.2 -> 90.5, whole step 13.95 -> 13.79 ms (round 4, profiles/r04/c28_*).  MN_HALO384: 0 never, 2 always.

@@ -79,6 +79,9 @@ _PROTOS = {
                                c_void, c_void]),
     "mn_op_stem_conv": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),
     "mn_op_stem_conv_x3": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),
+    "mn_op_dense": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_void]),
+    "mn_op_dense_wgrad": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, c_f, c_void]),
+    "mn_op_head_wgrad": (c_i, [c_void, c_void, c_void, c_void, c_void, c_void, c_i, c_i, c_f, c_i, c_void]),
     "mn_op_stem_bwd": (c_i, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_i, c_void, c_void, c_void,
                              c_void, c_void, c_i, c_i, c_i, c_i, c_f, c_void]),
     "mn_op_oihw_to_ohwi": (c_i, [c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),

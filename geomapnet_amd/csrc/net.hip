@@ -15,6 +15,7 @@
 #include "elementwise.h"
 #include "elementwise_h2.h"
 #include "head.h"
+#include "dense.h"
 #include "igemm.h"
 #include "dgrad.h"
 #include "halo_pp.h"
@@ -663,6 +664,8 @@ struct Plan : PlanBase {
   // persistent two-group kernel of halo_pp.h (MN_HALO=0: the implicit-GEMM kernel, for A/B measurements)
   bool use_halo = DT == MN_F16 && !(getenv("MN_HALO") && atoi(getenv("MN_HALO")) == 0);
   bool use_stem_kernel = !(getenv("MN_STEM_KERNEL") && atoi(getenv("MN_STEM_KERNEL")) == 0);
+  // MN_DENSE=0: the head's fc layer through igemm.h's 128 x 128 tiles (parity tests, A/B)
+  bool use_dense = !(getenv("MN_DENSE") && atoi(getenv("MN_DENSE")) == 0);
   bool halo_path(const GatherGeom& g) const { return use_halo && conv_halo_applies(g); }
   void bn_finalize(Unit& u, hipStream_t s) {  // statistics -> (scale, shift), mean / invstd, running statistics
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(u.cp.cout, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)u.accum_f, (double)u.M,
@@ -752,7 +755,13 @@ struct Plan : PlanBase {
     Epilogue ep;
     ep.out = feat; ep.ldc = F; ep.stats = nullptr; ep.bias = params + L.fc_b; ep.relu = 1; ep.res = nullptr;
     ep.res_gate = nullptr; ep.alpha = 1.f;
-    launch_igemm<float>(g, (const float*)pooled, (const float*)(params + L.fc_w), ep, s, (const float*)zero_page);
+    DenseArgs da;
+    da.A = pooled; da.W = params + L.fc_w; da.bias = params + L.fc_b; da.C = feat; da.M = B; da.N = F; da.K = 512; da.lda = 512;
+    da.ldw = 512; da.ldc = F; da.relu = 1;
+    if (use_dense && dense_nt_applies(da))  // 32 x 32 tiles, K split over the workgroup's waves (dense.h)
+      launch_dense_nt(da, s);
+    else
+      launch_igemm<float>(g, (const float*)pooled, (const float*)(params + L.fc_w), ep, s, (const float*)zero_page);
     // F.dropout(x, p=droprate) (models/posenet.py:68-69), in training mode only (mn_set_dropout explains the reference's two
     // readings): a fresh Philox mask per training forward pass, kept for the backward pass
     drop_this_step = training && drop_p > 0.f;
@@ -911,24 +920,29 @@ struct Plan : PlanBase {
     hipLaunchKernelGGL(head_bwd_input_kernel, dim3(cdiv((long)B * F, 256)), dim3(256), 0, s, (const float*)dposes,
                        (const float*)feat, (const float*)(params + L.xyz_w), (const float*)(params + L.wpqr_w), dz, B, F,
                        cfg.filter_nans, drop_this_step ? (const float*)dropmask : (const float*)nullptr);
-    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(cdiv(6L * (F + 1), 256)), dim3(256), 0, s, (const float*)dposes,
+    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(cdiv(F + 1, 64)), dim3(256), 0, s, (const float*)dposes,
                        (const float*)feat, grads + L.xyz_w, grads + L.xyz_b, grads + L.wpqr_w, grads + L.wpqr_b, B, F,
                        unscale, cfg.filter_nans);
-    // fc backward
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(F, 256)), dim3(256), 0, s, (const float*)dz, grads + L.fc_b, B, F, unscale);
+    // fc backward: weight + bias gradient in one launch of 32 x 32 tiles (dense.h), data gradient against the transposed copy
+    DenseWgradArgs dw;
+    dw.dY = dz; dw.X = pooled; dw.dW = grads + L.fc_w; dw.db = grads + L.fc_b; dw.B = B; dw.F = F; dw.Cin = 512; dw.ldy = F;
+    dw.ldx = 512; dw.ldw = 512; dw.alpha = unscale;
+    launch_dense_wgrad(dw, s);
     GatherGeom g;
     g.B = B; g.Hi = 1; g.Wi = 1; g.C = 512; g.P = 1; g.Q = 1; g.R = 1; g.S = 1; g.mul_p = 1; g.mul_q = 1; g.rsign = 1;
     g.ssign = 1; g.off_h = 0; g.off_w = 0; g.div = 1; g.M = B; g.N = F; g.K = 512;
-    WgradArgs a;
-    a.g = g; a.dY = dz; a.ldy = F; a.X = pooled; a.dW = grads + L.fc_w; a.ldw = 512; a.colmap = nullptr; a.alpha = unscale;
-    a.rows_per_split = 0;
-    launch_wgrad<float>(a, 1, s);
     GatherGeom gd = g;
     gd.C = F; gd.N = 512; gd.K = F;
     Epilogue ep;
     ep.out = dpooled; ep.ldc = 512; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = nullptr;
     ep.res_gate = nullptr; ep.alpha = 1.f;
-    launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s, (const float*)zero_page);
+    DenseArgs dd;
+    dd.A = dz; dd.W = fcT; dd.bias = nullptr; dd.C = dpooled; dd.M = B; dd.N = 512; dd.K = F; dd.lda = F; dd.ldw = F; dd.ldc = 512;
+    dd.relu = 0;
+    if (use_dense && dense_nt_applies(dd))
+      launch_dense_nt(dd, s);
+    else
+      launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s, (const float*)zero_page);
     Block& last = blocks.back();
     if (h2)
       hipLaunchKernelGGL(avgpool_bwd_h2_kernel, dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s, (const float*)dpooled,
@@ -1060,7 +1074,7 @@ struct Plan : PlanBase {
   int optim_step(float grad_mul, hipStream_t s) override {
     // squared gradient norm: for clip_grad_norm, and (fp16) as the overflow detector of this step
     if (max_grad_norm > 0.f || overflow_guard) {
-      const int nb = ew_grid(L.model_floats);
+      const int nb = sqnorm_grid(L.model_floats);
       if (deterministic && nb <= kSqPartials) {
         hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(nb), dim3(256), 0, s, (const float*)grads, (long)L.model_floats, sqnorm,
                            sq_partials);

@@ -7,6 +7,7 @@
 #include "criterion.h"
 #include "elementwise.h"
 #include "head.h"
+#include "dense.h"
 #include "igemm.h"
 #include "dgrad.h"
 #include "halo_pp.h"
@@ -148,6 +149,34 @@ extern "C" int mn_op_stem_conv_x3(const float* xpad, const float* wf, float* y, 
   return check_launch("stem_conv_x3");
 }
 
+extern "C" int mn_op_dense(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int relu, void* stream) {
+  begin_call();
+  DenseArgs a;
+  a.A = A; a.W = W; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N; a.relu = relu;
+  if (M <= 0 || N <= 0 || !dense_nt_applies(a)) return fail("dense: K must be a multiple of 128, A and W 16-byte aligned");
+  launch_dense_nt(a, (hipStream_t)stream);
+  return check_launch("dense");
+}
+
+extern "C" int mn_op_dense_wgrad(const float* dY, const float* X, float* dW, float* db, int B, int F, int Cin, float alpha,
+                                 void* stream) {
+  begin_call();
+  if (B <= 0 || F <= 0 || Cin <= 0) return fail("dense_wgrad: empty problem");
+  DenseWgradArgs a;
+  a.dY = dY; a.X = X; a.dW = dW; a.db = db; a.B = B; a.F = F; a.Cin = Cin; a.ldy = F; a.ldx = Cin; a.ldw = Cin; a.alpha = alpha;
+  launch_dense_wgrad(a, (hipStream_t)stream);
+  return check_launch("dense_wgrad");
+}
+
+extern "C" int mn_op_head_wgrad(const float* dposes, const float* feat, float* dWx, float* dbx, float* dWq, float* dbq, int B, int K,
+                                float scale, int filter_nans, void* stream) {
+  begin_call();
+  if (B <= 0 || K <= 0) return fail("head_wgrad: empty problem");
+  hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(cdiv(K + 1, 64)), dim3(256), 0, (hipStream_t)stream, dposes, feat, dWx, dbx, dWq,
+                     dbq, B, K, scale, filter_nans);
+  return check_launch("head_wgrad");
+}
+
 extern "C" int mn_op_stem_bwd(const void* y, const unsigned char* idx, const void* gp, const float* gamma, const float* beta,
                               const float* mean, const float* invstd, const void* xpad, float* dW, int ldw, const int32_t* colmap,
                               float* dgamma, float* dbeta, float* coef_scratch, double* accum_scratch, int B, int H, int W, int Wp,
@@ -259,7 +288,7 @@ extern "C" int mn_op_optim(int method, int nesterov, float* p, const float* g, f
   if (max_norm > 0.f) {
     if (!sqnorm_scratch) return fail("adam: clipping needs a scratch double");
     hipMemsetAsync(sqnorm_scratch, 0, sizeof(double), s);
-    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(ew_grid(n_clip)), dim3(256), 0, s, g, (long)n_clip, sqnorm_scratch, (double*)nullptr);
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(sqnorm_grid(n_clip)), dim3(256), 0, s, g, (long)n_clip, sqnorm_scratch, (double*)nullptr);
   }
   AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.n_clip = n_clip; a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2;

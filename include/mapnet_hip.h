@@ -259,6 +259,17 @@ int mn_op_stem_conv(const void* xpad, const void* wf, void* y, double* stats_acc
  * into fp16 hi + lo halves on the way into LDS / registers, three MFMAs per product, fp32 output */
 int mn_op_stem_conv_x3(const float* xpad, const float* wf, float* y, double* stats_accum, int stats_rows, int B, int H, int W,
                        int Wp, void* stream);
+/* The dense layer of the pose head in fp32 (csrc/dense.h; /root/reference/models/posenet.py:46,65-66: self.feature_extractor.fc and
+ * the ReLU behind it): C[M][N] = act(A[M][K] . W[N][K]^T + bias[N]); K a multiple of 128, bias optional, relu 0 / 1.  With W = the
+ * transposed weight the same call is the layer's data gradient. */
+int mn_op_dense(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int relu, void* stream);
+/* ... its weight and bias gradient: dW[F][Cin] += alpha * dY[B][F]^T . X[B][Cin], db[F] += alpha * column sums of dY (db optional) */
+int mn_op_dense_wgrad(const float* dY, const float* X, float* dW, float* db, int B, int F, int Cin, float alpha, void* stream);
+/* weight and bias gradients of the two pose regressors (posenet.py:48-49,71-73): dWx[3][K] / dbx[3] from dposes[:, 0:3], dWq[3][K] /
+ * dbq[3] from dposes[:, 3:6], all += scale * sum over the B rows; filter_nans zeroes NaN entries of the rotation gradients
+ * (filter_hook, posenet.py:28-34) */
+int mn_op_head_wgrad(const float* dposes, const float* feat, float* dWx, float* dbx, float* dWq, float* dbq, int B, int K, float scale,
+                     int filter_nans, void* stream);
 /* Stem backward (fp16) below maxpool(relu(bn1(conv1(x)))) in two launches (csrc/stem_bwd.h): BatchNorm sums with the
  * max-pool's input gradient gathered on the fly from (idx, gp), then conv1's weight gradient with d(conv output) computed
  * tile by tile in LDS.  y: raw conv output [B][H0][W0][64]; idx / gp: argmax bytes and gradient of the pooled activation

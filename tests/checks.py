@@ -1439,6 +1439,60 @@ def check_loss_trajectory(lib, dev, N=8, H=256, W=341, steps=50, lr=1e-4, envelo
     return curves["fp16"], curves["fp32x3"], gap
 
 
+def check_dense(lib, dev, B, Cin, F, seed=11):
+    """the pose head's dense layer (csrc/dense.h): forward with bias + ReLU, data gradient (the same kernel against the transposed
+    weight), weight + bias gradient (`+=` onto a non-zero start), and the pose regressors' weight gradient with the NaN filter, each
+    against torch in fp64 at fp32 round-off (exact fp32 products, sums in a different order)"""
+    _fresh()
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, generator=gen)
+    w = torch.randn(F, Cin, generator=gen) * 0.05
+    bias = torch.randn(F, generator=gen) * 0.1
+    ref = torch.relu(x.double() @ w.double().t() + bias.double())
+    out = torch.full((B, F), float("nan"), device=dev)
+    lib.check(lib.op_dense(K(x.to(dev)), K(w.to(dev)), K(bias.to(dev)), K(out), B, F, Cin, 1, None))
+    dev_sync(dev)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    dz = torch.randn(B, F, generator=gen)
+    if F % 128 == 0:  # data gradient: dz . W = dz . (W^T)^T
+        wt = w.t().contiguous()
+        gx = torch.full((B, Cin), float("nan"), device=dev)
+        lib.check(lib.op_dense(K(dz.to(dev)), K(wt.to(dev)), None, K(gx), B, Cin, F, 0, None))
+        dev_sync(dev)
+        rgx = dz.double() @ w.double()
+        assert (gx.cpu().double() - rgx).abs().max().item() <= 2e-6 * max(1.0, rgx.abs().max().item())
+    dw0, db0 = torch.randn(F, Cin, generator=gen), torch.randn(F, generator=gen)
+    dw, db = dw0.clone().to(dev), db0.clone().to(dev)
+    alpha = 0.25
+    lib.check(lib.op_dense_wgrad(K(dz.to(dev)), K(x.to(dev)), K(dw), K(db), B, F, Cin, f32(alpha), None))
+    dev_sync(dev)
+    rdw = dw0.double() + alpha * (dz.double().t() @ x.double())
+    rdb = db0.double() + alpha * dz.double().sum(0)
+    assert (dw.cpu().double() - rdw).abs().max().item() <= 2e-6 * max(1.0, rdw.abs().max().item())
+    assert (db.cpu().double() - rdb).abs().max().item() <= 2e-6 * max(1.0, rdb.abs().max().item())
+    # pose regressors: feat [B][F], dposes [B][6], a NaN in the rotation part of one row
+    feat = torch.relu(torch.randn(B, F, generator=gen))
+    dp = torch.randn(B, 6, generator=gen)
+    for filt in (0, 1):
+        dpn = dp.clone()
+        if filt:
+            dpn[B // 2, 4] = float("nan")
+        bufs = [torch.zeros(3, F, device=dev), torch.zeros(3, device=dev), torch.zeros(3, F, device=dev), torch.zeros(3, device=dev)]
+        for t in bufs:
+            t.fill_(0.5)
+        lib.check(lib.op_head_wgrad(K(dpn.to(dev)), K(feat.to(dev)), K(bufs[0]), K(bufs[1]), K(bufs[2]), K(bufs[3]), B, F, f32(alpha),
+                                    filt, None))
+        dev_sync(dev)
+        rx = 0.5 + alpha * (dpn[:, :3].double().t() @ feat.double())
+        rq = 0.5 + alpha * (dpn[:, 3:].double().t() @ feat.double())
+        rbx, rbq = 0.5 + alpha * dpn[:, :3].double().sum(0), 0.5 + alpha * dpn[:, 3:].double().sum(0)
+        if filt:  # filter_hook: NaN entries of the rotation regressor's gradients become 0 before they are accumulated
+            rq = torch.where(torch.isnan(rq), torch.full_like(rq, 0.5), rq)
+            rbq = torch.where(torch.isnan(rbq), torch.full_like(rbq, 0.5), rbq)
+        for got, want in zip(bufs, (rx, rbx, rq, rbq)):
+            assert (got.cpu().double() - want).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item())
+
+
 def check_stem_bwd(lib, dev, B, H, W, seed=5):
     """stem backward in two launches (csrc/stem_bwd.h: BatchNorm sums with the max-pool gradient gathered on the fly, then the
     weight gradient with d(conv output) computed in LDS), two ways: (1) SELF-CONSISTENCY against the four-launch chain of

@@ -110,6 +110,13 @@ def test_stem_conv(lib, dtype, hw):
     checks.check_stem(lib, DEV, dtype, 2, *hw)
 
 
+@pytest.mark.parametrize("shape", [(6, 128, 128), (37, 256, 200), (65, 128, 70), (192, 512, 2048)])
+def test_pose_head_dense_layer(lib, shape):
+    """csrc/dense.h: the head's fc layer forward / data gradient / weight + bias gradient in 32 x 32 tiles and the pose
+    regressors' weight gradient, ragged rows and feature counts, against torch fp64"""
+    checks.check_dense(lib, DEV, *shape)
+
+
 @pytest.mark.parametrize("shape", [(1, 20, 27), (2, 33, 70), (3, 256, 341)])
 def test_stem_backward_two_launch_form(lib, shape):
     """csrc/stem_bwd.h against the maxpool_bwd -> bn_bwd -> wgrad chain it replaces, identical fp16 tensors"""

@@ -608,8 +608,9 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   // ~512 workgroups (2 per CU): the reduction is HBM-bound and needs the whole chip, but every workgroup ends with an LDS
   // reduction and 2 x C fp64 atomics -- at 4096 workgroups (round 1) layers 3-4 did ONE loop iteration per workgroup and
   // that epilogue weighed as much as the loads (same-box A/Bs of the whole step: 4096 workgroups 17.77 ms,
-  // 1024 17.60, 512 17.42, 256 17.97)
-  constexpr long target = 512;
+  // 1024 17.60, 512 17.42, 256 17.97; round 4, MN_BN_REDUCE_WGS: 512 / 768 / 1024 = 13.48 / 13.58 / 13.63 ms in fp16, equal within
+  // 0.1 % on the fp16x2 mode's fp32 tensors, profiles/r04/c36_*)
+  static const long target = getenv("MN_BN_REDUCE_WGS") ? atol(getenv("MN_BN_REDUCE_WGS")) : 512;
   const int rlanes = 256 / (C / VEC);
   long rows = (M + target - 1) / target;
   rows = ((rows + rlanes - 1) / rlanes) * rlanes;

@@ -642,6 +642,13 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   }
+#ifdef MN_ABLATION_BUILD
+  // timing experiment (results wrong): what the finalize launches of the units with at most MN_ABL_SKIP_FINALIZE channels cost a
+  // step -- they run for the first 400 calls (coefficients of the warm-up steps stay in place), then are skipped
+  static const int skip_c = getenv("MN_ABL_SKIP_FINALIZE") ? atoi(getenv("MN_ABL_SKIP_FINALIZE")) : 0;
+  static long calls = 0;
+  if (!(C <= skip_c && ++calls > 400))
+#endif
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)accum, (double)M, gamma, mean,
                      invstd, dgamma, dbeta, grad_unscale, self_gate_beta, coef, C, accum_rows);
   if (!apply) return;

@@ -668,6 +668,11 @@ struct Plan : PlanBase {
   bool use_dense = !(getenv("MN_DENSE") && atoi(getenv("MN_DENSE")) == 0);
   bool halo_path(const GatherGeom& g) const { return use_halo && conv_halo_applies(g); }
   void bn_finalize(Unit& u, hipStream_t s) {  // statistics -> (scale, shift), mean / invstd, running statistics
+#ifdef MN_ABLATION_BUILD
+    static const int skip_c = getenv("MN_ABL_SKIP_FINALIZE") ? atoi(getenv("MN_ABL_SKIP_FINALIZE")) : 0;  // (see launch_bn_bwd)
+    static long calls = 0;
+    if (u.cp.cout <= skip_c && ++calls > 400) return;
+#endif
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(u.cp.cout, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)u.accum_f, (double)u.M,
                        bn_params(u), cur_training, u.coef_f, u.cp.cout, u.rows_f);
   }

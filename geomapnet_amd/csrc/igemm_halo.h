@@ -412,6 +412,9 @@ static __global__ void __launch_bounds__(WM* WN * 64, (A1 ? 2 : 1) * WM* WN / 4)
   }
 }
 
+// (Measured and removed, round 4: static wave priorities -- s_setprio 0 / 1 / 2 for the three waves that share a SIMD (w, w + 4,
+// w + 8), or 0 / 1 / 1 -- in the 8- and 12-wave shapes: layers 2-4 forward / data gradient within +-1 % in fp16 and fp16x2, whole
+// step 13.43 / 13.46 / 13.46 and 13.42 / 13.42 / 13.41 ms; the per-K-step barrier re-aligns the waves.  profiles/r04/c41_*.)
 // the launches the kernels cover: fp16 3x3, stride 1, same size, 64-channel chunks
 inline bool igemm_halo_applies(const GatherGeom& g, const Epilogue& ep, int bn, int ah, int bm = 288) {
   return g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi &&

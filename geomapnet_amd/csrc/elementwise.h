@@ -301,13 +301,32 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const T* __
   }
 }
 
+// N consecutive elements of type TY starting at element index `i * N` (N * sizeof(TY) = 16 or 32 bytes), read as floats
+template <typename TY, int N>
+struct YVec {
+  static constexpr int PIECES = N * (int)sizeof(TY) / 16;
+  static constexpr int PER = 16 / (int)sizeof(TY);
+  PieceView<TY> v[PIECES];
+  __device__ __forceinline__ void load(const TY* __restrict__ base, long i) {
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) v[k].p = reinterpret_cast<const piece_t*>(base)[i * PIECES + k];
+  }
+  __device__ __forceinline__ void load_last(const TY* __restrict__ base, long i) {
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) v[k].p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(base) + i * PIECES + k);
+  }
+  __device__ __forceinline__ float at(int e) const { return (float)v[e / PER].e[e % PER]; }
+};
+
 // ---- BatchNorm backward ---------------------------------------------------------------------------
 // reduce: accum[0][c] += sum gm, accum[1][c] += sum gm * xhat,  gm = g * (gate > 0 if gate)
 // POOL: the gradient is gathered from (argmax, pooled gradient) -- a separate instantiation so that the common form does
 // not carry the gather's registers
-template <typename T, bool POOL = false, int U = 4>
+// TY (round 5, the fp16x2m mode): element type of the conv output y when it differs from the gradient's -- fp16 gradients against
+// the fp32 conv output of the split-operand forward pass (the self gate and xhat then come from the exact forward values)
+template <typename T, bool POOL = false, int U = 4, typename TY = T>
 static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ gate,
-                                                             const T* __restrict__ y, const float* __restrict__ mean,
+                                                             const TY* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long M, int C,
                                                              double* __restrict__ accum, int rows_per_block,
                                                              float* __restrict__ partial,
@@ -335,7 +354,8 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
   const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   // U rows per iteration, all loads issued before the arithmetic (memory-level parallelism)
   for (long r = r0 + rl; r < r1; r += (long)U * rlanes) {
-    PieceView<T> vg[U], vy[U], vm[U];
+    PieceView<T> vg[U], vm[U];
+    YVec<TY, VEC> vy[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long rr = r + (long)u * rlanes;
@@ -353,7 +373,7 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
       } else {
         vg[u].p = in ? reinterpret_cast<const piece_t*>(g)[idx] : zero_piece();
       }
-      vy[u].p = reinterpret_cast<const piece_t*>(y)[idx];
+      vy[u].load(y, idx);
       if (gate) vm[u].p = reinterpret_cast<const piece_t*>(gate)[idx];
     }
 #pragma unroll
@@ -362,9 +382,9 @@ static __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __re
       for (int e = 0; e < VEC; ++e) {
         float gv = (float)vg[u].e[e];
         if (gate && !((float)vm[u].e[e] > 0.f)) gv = 0.f;
-        if (sg_gamma && !((float)vy[u].e[e] * sc[e] + sh[e] > 0.f)) gv = 0.f;
+        if (sg_gamma && !(vy[u].at(e) * sc[e] + sh[e] > 0.f)) gv = 0.f;
         s1[e] += gv;
-        s2[e] += gv * ((float)vy[u].e[e] - mu[e]) * is[e];
+        s2[e] += gv * (vy[u].at(e) - mu[e]) * is[e];
       }
   }
 #pragma unroll
@@ -485,9 +505,9 @@ static __global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const doubl
 }
 
 // apply: gy = k1 * (gm - mg - xhat * mgx)
-template <typename T, bool POOL = false>
+template <typename T, bool POOL = false, typename TY = T>
 static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ gate,
-                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            const TY* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ coef,
                                                             T* __restrict__ gy, long npieces, int C, int self_gate,
                                                             PoolGradSrc pg) {
@@ -522,7 +542,8 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
   // (Walking the tensor back to front -- the reduction pass that ran just before read g and y front to back, so their
   // tails are what the caches still hold -- was measured: no gain.)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
-    PieceView<T> vg, vy, vm, o;
+    PieceView<T> vg, vm, o;
+    YVec<TY, VEC> vy;
     if constexpr (POOL) {
       float a[VEC];
       const long row = i / cpr;
@@ -535,14 +556,14 @@ static __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __res
     } else {
       vg.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(g) + i);
     }
-    vy.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(y) + i);
+    vy.load_last(y, i);
     if (gate) vm.p = reinterpret_cast<const piece_t*>(gate)[i];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float gv = (float)vg.e[e];
       if (gate && !((float)vm.e[e] > 0.f)) gv = 0.f;
-      if (sg_beta && !((float)vy.e[e] * k1[e] + sh[e] > 0.f)) gv = 0.f;  // self gate (see the reduce kernel)
-      o.e[e] = (T)(k1[e] * gv + (kb[e] * ((float)vy.e[e] - mu[e]) + kd[e]));
+      if (sg_beta && !(vy.at(e) * k1[e] + sh[e] > 0.f)) gv = 0.f;  // self gate (see the reduce kernel)
+      o.e[e] = (T)(k1[e] * gv + (kb[e] * (vy.at(e) - mu[e]) + kd[e]));
     }
     reinterpret_cast<piece_t*>(gy)[i] = o.p;
   }
@@ -593,8 +614,8 @@ static __global__ void __launch_bounds__(256) bn_fwd_stats_kernel(const T* __res
 
 // BatchNorm backward = reduce -> finalize -> apply.  accum: [accum_rows][2][C] doubles, zero on entry (left holding the
 // sums); coef: [4][C] floats of scratch ([3][C] without the self gate).
-template <typename T>
-inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, const float* gamma, const float* mean,
+template <typename T, typename TY = T>
+inline void launch_bn_bwd(const T* g, const T* gate, const TY* y, long M, int C, const float* gamma, const float* mean,
                           const float* invstd, float* dgamma, float* dbeta, T* gy, double* accum, float* coef,
                           float grad_unscale, hipStream_t s, const float* self_gate_beta = nullptr,
                           PoolGradSrc pg = PoolGradSrc(), int accum_rows = 1, bool apply = true) {
@@ -621,7 +642,7 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   // rows in flight per thread: 2 for fp16 tensors (111 instead of 122 registers: one more wave fits beside the side stream's
   // weight gradient; 14.01 -> 13.89 ms per step), 4 for fp32 tensors (2: 30.74 -> 30.88 ms in the fp16x2 mode); profiles/r04/c11_*
   static const bool pool_windows = !(getenv("MN_POOL_WINDOWS") && atoi(getenv("MN_POOL_WINDOWS")) == 0);
-  if (pg.idx && sizeof(T) == 4 && self_gate_beta && pool_windows) {  // the stem on fp32 tensors: sums in pooled-window order
+  if (pg.idx && sizeof(T) == 4 && sizeof(TY) == 4 && self_gate_beta && pool_windows) {  // the stem on fp32 tensors: sums in pooled-window order
     const long nwin = (long)(M / ((long)pg.H * pg.W)) * pg.Po * pg.Qo;
     long wrows = (nwin + target - 1) / target;
     wrows = ((wrows + rlanes - 1) / rlanes) * rlanes;
@@ -633,13 +654,13 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   // (s_setprio 3 in the backward kernels, so that their waves are not starved by the weight gradient's MFMA waves on the same
   //  SIMD: no effect, 13.95 vs 14.00 ms fp16, 30.36 vs 30.38 ms fp16x2, profiles/r04/c12_*; removed)
   if (pg.idx)
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, 4, TY>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   else if (reduce_u == 2)
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false, 2>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false, 2, TY>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   else
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false, 4, TY>), dim3(nblk), dim3(256), 0, s, g, gate, y, mean, invstd, M, C, accum,
                        rows_per_block, (float*)nullptr, sg_gamma, self_gate_beta, pg, accum_rows);
   }
 #ifdef MN_ABLATION_BUILD
@@ -654,10 +675,10 @@ inline void launch_bn_bwd(const T* g, const T* gate, const T* y, long M, int C, 
   if (!apply) return;
   long np = M * C / VEC;
   if (pg.idx)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, TY>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
                        (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, TY>), dim3(ew_grid(np)), dim3(256), 0, s, g, gate, y, mean, invstd,
                        (const float*)coef, gy, np, C, self_gate_beta ? 1 : 0, pg);
 }
 

@@ -27,10 +27,21 @@ __device__ __forceinline__ void h2_load8(const half* __restrict__ base, long row
   for (int e = 0; e < 8; ++e) x[e] = (float)hi.e[e] + (float)lo.e[e];
 }
 
-// out(h2) = [relu]( y * scale[c] + shift[c] [+ res(h2)] );  bn_apply_kernel with 8 channels per thread
+// 8 channels of row `row` as ONE plain fp16 piece (round-to-nearest) of a [rows][C] fp16 tensor: the copy of an activation the
+// single-fp16 backward pass of the fp16x2m mode reads (weight-gradient operand, ReLU gates), written by the kernel that
+// produces the h2 tensor
+__device__ __forceinline__ void f16_store8(half* __restrict__ base, long row, int C, int c, const float (&x)[8]) {
+  PieceView<half> o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.e[e] = (half)x[e];
+  *reinterpret_cast<piece_t*>(base + row * C + c) = o.p;
+}
+
+// out(h2) = [relu]( y * scale[c] + shift[c] [+ res(h2)] );  bn_apply_kernel with 8 channels per thread; out16: optional plain
+// fp16 copy of the same values (fp16x2m)
 static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
                                                                  const half* __restrict__ res, half* __restrict__ out,
-                                                                 long nitems, int C, int relu) {
+                                                                 long nitems, int C, int relu, half* __restrict__ out16) {
   constexpr int VEC = 8;
   const int cpr = C / VEC;
   __shared__ floatx2 tab[512];  // [e][piece] -> (scale, shift)
@@ -62,6 +73,7 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
       if (relu) f[e] = fmaxf(f[e], 0.f);
     }
     h2_store8(out, row, C, cp * VEC, f);
+    if (out16) f16_store8(out16, row, C, cp * VEC, f);
   }
 }
 
@@ -69,7 +81,8 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
 // The comparison is on the fp32 values (the oracle's), so the routing is the reference's.
 static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
                                                                         half* __restrict__ out, unsigned char* __restrict__ idx,
-                                                                        int B, int H, int W, int C, int Po, int Qo) {
+                                                                        int B, int H, int W, int C, int Po, int Qo,
+                                                                        half* __restrict__ out16) {
   constexpr int VEC = 8;
   const int cpr = C / VEC;
   float s_scale[VEC], s_shift[VEC];
@@ -128,6 +141,7 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const fl
       }
     }
     h2_store8(out, orow, C, cp * VEC, best);
+    if (out16) f16_store8(out16, orow, C, cp * VEC, best);
     if (idx) {
       unsigned long long packed = 0;
 #pragma unroll
@@ -199,6 +213,22 @@ inline void launch_bn_bwd_h2(const float* g, const float* y, long M, int C, cons
   const long ni = M * C / 8;
   hipLaunchKernelGGL(bn_bwd_apply_h2_kernel, dim3(ew_grid(ni)), dim3(256), 0, s, g, y, mean, invstd, (const float*)coef, gy, ni, C,
                      self_gate_beta ? 1 : 0);
+}
+
+// out[i] = (float) in[i], 8 elements per thread (fp16x2m: the pooled stem activation's fp16 gradient for the stem's fp32 chain)
+static __global__ void __launch_bounds__(256) widen_f16_kernel(const half* __restrict__ in, float* __restrict__ out, long npieces) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
+    PieceView<half> v;
+    v.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(in) + i);
+    PieceView<float> a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a.e[e] = (float)v.e[e];
+      b.e[e] = (float)v.e[4 + e];
+    }
+    reinterpret_cast<piece_t*>(out)[2 * i] = a.p;
+    reinterpret_cast<piece_t*>(out)[2 * i + 1] = b.p;
+  }
 }
 
 // global average pool of an h2 activation

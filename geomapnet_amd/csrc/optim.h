@@ -232,8 +232,9 @@ __device__ __forceinline__ void h2_put(void* base, long row, int C, int c, float
   p[32] = (half)(v - (float)hi);
 }
 // H2 (T = float): mode-0 destinations are h2 matrices -- the forward operand [O][R][S][I] split along I, the data-gradient
-// operand [I][R][S][O] along O (MN_DTYPE_F16X2); modes 2 and 3 (stem, fc) stay fp32
-template <typename T, bool H2 = false>
+// operand [I][R][S][O] along O (MN_DTYPE_F16X2); modes 2 and 3 (stem, fc) stay fp32.  B16 (with H2, the fp16x2m mode): the
+// data-gradient operand is a plain fp16 matrix -- the backward pass contracts single fp16 operands
+template <typename T, bool H2 = false, bool B16 = false>
 static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob* __restrict__ jobs, int njobs,
                                                                 const float* __restrict__ params, int blk_base) {
   const int bid = (int)blockIdx.x + blk_base;  // a launch may cover a sub-range of the table's workgroups
@@ -274,7 +275,9 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
       const float v = tile[col][irow];
       const long didx = ((long)(it * 64 + irow) * RS + rs) * O + ot * 64 + col;
       if (job.mode == 0) {
-        if constexpr (H2)
+        if constexpr (H2 && B16)
+          reinterpret_cast<half*>(job.dst_b)[didx] = (half)v;
+        else if constexpr (H2)
           h2_put(job.dst_b, (long)(it * 64 + irow) * RS + rs, O, ot * 64 + col, v);
         else
           reinterpret_cast<T*>(job.dst_b)[didx] = (T)v;
@@ -299,7 +302,10 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
       const int o = (int)(t / R);
       if constexpr (H2) {
         if (job.dst_a) h2_put(job.dst_a, idx / I, I, i, v);
-        h2_put(job.dst_b, ((long)i * R + r) * S + s, O, o, v);
+        if constexpr (B16)
+          reinterpret_cast<half*>(job.dst_b)[(((long)i * R + r) * S + s) * O + o] = (half)v;
+        else
+          h2_put(job.dst_b, ((long)i * R + r) * S + s, O, o, v);
       } else {
         if (job.dst_a) reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
         reinterpret_cast<T*>(job.dst_b)[(((long)i * R + r) * S + s) * O + o] = (T)v;

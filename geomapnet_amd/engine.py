@@ -19,8 +19,11 @@ MODE_POSENET, MODE_MAPNET, MODE_ONLINE, MODE_GPS = 0, 1, 2, 3
 # split once by the producing kernel; the convolutions run three fp16 MFMAs per product on DMA-fed operands; conv outputs,
 # data gradients, BatchNorm, head, criterion and optimiser in fp32 (include/mapnet_hip.h MN_DTYPE_F16X2).  Gradients live in
 # fp16 pairs, so the mode uses the fp16 mode's loss scale and overflow guard.
-DTYPES = {"fp32": 0, "fp16": 1, "fp32x3": 2, "fp16x2": 3}
-SCALED_DTYPES = ("fp16", "fp16x2")  # modes whose gradients pass through fp16 halves
+# "fp16x2m": the forward pass of "fp16x2" bit for bit (loss and poses are that mode's) and a backward pass on the "fp16" kernels --
+# one MFMA per product on single fp16 operands, gates and BatchNorm statistics from the exact forward values
+# (include/mapnet_hip.h MN_DTYPE_F16X2M; what it costs the gradients: tools/mixed_budget.py)
+DTYPES = {"fp32": 0, "fp16": 1, "fp32x3": 2, "fp16x2": 3, "fp16x2m": 4}
+SCALED_DTYPES = ("fp16", "fp16x2", "fp16x2m")  # modes whose gradients pass through fp16 halves
 
 _default_dtype = "fp16"
 _default_loss_scale = 1024.0
@@ -28,7 +31,8 @@ _default_loss_scale = 1024.0
 
 def set_compute_dtype(name, loss_scale=None):
     """'fp16' (fp16 tensors, fp32 accumulate; the benchmark configuration), 'fp16x2' (fp16-pair conv operands, fp32
-    everything else: the parity configuration), 'fp32x3' (fp32 tensors, operands split inside the convolution kernels) or
+    everything else: the parity configuration), 'fp16x2m' (that forward pass, the fp16 mode's backward pass),
+    'fp32x3' (fp32 tensors, operands split inside the convolution kernels) or
     'fp32' (fp32 tensors on v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain)."""
     global _default_dtype, _default_loss_scale
     if name not in DTYPES:
@@ -230,9 +234,15 @@ class Engine:
         self.lib.check(self.lib.debug_tensor(plan["handle"], name.encode(), C.byref(ptr_), C.byref(n), C.byref(dt)))
         work = plan["work"]
         off = ptr_.value - work.data_ptr()
+        if dt.value not in (0, 1, 3):
+            raise MapNetHipError("debug_tensor: unknown dtype code %d for %r" % (dt.value, name))
         es = 2 if dt.value == 1 else 4
         assert 0 <= off and off + n.value * es <= work.numel()
-        return work[off: off + n.value * es].view(torch.float16 if dt.value == 1 else torch.float32)
+        raw = work[off: off + n.value * es]
+        if dt.value == 3:  # h2 (fp16 pairs): per 32 channels 32 hi halves then 32 lo halves -> fp32 values hi + lo, a COPY
+            h = raw.view(torch.float16).view(-1, 2, 32).float()
+            return (h[:, 0, :] + h[:, 1, :]).reshape(-1)
+        return raw.view(torch.float16 if dt.value == 1 else torch.float32)
 
     # -- calls --------------------------------------------------------------------------------------
     def set_dropout(self, p, seed=0):

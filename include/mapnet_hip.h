@@ -44,8 +44,16 @@ extern "C" {
  *                 BatchNorm / pooling / head / optimiser kernels compute on stay fp32.  The convolutions then run three
  *                 v_mfma_f32_32x32x16_f16 per product on operands that reach LDS by DMA, with no conversion in their K loops.
  *                 Gradients are kept inside fp16's range by the loss scale + overflow guard of MN_DTYPE_F16.  Operator entry
- *                 points: dtype 3 = A / Bw / dY / X / gates h2, out / res / dW fp32. */
-enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1, MN_DTYPE_F32X3 = 2, MN_DTYPE_F16X2 = 3 };
+ *                 points: dtype 3 = A / Bw / dY / X / gates h2, out / res / dW fp32.
+ * MN_DTYPE_F16X2M: (round 5, plans only) the forward pass of MN_DTYPE_F16X2 bit for bit -- the loss and the predicted poses of a
+ *                 step ARE that mode's, i.e. inside the north-star tolerance -- and a backward pass on the MN_DTYPE_F16 kernels:
+ *                 one MFMA per product on single fp16 operands (d(conv output), data gradients and the data-gradient weight copy
+ *                 are plain fp16; the weight gradients' X operand and the ReLU gates read plain fp16 copies of the activations
+ *                 that the h2 producers write beside the h2 tensor).  Gates and BatchNorm's backward statistics come from the
+ *                 exact forward values (fp32 conv outputs), so the gradients differ from MN_DTYPE_F16X2's by operand rounding
+ *                 only: 1.1e-3 relative L2 overall (tools/mixed_budget.py), below the 4.9e-3 by which two fp32 evaluations of
+ *                 the reference's step differ through ReLU gate flips.  Loss scale + overflow guard as MN_DTYPE_F16. */
+enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1, MN_DTYPE_F32X3 = 2, MN_DTYPE_F16X2 = 3, MN_DTYPE_F16X2M = 4 };
 /* criterion / batch-layout modes */
 enum {
   MN_MODE_POSENET = 0,      /* PoseNetCriterion,        common/criterion.py:33-52   */
@@ -192,7 +200,9 @@ int64_t mn_stuck_overflow_steps(mn_handle* h);
  * tensor of the work arena as the last step left it.  Names: "xpad", "stem.y", "stem.gy", "p0", "gp0", "pooled", "feat",
  * "poses", "dposes", "dz", "dpooled", "dropmask", and per residual block i = 0..15 "b<i>.y1 | a1 | y2 | out | gy1 | ga1 | gy2 | gout"
  * (+ "yd", "zd", "gyd" for blocks with a projection); NHWC.  In the fp16x2 mode the tensors the convolutions consume ("p0",
- * "a1", "out", "zd", "gy1", "gy2", "gyd") are h2 tensors and report dtype MN_DTYPE_F16X2.  Read-only for the caller. */
+ * "a1", "out", "zd", "gy1", "gy2", "gyd") are h2 tensors and report dtype MN_DTYPE_F16X2; in the fp16x2m mode the forward ones
+ * of these are h2 and every gradient tensor of the blocks ("gp0", "gy1", "ga1", "gy2", "gout", "gyd") is plain fp16 (MN_DTYPE_F16),
+ * and "p0.f16" / "b<i>.a1.f16" / "b<i>.out.f16" name the plain fp16 copies of the activations.  Read-only for the caller. */
 int mn_debug_tensor(mn_handle* h, const char* name, void** ptr, int64_t* numel, int32_t* dtype);
 
 /* parameters changed behind the library's back (load_state_dict): refresh compute copies */

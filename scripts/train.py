@@ -45,7 +45,7 @@ def build_parser():
     parser.add_argument("--dropout_active", action="store_true",
                         help="apply the config's dropout on the device in training mode (default: identity, the reference's "
                              "behaviour under its pinned PyTorch 0.4.1)")
-    parser.add_argument("--dtype", choices=("fp16", "fp16x2", "fp32x3", "fp32"), default="fp16", help="compute precision of the HIP kernels")
+    parser.add_argument("--dtype", choices=("fp16", "fp16x2m", "fp16x2", "fp32x3", "fp32"), default="fp16", help="compute precision of the HIP kernels")
     parser.add_argument("--pretrained", choices=("auto", "yes", "no"), default="auto",
                         help="start from the torchvision ImageNet ResNet-34 ($TORCH_MODEL_ZOO/resnet34-333f7ec4.pth, as the "
                              "reference does: models.resnet34(pretrained=True), scripts/train.py:76) and re-initialise only the "

@@ -31,6 +31,13 @@ def test_mapnet_train_step_fp16x2_parity(lib):
     assert rep[0][2] < 1e-3
 
 
+def test_mapnet_train_step_fp16x2m_parity(lib):
+    """the fp16x2 forward pass + the fp16 mode's single-MFMA backward pass on plain fp16 copies: loss / poses at the fp32 bar (they
+    are the fp16x2 mode's bits), every parameter gradient within the fp32-class bar of 2e-2 per tensor"""
+    rep = checks.check_train_step(lib, DEV, "fp16x2m", mode="mapnet", N=2, H=64, W=85, steps=1)
+    assert rep[0][2] < 1e-3
+
+
 def test_dropout_on_the_device_with_the_oracle_applying_the_same_mask(lib):
     checks.check_dropout(lib, DEV, "fp32", N=1, H=32, W=40, wiring=False)
 

@@ -43,8 +43,18 @@ GFLOP_PER_IMAGE_EXECUTED = 38.65  # the stem's unused input gradient is not comp
 PEAK_F16_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_BYTES_PER_S = 8.0e12   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PROFILE_ROUND = "r04"
-PARITY_MODE = "fp16x2"
+PROFILE_ROUND = "r05"
+PARITY_MODE = "fp16x2m"   # fp16x2's forward pass (its loss / poses, bit for bit) + the fp16 mode's single-MFMA backward pass
+PARITY_MODE_FULL = "fp16x2"  # three MFMAs per product in the backward pass as well (round 4's parity mode), timed beside it
+# matrix-pipe MFMAs issued per reference FLOP: fp32x3 / fp16x2 contract every product three times, fp16x2m only the forward third
+MFMA_PER_FLOP = {"fp32x3": 3.0, "fp16x2": 3.0, "fp16x2m": 5.0 / 3.0}
+PARITY_DTYPE_TEXT = {
+    "fp16x2m": "fp16x2m: forward pass = fp16x2 (conv operands as fp16 pairs split once by their producers, 3 x v_mfma_f32_32x32x16_f16 "
+               "per product, fp32 conv outputs / BatchNorm / head / criterion: loss and poses are fp16x2's bits); backward pass = the fp16 "
+               "mode's kernels, one MFMA per product on single fp16 operands, with every ReLU gate and BatchNorm backward statistic taken "
+               "from the exact forward values (gradients differ from fp16x2's by operand rounding: `parity.grad_*`)",
+    "fp16x2": "fp16x2: conv operands as fp16 pairs (hi + lo, split once by their producers), 3 x v_mfma_f32_32x32x16_f16 per "
+              "product on DMA-fed operands, forward AND backward; conv outputs, gradients, BatchNorm, head, criterion, optimiser f32"}
 
 
 def cpu_model():
@@ -86,7 +96,11 @@ def hip_first_step(dtype_name, state_dict, x, t, dev, binding):
                       "adam", base_lr=1e-4, weight_decay=5e-4)
     net.train()
     l, p = G.step_feedfwd(x.to(dev), net, dev.type == "cuda", t.to(dev), crit, opt, True)
-    return l, p.cpu()
+    from geomapnet_amd.posenet import _view
+    eng = net.mapnet._engine
+    # parameter gradients of the step (loss scale already divided out) by the reference's names, in the reference's shapes
+    grads = {e.name.decode(): _view(eng.grads(), e).detach().cpu().double().clone() for e in eng.entries if not e.is_buffer}
+    return l, p.cpu(), grads
 
 
 def cpu_baseline_and_parity(args, dev, binding=None, dtypes=("fp16",)):
@@ -105,7 +119,19 @@ def cpu_baseline_and_parity(args, dev, binding=None, dtypes=("fp16",)):
     lo, po = oracle.step_feedfwd(x, onet, False, t, ocrit, oopt, True)
     full_s = time.perf_counter() - t0
     po = po.detach()
-    for d, (l, p) in hip.items():
+    ograd = {k: v.grad.detach().double() for k, v in onet.mapnet.named_parameters()}
+
+    def grad_dev(g, ref):  # relative L2 deviation over all parameters / of the worst tensor
+        num = den = worst = 0.0
+        for k, r in ref.items():
+            a = g[k]
+            num += (a - r).pow(2).sum().item()
+            den += r.pow(2).sum().item()
+            if r.norm() > 1e-8:
+                worst = max(worst, ((a - r).norm() / r.norm()).item())
+        return float("%.3e" % ((num / den) ** 0.5)), float("%.3e" % worst)
+
+    for d, (l, p, g) in hip.items():
         out["parity"][d] = {
             "dtype": d, "checker": "oracle (CPU fp32 port of the reference path), same batch, same initial weights, step 1",
             "config": "%d windows x T=3 = %d images %dx%d" % (n, n * 3, H, W),
@@ -118,6 +144,15 @@ def cpu_baseline_and_parity(args, dev, binding=None, dtypes=("fp16",)):
                    "relative to max(1,|loss|), `meets_bar_abs` as an absolute 1e-4 on the loss value itself",
             "meets_bar": bool(abs(l - lo) / max(1.0, abs(lo)) <= 1e-4 and (p - po).abs().max().item() <= 1e-3),
             "meets_bar_abs": bool(abs(l - lo) <= 1e-4 and (p - po).abs().max().item() <= 1e-3)}
+        # parameter gradients of the step against the oracle's (the floor for ANY fp32 evaluation of this step is ~5e-3 / 1e-2:
+        # ReLU gate flips at 1e-7 perturbations)
+        out["parity"][d]["grad_l2_rel_all"], out["parity"][d]["grad_l2_rel_worst_tensor"] = grad_dev(g, ograd)
+    if PARITY_MODE in hip and PARITY_MODE_FULL in hip:  # what the single-fp16 backward pass changes, arena against arena
+        a, w = grad_dev(hip[PARITY_MODE][2], hip[PARITY_MODE_FULL][2])
+        out["parity"][PARITY_MODE]["grad_vs_%s_all" % PARITY_MODE_FULL] = a
+        out["parity"][PARITY_MODE]["grad_vs_%s_worst_tensor" % PARITY_MODE_FULL] = w
+        out["parity"][PARITY_MODE]["forward_bits_equal_%s" % PARITY_MODE_FULL] = bool(
+            hip[PARITY_MODE][0] == hip[PARITY_MODE_FULL][0] and bool((hip[PARITY_MODE][1] == hip[PARITY_MODE_FULL][1]).all()))
     del onet, ocrit, oopt, x, t
     # ---- (2) bounded timing sample
     sw, warm, timed = 5, 3, 10
@@ -275,11 +310,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--windows", type=int, default=64, help="windows per GPU per step")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp16x2", "fp32x3", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp16x2m", "fp16x2", "fp32x3", "fp32"])
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=341)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline + parity)")
-    ap.add_argument("--no-parity-mode", action="store_true", help="skip the second timed pass in the parity mode (fp16x2)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the timed passes in the parity modes (fp16x2m, fp16x2)")
     ap.add_argument("--no-events", action="store_true", help="do not time conv launches with HIP events")
     ap.add_argument("--no-eval-metric", action="store_true",
                     help="skip the accuracy leg (BASELINE's 'median t/q err': a learnable synthetic scene trained and evaluated "
@@ -331,9 +366,10 @@ def main():
     # The parity mode, timed by the same code in the same run: fp16-pair conv operands, three MFMAs per product, fp32 everything
     # else (fp16x2) -- the mode that meets the north-star tolerance -- so that the throughput claim and the parity claim are one
     # measurement (fewer regions: it is ~2x slower per step).
-    pm_rec = None
+    pm_rec = pf_rec = None
     if args.dtype == "fp16" and not args.no_parity_mode and not args.emu:
         pm_rec = timed_mode(args, PARITY_MODE, dev, binding, world, rank, min(repeats, 3))
+        pf_rec = timed_mode(args, PARITY_MODE_FULL, dev, binding, world, rank, min(repeats, 2))  # (round 4's parity mode, beside it)
 
     if rank == 0:
         n, T, H, W = args.windows, 3, args.height, args.width
@@ -343,7 +379,8 @@ def main():
         def roofline(rec, ms_per_step):
             if rec["conv_ms_per_step"] is None or rec["conv_ms_per_step"] <= 0:
                 return None
-            x3 = rec["dtype"] in ("fp32x3", "fp16x2")
+            x3 = rec["dtype"] in MFMA_PER_FLOP
+            mpf = MFMA_PER_FLOP.get(rec["dtype"], 1.0)
             peak = PEAK_F32_TFLOPS if rec["dtype"] == "fp32" else PEAK_F16_TFLOPS
             ach = flops_G / rec["conv_ms_per_step"]  # GFLOP / ms = TFLOP/s per GPU; fp32x3: fp32-EQUIVALENT flops
             traffic, src, whole_bytes = None, None, 0  # HBM bytes of the same launches: separate rocprofv3 --pmc passes (profiles/), static
@@ -359,19 +396,21 @@ def main():
                               "this workload, not measured in this run)" % rnd
                         break
             r = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                 "frac": round((3.0 if x3 else 1.0) * ach / peak, 4), "traffic": traffic, "traffic_source": src,
+                 "frac": round(mpf * ach / peak, 4), "traffic": traffic, "traffic_source": src,
                  "kernel": "all conv MFMA kernels of a step (igemm* + conv_halo_pp + wgrad* + stem): %d convolution operators "
                            "per step, each timed as one region (a stride-2 data gradient is 2-4 launches)" % rec["conv_regions"],
                  "conv_ms_per_step": round(rec["conv_ms_per_step"], 3), "eager_profiled_ms_per_step": rec["eager_profiled_ms_per_step"],
                  "flops_per_step_G": round(flops_G, 1),
-                 "whole_step_frac": round((3.0 if x3 else 1.0) * flops_G / ms_per_step / peak, 4)}
+                 "whole_step_frac": round(mpf * flops_G / ms_per_step / peak, 4)}
             if whole_bytes:  # every kernel of the step (same PMC passes): bytes, and that traffic over this run's step time vs 8 TB/s
                 r["whole_step_traffic"] = whole_bytes
                 r["whole_step_hbm_frac"] = round(whole_bytes / (ms_per_step * 1e-3) / PEAK_HBM_BYTES_PER_S, 4)
             if x3:
-                r["note"] = ("fp16x2 / fp32x3 execute three v_mfma_f32_32x32x16_f16 (bf16) per fp32-class product: `achieved` counts the "
-                             "reference's fp32 FLOPs once, `frac` = 3 x achieved / 2.5 PF is the matrix pipe's utilisation; the "
-                             "exact-fp32 pipe peaks at 157.3 TF")
+                r["note"] = ("fp16x2 / fp32x3 execute three v_mfma_f32_32x32x16_f16 (bf16) per fp32-class product, fp16x2m three in the forward "
+                             "third of the FLOPs and one in the backward two thirds (5/3 on average): `achieved` counts the reference's "
+                             "FLOPs once, `frac` = mfma_per_flop x achieved / 2.5 PF is the matrix pipe's utilisation; the exact-fp32 pipe "
+                             "peaks at 157.3 TF")
+                r["mfma_per_flop"] = round(mpf, 4)
                 r["x_fp32_pipe_peak"] = round(ach / PEAK_F32_TFLOPS, 3)
             return r
 
@@ -381,7 +420,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": {"fp16": "f16", "fp32": "f32", "fp32x3": "f32 tensors, f16x3/bf16x3 MFMA",
-                         "fp16x2": "f16 pairs (hi + lo) for conv operands, f32 elsewhere, 3 x f16 MFMA per product"}[args.dtype], "data": "synthetic",
+                         "fp16x2": "f16 pairs (hi + lo) for conv operands, f32 elsewhere, 3 x f16 MFMA per product",
+                         "fp16x2m": "forward: f16 pairs, 3 x f16 MFMA per product; backward: f16, 1 MFMA per product"}[args.dtype], "data": "synthetic",
                "config": {"workload": "BASELINE configs[2]: MapNet ResNet-34, %d windows x T=3 = %d images/GPU/step, %dx%d, "
                                       "MapNetCriterion learned beta/gamma, Adam, random-init weights" % (n, n * T, H, W),
                           "global_windows": n * world, "parallelism": "dp%d" % world, "n_ranks_seen": ranks_seen,
@@ -395,24 +435,26 @@ def main():
                           "loss_first": main_rec["loss_first"], "loss_last": main_rec["loss_last"],
                           "gflop_per_image": GFLOP_PER_IMAGE_TRAIN, "gflop_per_image_executed": GFLOP_PER_IMAGE_EXECUTED},
                "roofline": roofline(main_rec, ms_per_step)}
-        if pm_rec is not None:
-            pms = median(pm_rec["region_ms_per_step"])
-            out["parity_mode"] = {
-                "dtype": "fp16x2: conv operands as fp16 pairs (hi + lo, split once by their producers), 3 x v_mfma_f32_32x32x16_f16 per "
-                         "product on DMA-fed operands; conv outputs, gradients, BatchNorm, head, criterion, optimiser f32",
+        for key, r_ in (("parity_mode", pm_rec), ("parity_mode_full", pf_rec)):
+            if r_ is None:
+                continue
+            pms = median(r_["region_ms_per_step"])
+            out[key] = {
+                "dtype": PARITY_DTYPE_TEXT[r_["dtype"]],
                 "value": round(images_per_step / (pms / 1e3), 2), "unit": "images/s", "ms_per_step": round(pms, 3),
-                "region_ms_per_step": pm_rec["region_ms_per_step"], "comm_exposed_ms": pm_rec["comm_exposed_ms"],
-                "loss_first": pm_rec["loss_first"], "loss_last": pm_rec["loss_last"], "roofline": roofline(pm_rec, pms)}
+                "region_ms_per_step": r_["region_ms_per_step"], "comm_exposed_ms": r_["comm_exposed_ms"],
+                "loss_first": r_["loss_first"], "loss_last": r_["loss_last"], "roofline": roofline(r_, pms)}
         if args.emu:
             out["data"] = "synthetic (CPU emulator dry-run: NOT a measurement)"
         if world == 1 and not args.no_cpu_baseline:
             try:
-                dts = (args.dtype,) + ((PARITY_MODE,) if pm_rec is not None else ())
+                dts = (args.dtype,) + ((PARITY_MODE, PARITY_MODE_FULL) if pm_rec is not None else ())
                 leg = cpu_baseline_and_parity(args, dev, binding, dts)
                 out["cpu_baseline"] = leg["cpu_baseline"]
                 out["parity"] = leg["parity"][args.dtype]
                 if pm_rec is not None:
                     out["parity_mode"]["parity"] = leg["parity"][PARITY_MODE]
+                    out["parity_mode_full"]["parity"] = leg["parity"][PARITY_MODE_FULL]
             except Exception as e:  # the oracle leg must never hide the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         if world == 1 and not args.no_eval_metric and not args.emu:

@@ -1351,7 +1351,7 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
     rec = {"mode": mode, "windows": N, "images": N * frames, "H": H, "W": W, "oracle_step_s": round(oracle_s, 1),
            "loss_oracle": lo, "pose_scale": po.abs().max().item()}
     del omodel, oopt
-    for dtype_name in ("fp16x2", "fp32x3", "fp32", "fp16"):
+    for dtype_name in ("fp16x2m", "fp16x2", "fp32x3", "fp32", "fp16"):
         G.set_compute_dtype(dtype_name)
         net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, filter_nans=filter_nans, _binding=lib))
         net.load_state_dict(sd0)
@@ -1374,10 +1374,12 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
         eng = net.mapnet._engine
         num = den = 0.0
         worst = 0.0
+        mine = {}
         for e in eng.entries:
             if e.is_buffer:
                 continue
             g = _view(eng.grads(), e).cpu().double()
+            mine[e.name.decode()] = g.clone()
             r = ograd[e.name.decode()].double()
             if max_grad_norm > 0.0:
                 continue  # the oracle's stored gradients are already clipped, the arena's are not
@@ -1388,8 +1390,28 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
         rec[dtype_name] = {"loss": l, "loss_rel": abs(l - lo) / max(1.0, abs(lo)), "pose_abs_max": d.abs().max().item(),
                            "pose_abs_rms": d.pow(2).mean().sqrt().item(),
                            "grad_l2_rel_all": (num / den) ** 0.5 if den > 0 else None, "grad_l2_rel_worst_tensor": worst}
+        if dtype_name in ("fp16x2m", "fp16x2"):  # the two arenas against each other (unclipped on both sides)
+            if dtype_name == "fp16x2m":
+                mixed_grads = mine
+            else:
+                n2 = d2 = w2 = 0.0
+                for k, g2 in mine.items():
+                    n2 += (mixed_grads[k] - g2).pow(2).sum().item()
+                    d2 += g2.pow(2).sum().item()
+                    if g2.norm() > 1e-8:
+                        w2 = max(w2, ((mixed_grads[k] - g2).norm() / g2.norm()).item())
+                rec["fp16x2m"]["grad_vs_fp16x2_all"] = (n2 / d2) ** 0.5
+                rec["fp16x2m"]["grad_vs_fp16x2_worst_tensor"] = w2
+                del mixed_grads
         del net, model, opt, c
-    for name in ("fp16x2", "fp32x3", "fp32"):
+    # fp16x2m (round 5): the fp16x2 forward pass, so its loss and poses must be that mode's BITS; its single-fp16 backward pass is
+    # held to the same gradient bars as the fp32-class modes and, directly, to 3e-3 / 6e-3 of fp16x2's gradients -- operand
+    # rounding only (tools/mixed_budget.py: 6.4e-4 / 1.6e-3 from the oracle's own arithmetic), where a gate or a BatchNorm statistic
+    # taken from a rounded forward value would show as percents
+    assert rec["fp16x2m"]["loss"] == rec["fp16x2"]["loss"] and rec["fp16x2m"]["pose_abs_max"] == rec["fp16x2"]["pose_abs_max"], rec
+    if rec["fp16x2m"].get("grad_vs_fp16x2_all") is not None:
+        assert rec["fp16x2m"]["grad_vs_fp16x2_all"] <= 3e-3 and rec["fp16x2m"]["grad_vs_fp16x2_worst_tensor"] <= 6e-3, rec
+    for name in ("fp16x2m", "fp16x2", "fp32x3", "fp32"):
         assert rec[name]["loss_rel"] <= fp32_loss_rtol, (name, rec)
         assert rec[name]["pose_abs_max"] <= fp32_pose_atol, (name, rec)
         if rec[name]["grad_l2_rel_all"] is not None:  # (gate flips: DESIGN.md section 6)

@@ -169,14 +169,14 @@ def test_mapnet_train_step_fp32_parity_one_weight_gradient_fork_per_block(lib, m
 
 
 @pytest.mark.parametrize("sched", ["0", "1", "2"])
-@pytest.mark.parametrize("dtype", ["fp16x2", "fp16"])
+@pytest.mark.parametrize("dtype", ["fp16x2m", "fp16x2", "fp16"])
 def test_mapnet_train_step_under_every_weight_gradient_schedule(lib, monkeypatch, dtype, sched):
     """MN_WGRAD_SCHED (read per plan): one fork per block / a fork as soon as d(conv output) exists / deferred to the next
     BatchNorm-backward pass.  The defaults differ by mode since round 4 (fp16 0, fp16x2 1, fp32 2): every mode must be parity-green
     under every order -- the side stream only reads tensors that live until the stage's join."""
     monkeypatch.setenv("MN_WGRAD_SCHED", sched)
-    if dtype == "fp16x2":
-        checks.check_train_step(lib, DEV, "fp16x2", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+    if dtype in ("fp16x2", "fp16x2m"):
+        checks.check_train_step(lib, DEV, dtype, mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
     else:
         checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=2e-2, pose_atol=5e-2,
                                 grad_l2_rtol=None)
@@ -201,6 +201,27 @@ def test_mapnet_train_step_fp16x2_parity_full_resolution(lib):
     fp32 everything else): north-star tolerances as written, gradients to the fp32 build's 2e-2 per tensor"""
     checks.check_train_step(lib, DEV, "fp16x2", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3,
                             pose_abs=1e-3)
+
+
+def test_mapnet_train_step_fp16x2m_parity_full_resolution(lib):
+    """fp16x2m (round 5): the fp16x2 forward pass (its loss and poses, bit for bit) + the fp16 mode's single-MFMA backward pass on
+    plain fp16 copies, gates and BatchNorm statistics from the exact forward values: north-star tolerances as written, gradients to
+    the fp32-class bar of 2e-2 per tensor"""
+    checks.check_train_step(lib, DEV, "fp16x2m", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3,
+                            pose_abs=1e-3)
+
+
+def test_mapnet_train_step_fp16x2m_two_steps_small(lib):
+    checks.check_train_step(lib, DEV, "fp16x2m", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+
+
+def test_mapnet_online_train_step_fp16x2m_parity_clip_and_nan_filter(lib):
+    checks.check_train_step(lib, DEV, "fp16x2m", mode="mapnet++", N=2, H=64, W=85, steps=1, max_grad_norm=5.0, lr=1e-5, wd=0.0,
+                            filter_nans=True, grad_l2_rtol=None)
+
+
+def test_posenet_train_step_fp16x2m(lib):
+    checks.check_train_step(lib, DEV, "fp16x2m", mode="posenet", N=5, H=64, W=85, steps=1)
 
 
 def test_mapnet_train_step_fp16x2_two_steps_small(lib):
@@ -565,7 +586,7 @@ def test_chunk_resident_a_kernel_h2_race_screen():
     _run_forced(dict(os.environ, MN_H2_CASES="1", MN_H2_HALO256="1"), True)
 
 
-@pytest.mark.parametrize("dtype_name", ["fp16", "fp32", "fp32x3", "fp16x2"])
+@pytest.mark.parametrize("dtype_name", ["fp16", "fp32", "fp32x3", "fp16x2", "fp16x2m"])
 def test_deterministic_mode_is_bit_reproducible(lib, dtype_name):
     """MN_DETERMINISTIC=1: three MapNet training steps (clipping on) twice from the same state -> identical bits; the
     default mode's atomics only differ from it by summation order"""

@@ -116,9 +116,30 @@ struct PlanBase {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     // (a side stream of lower or higher priority was measured: no gain)
-    if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
-      streams[dev] = nullptr;
-      (void)hipGetLastError();
+    // MN_WGRAD_CUS=n (experiment, round 5): the side stream may only use n of the chip's CUs (hipExtStreamCreateWithCUMask) -- a
+    // static partition, so that weight-gradient workgroups cannot take every CU away from the main stream's BatchNorm /
+    // data-gradient launches.  MN_WGRAD_CU_SPREAD=1 spreads the n CUs evenly over the mask's bit range instead of taking the first
+    // n.  Measured: profiles/r05 (cu mask); not a default.
+    if (!streams[dev]) {
+      const int ncu = getenv("MN_WGRAD_CUS") ? atoi(getenv("MN_WGRAD_CUS")) : 0;
+      int total = 0;
+      hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev);
+      hipError_t e;
+      if (ncu > 0 && total > 0 && ncu < total) {
+        const bool spread = getenv("MN_WGRAD_CU_SPREAD") && atoi(getenv("MN_WGRAD_CU_SPREAD")) != 0;
+        std::vector<uint32_t> mask((total + 31) / 32, 0u);
+        for (int i = 0; i < ncu; ++i) {
+          const int bit = spread ? (int)((long)i * total / ncu) : i;
+          mask[bit / 32] |= 1u << (bit % 32);
+        }
+        e = hipExtStreamCreateWithCUMask(&streams[dev], (uint32_t)mask.size(), mask.data());
+      } else {
+        e = hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking);
+      }
+      if (e != hipSuccess) {
+        streams[dev] = nullptr;
+        (void)hipGetLastError();
+      }
     }
     return streams[dev];
   }
@@ -206,19 +227,29 @@ struct PlanBase {
   // one or two steps late; until then the device keeps skipping, so no non-finite value reaches weights or moments.
   float cur_scale = 1.f;
   bool overflow_guard = false;
-  long long* overflow_host = nullptr;  // pinned: {last step skipped, skipped steps in total, last skipped attempt}
+  long long* overflow_host = nullptr;  // pinned: {last step skipped, skipped steps in total, last skipped attempt, last COMPLETED attempt}
   long long skipped_seen = 0;
+  long long done_seen = 0;        // last completed attempt the host has accounted for (overflow_host[3])
   int64_t attempts = 0;           // optimiser steps enqueued on this plan (skipped ones included)
   int64_t scale_set_at = 0;       // `attempts` when the loss scale last changed: later attempts ran under cur_scale
-  int64_t stuck_skips = 0;        // CONSECUTIVE skips seen while the scale already was 1 (nothing left to lower); any clean
+  int64_t stuck_skips = 0;        // CONSECUTIVE skips seen while the scale already was 1 (nothing left to lower); an APPLIED
                                   // step, a scale growth or mn_set_loss_scale resets it
-  int clean_steps = 0;
+  long long clean_steps = 0;      // applied steps since the last skip the host has seen
   int scale_growth_interval = getenv("MN_SCALE_GROWTH") ? atoi(getenv("MN_SCALE_GROWTH")) : 2000;
+  // The host reads the pinned words WITHOUT waiting for the device, so a poll that sees no new skip proves nothing by itself: the
+  // host may simply be ahead (C-API callers that never read the loss, DataLoader jitter).  Progress is only what the device reports:
+  // overflow_host[3], the index of the last attempt it completed.  (Round-4 ADVICE: the previous form reset `stuck_skips` and
+  // advanced `clean_steps` on every poll without a new skip, so a run with permanently non-finite inputs whose polls interleave
+  // with "nothing finished yet" could reset the counter forever and silently train nothing, and the loss scale grew on polls
+  // that observed nothing.)
   void poll_overflow() {
     if (!overflow_guard || !overflow_host) return;
-    const long long seen = *(volatile long long*)(overflow_host + 1);
+    const long long done = *(volatile long long*)(overflow_host + 3);   // read first: a copy landing in between can only make
+    const long long seen = *(volatile long long*)(overflow_host + 1);   // `seen` newer than `done` (fewer clean steps counted)
     const long long last_bad = *(volatile long long*)(overflow_host + 2);
-    if (seen > skipped_seen) {
+    const long long new_skips = seen > skipped_seen ? seen - skipped_seen : 0;
+    const long long new_done = done > done_seen ? done - done_seen : 0;
+    if (new_skips > 0) {
       // The host reads the count one or two steps late, and the steps enqueued meanwhile overflow under the OLD scale too:
       // a burst is ONE overflow event.  Halve once per burst -- i.e. only when a skipped step was enqueued after the
       // scale last changed.
@@ -227,19 +258,24 @@ struct PlanBase {
           cur_scale *= 0.5f;
           scale_set_at = attempts;
         } else {
-          stuck_skips += seen - skipped_seen;  // non-finite values that no loss scale can fix (inputs, forward pass)
+          stuck_skips += new_skips;  // non-finite values that no loss scale can fix (inputs, forward pass)
         }
       }
       skipped_seen = seen;
       clean_steps = 0;
-    } else {
-      // no new skip since the last poll: training is progressing (isolated non-finite batches at scale 1 are not "stuck")
-      stuck_skips = 0;
-      if (scale_growth_interval > 0 && ++clean_steps >= scale_growth_interval) {
-        clean_steps = 0;
-        if (cur_scale < 65536.f) {
-          cur_scale *= 2.f;
-          scale_set_at = attempts;
+    }
+    if (new_done > 0) {
+      done_seen = done;
+      // positive evidence of an applied step: the most recent completed attempt was not a skipped one
+      if (last_bad < done) stuck_skips = 0;
+      if (new_skips == 0) {
+        clean_steps += new_done;
+        if (scale_growth_interval > 0 && clean_steps >= scale_growth_interval) {
+          clean_steps = 0;
+          if (cur_scale < 65536.f) {
+            cur_scale *= 2.f;
+            scale_set_at = attempts;
+          }
         }
       }
     }
@@ -330,7 +366,7 @@ struct Plan : PlanBase {
   float* wgf_ws = nullptr;  // partial tiles of the fused weight gradient (wgrad_fused.h), shared by its launches (one stream)
   long wgf_ws_floats = 0;
   void* zero_page;          // 256 zero bytes: source of out-of-image taps for the DMA conv pipeline
-  long long* overflow_dev;  // {this step skipped, skipped steps in total} (adam_prep_kernel)
+  long long* overflow_dev;  // {this step skipped, skipped steps in total, last skipped attempt, last completed attempt} (adam_prep_kernel)
   long long* step_dev;      // device-resident Adam step counter
   float* bc_dev;            // {1 - beta1^t, 1 - beta2^t}, derived on device from step_dev
   const float* cur_targets = nullptr;
@@ -562,11 +598,11 @@ struct Plan : PlanBase {
     hipStreamSynchronize(s);  // cm is a host temporary
     stem.colmap = stem_colmap;
     if (overflow_guard && !overflow_host) {
-      if (hipHostMalloc((void**)&overflow_host, 3 * sizeof(long long)) != hipSuccess) {
+      if (hipHostMalloc((void**)&overflow_host, 4 * sizeof(long long)) != hipSuccess) {
         overflow_host = nullptr;
         (void)hipGetLastError();
       } else {
-        overflow_host[0] = overflow_host[1] = overflow_host[2] = 0;
+        overflow_host[0] = overflow_host[1] = overflow_host[2] = overflow_host[3] = 0;
       }
     }
     build_repack_table(s);
@@ -1177,7 +1213,7 @@ struct Plan : PlanBase {
     a.method = optim_method; a.nesterov = nesterov;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(L.param_floats)), dim3(256), 0, s, a);
     if (overflow_guard && overflow_host)
-      hipMemcpyAsync(overflow_host, overflow_dev, 3 * sizeof(long long), hipMemcpyDeviceToHost, s);
+      hipMemcpyAsync(overflow_host, overflow_dev, 4 * sizeof(long long), hipMemcpyDeviceToHost, s);
     return check_launch("optim_step");
   }
 };
@@ -1325,6 +1361,7 @@ extern "C" int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval)
   if (P.overflow_host) {  // skips of steps still in flight belong to the old scale: do not halve the new one for them
     hipDeviceSynchronize();
     P.skipped_seen = *(volatile long long*)(P.overflow_host + 1);
+    P.done_seen = *(volatile long long*)(P.overflow_host + 3);
   }
   return 0;
 }

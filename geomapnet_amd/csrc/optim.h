@@ -112,6 +112,7 @@ static __global__ void adam_prep_kernel(long long* step, float beta1, float beta
       const double v = *sqnorm;
       const bool bad = !(v == v) || v > 1.7e308 || v < -1.7e308;
       overflow[0] = bad ? 1 : 0;
+      overflow[3] = attempt;  // the last attempt the device has COMPLETED (applied or skipped): the host's evidence of progress
       if (bad) {
         overflow[1] += 1;
         overflow[2] = attempt;

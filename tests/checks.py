@@ -1208,13 +1208,15 @@ def check_nan_filter(lib, dev, dtype_name="fp32", N=2, H=64, W=85):
 
 
 # ---- fp16 overflow: the step is skipped on the device, the host lowers the loss scale -----------------------------------
-def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3):
+def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3, dtype_name="fp16"):
     """A loss scale far too large makes the fp16 activation gradients overflow: the step must leave parameters, Adam
     moments and the Adam step counter untouched (no inf/NaN anywhere), be counted, and the scale must come down; with a
-    sane scale the next step is applied."""
+    sane scale the next step is applied.  dtype_name fp16x2 / fp16x2m (the parity modes: their gradients pass through fp16 halves
+    too): the first APPLIED step after the skipped ones must still be the oracle's first step to the north-star tolerance -- a
+    skipped step may leave nothing behind (statistics, moments, step count) that bends the next one."""
     _fresh()
     import geomapnet_amd as G
-    G.set_compute_dtype("fp16", loss_scale=2.0 ** 60)
+    G.set_compute_dtype(dtype_name, loss_scale=2.0 ** 60)
     try:
         onet, net = build_pair(lib, dev)
         c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
@@ -1242,9 +1244,23 @@ def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3):
         assert opt.learner.state_dict()["state"] == {} or int(opt.learner.state_dict()["state"][0]["step"]) == 0
         plan = next(iter(eng.plans.values()))
         lib.check(lib.set_loss_scale(plan["handle"], C.c_float(1024.0), 0))
-        G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)
+        l_rec, p_rec = G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)
         dev_sync(dev)
         assert eng.loss_scale_state() == (1024.0, 1 + more)
+        if dtype_name != "fp16":  # the recovery step against the oracle's FIRST step (no step has been applied before it)
+            oc = oracle.MapNetCriterion(0.0, -3.0, 0.0, -3.0, True, True)
+            oopt = oracle.Optimizer([{"params": onet.parameters()}, {"params": [oc.sax, oc.saq]}, {"params": [oc.srx, oc.srq]}],
+                                    "adam", base_lr=1e-3, weight_decay=5e-4)
+            onet.train()
+            lo, po = oracle.step_feedfwd(x.cpu(), onet, False, t.cpu(), oc, oopt, True, 0.0)
+            assert abs(l_rec - lo) <= 1e-4 * max(1.0, abs(lo)), (l_rec, lo)
+            assert (p_rec.cpu() - po.detach()).abs().max().item() <= 1e-3
+            # BatchNorm running statistics: the skipped forward passes DID update them (as the reference's would have: they are
+            # not part of the optimiser step), so only finiteness is asserted for them; parameters must match the oracle's
+            hp = dict(net.named_parameters())
+            for k, v in onet.named_parameters():
+                d_or = (v.detach() - hp[k].detach().cpu()).abs().max().item()
+                assert d_or <= 2.5e-3, (k, d_or)  # lr 1e-3, sign-like first Adam update: a flipped sign costs 2 lr
         assert not torch.equal(eng.params[:-4], p0[:-4]) and torch.isfinite(eng.params).all()
         assert int(opt.learner.state_dict()["state"][0]["step"]) == 1
         # a second plan (another batch size, e.g. the last partial batch of an epoch) continues from the APPLIED count, not
@@ -1256,6 +1272,79 @@ def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3):
         assert len(eng.plans) == 2 and int(opt.learner.state_dict()["state"][0]["step"]) == 2
         G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)  # ... and back on the first plan
         assert int(opt.learner.state_dict()["state"][0]["step"]) == 3
+    finally:
+        G.set_compute_dtype("fp16", loss_scale=1024.0)
+
+
+def check_overflow_progress_accounting(lib, dev, dtype_name="fp16", N=1, H=32, W=40):
+    """The host's overflow bookkeeping (net.hip poll_overflow) must act on what the DEVICE reports as completed, not on polls that
+    happened to see nothing new (round-4 ADVICE): (1) an isolated non-finite batch at loss scale 1 counts one stuck skip, polls that
+    observe no newly completed attempt neither clear it nor advance the scale-growth counter, the next APPLIED step clears it;
+    (2) the scale grows after `growth_interval` applied steps, not after that many polls; (3) permanently non-finite inputs at
+    scale 1 keep counting and Engine.check_overflow_progress raises."""
+    _fresh()
+    import geomapnet_amd as G
+    from geomapnet_amd._binding import MapNetHipError
+    G.set_compute_dtype(dtype_name, loss_scale=1.0)
+    try:
+        _, net = build_pair(lib, dev)
+        c = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
+        opt = G.Optimizer([{"params": net.parameters()}, {"params": [c.sax, c.saq]}, {"params": [c.srx, c.srq]}], "adam",
+                          base_lr=1e-4, weight_decay=5e-4)
+        net.train()
+        x, t = oracle.make_batch("mapnet", N, H, W, seed=7)
+        x, t = x.to(dev), t.to(dev)
+        bad = x.clone()
+        bad[0, 0, 0, 0, 0] = float("nan")
+        eng = net.mapnet._engine
+
+        def step(inp):
+            G.step_feedfwd(inp, net, dev != "cpu", t, c, opt, True)
+            dev_sync(dev)
+
+        step(x)  # creates the plan; applied
+        plan = next(iter(eng.plans.values()))
+        h = plan["handle"]
+        stuck = lambda: int(lib.stuck_overflow_steps(h))  # noqa: E731
+        lib.check(lib.set_loss_scale(h, C.c_float(1.0), 3))
+        p_before = eng.params.clone()
+        step(bad)  # skipped on the device; the host has not polled yet
+        assert torch.equal(eng.params[:-4], p_before[:-4]) and eng.loss_scale_state() == (1.0, 1)
+        assert stuck() == 0
+        # polls WITHOUT a completed attempt in between: mn_train_forward_loss polls, runs a forward pass, applies nothing
+        poses = torch.empty(plan["images"], 6, dtype=torch.float32, device=eng.device)
+        for i in range(4):
+            lib.check(lib.train_forward_loss(h, ptr(x), ptr(t.contiguous()), ptr(plan["loss"]), ptr(poses), None))
+            dev_sync(dev)
+            assert stuck() == 1, (i, stuck())                     # seen once, and NOT cleared by polls that observed nothing
+            assert eng.loss_scale_state()[0] == 1.0, (i, eng.loss_scale_state())  # ... which do not count towards growth either
+        step(x)   # applied (its own poll still saw nothing new: stuck stays 1 until the device reports the applied step)
+        assert stuck() == 1
+        step(x)   # this step's poll sees the applied attempt
+        assert stuck() == 0
+        # growth after 3 APPLIED steps (interval set above); two of them have completed and been seen so far
+        assert eng.loss_scale_state()[0] == 1.0
+        step(x)
+        step(x)
+        assert eng.loss_scale_state()[0] == 2.0, eng.loss_scale_state()
+        # permanently non-finite inputs: the scale comes down to 1 first, then every further skip is a stuck one
+        lib.check(lib.set_loss_scale(h, C.c_float(1.0), 0))
+        raised = False
+        try:  # (Engine._stepped samples the count every 16 steps: the raise may come from inside a step)
+            for _ in range(10):
+                step(bad)
+            assert stuck() >= 8, stuck()
+            eng.check_overflow_progress(plan)
+        except MapNetHipError:
+            raised = True
+        assert raised and stuck() >= 8, "ten consecutive skipped steps at loss scale 1 must raise"
+        try:
+            step(x)
+        except MapNetHipError:  # (the sampled check may fire once more before the applied step has been seen)
+            pass
+        step(x)
+        step(x)
+        assert stuck() == 0
     finally:
         G.set_compute_dtype("fp16", loss_scale=1024.0)
 

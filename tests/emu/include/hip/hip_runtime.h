@@ -111,6 +111,10 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
   *s = nullptr;
   return hipErrorUnknown;
 }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) {
+  *s = nullptr;
+  return hipErrorUnknown;
+}
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) {
   *d = 0;

@@ -85,6 +85,15 @@ def test_fp16_overflow_skips_the_step_and_lowers_the_scale(lib):
     checks.check_overflow_skip(lib, DEV, N=1, H=32, W=40, more=1)
 
 
+@pytest.mark.slow
+def test_parity_mode_overflow_recovery_step_meets_the_bar(lib):
+    checks.check_overflow_skip(lib, DEV, N=1, H=32, W=40, more=1, dtype_name="fp16x2m")
+
+
+def test_overflow_bookkeeping_acts_on_completed_attempts_not_on_polls(lib):
+    checks.check_overflow_progress_accounting(lib, DEV)
+
+
 def test_training_target_layout_is_validated_before_launch(lib):
     """a target of the wrong layout (MF batch handed to the online criterion, wrong window count) must raise on the host:
     the fused kernel would index it out of bounds"""

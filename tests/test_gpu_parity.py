@@ -324,6 +324,18 @@ def test_fp16_overflow_skips_the_step_and_lowers_the_scale(lib):
     checks.check_overflow_skip(lib, DEV, N=2, H=64, W=85, more=3)
 
 
+@pytest.mark.parametrize("dtype_name", ["fp16x2", "fp16x2m"])
+def test_parity_mode_overflow_skips_the_step_and_the_recovery_step_meets_the_bar(lib, dtype_name):
+    """the parity modes' gradients pass through fp16 halves under a loss scale: an overflowed step is skipped, the scale backs off,
+    and the first applied step afterwards is still the oracle's first step to 1e-4 / 1e-3"""
+    checks.check_overflow_skip(lib, DEV, N=2, H=64, W=85, more=3, dtype_name=dtype_name)
+
+
+@pytest.mark.parametrize("dtype_name", ["fp16", "fp16x2m"])
+def test_overflow_bookkeeping_acts_on_completed_attempts_not_on_polls(lib, dtype_name):
+    checks.check_overflow_progress_accounting(lib, DEV, dtype_name, N=2, H=64, W=85)
+
+
 # ---- BASELINE.json configurations at FULL size against the oracle, fp32 (north-star bar asserted) and fp16 (recorded) --
 def _record_parity(rec):
     import json

@@ -17,7 +17,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "scripts")]
 
 
-def train_and_eval(dtype, epochs, n_train, n_val, H, W, batch, lr, binding=None, log=lambda *a: None, seed=7):
+def train_and_eval(dtype, epochs, n_train, n_val, H, W, batch, lr, binding=None, log=lambda *a: None, seed=7, deterministic=False):
+    """deterministic: run under MN_DETERMINISTIC=1 (read when a plan is created): every step is bit-reproducible, so a (dtype, seed)
+    pair always trains to the same numbers and two dtypes differ by their arithmetic only, not by atomics' summation order"""
+    if deterministic:
+        old = os.environ.get("MN_DETERMINISTIC")
+        os.environ["MN_DETERMINISTIC"] = "1"
+        try:
+            return train_and_eval(dtype, epochs, n_train, n_val, H, W, batch, lr, binding, log, seed, False)
+        finally:
+            if old is None:
+                os.environ.pop("MN_DETERMINISTIC", None)
+            else:
+                os.environ["MN_DETERMINISTIC"] = old
     import numpy as np
     import torch
     # the DataLoader's collate (torch.stack of 48 small frames per step) runs on this thread: with the box's 128 cores as intra-op
@@ -68,15 +80,19 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--seeds", default="7", help="comma-separated [training] seeds (initial weights + data order); one run per seed")
+    ap.add_argument("--deterministic", action="store_true", help="MN_DETERMINISTIC=1: bit-reproducible steps")
     a = ap.parse_args()
     out = {"config": {"scene": "RenderedFrames scene_seed=1", "train_frames": a.train, "val_frames": a.val, "HxW": [a.height, a.width],
-                      "epochs": a.epochs, "windows_per_step": a.batch, "steps": a.epochs * (a.train // a.batch), "lr": a.lr}}
+                      "epochs": a.epochs, "windows_per_step": a.batch, "steps": a.epochs * (a.train // a.batch), "lr": a.lr,
+                      "deterministic": bool(a.deterministic)}}
     seeds = [int(v) for v in a.seeds.split(",")]
     for d in a.dtypes.split(","):
         runs = []
         for sd in seeds:
-            res, base = train_and_eval(d, a.epochs, a.train, a.val, a.height, a.width, a.batch, a.lr, seed=sd)
+            res, base = train_and_eval(d, a.epochs, a.train, a.val, a.height, a.width, a.batch, a.lr, seed=sd,
+                                       deterministic=a.deterministic)
             runs.append(dict(res, seed=sd))
+            print("# %s seed %d: median_t %.4f median_q %.3f" % (d, sd, res["median_t"], res["median_q"]), file=sys.stderr, flush=True)
         out[d] = runs[0] if len(runs) == 1 else {"runs": runs, "median_t": sum(r["median_t"] for r in runs) / len(runs),
                                                  "median_q": sum(r["median_q"] for r in runs) / len(runs)}
         out["baseline_predict_mean"] = base

@@ -9,7 +9,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${TAG:-cur}; R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof_$TAG; export TMPDIR=/tmp
 timeout 900 python bench.py ${BENCH_ARGS} > gpurun_out/prof_$TAG/bench.json 2> gpurun_out/prof_$TAG/bench.err; tail -1 gpurun_out/prof_$TAG/bench.json
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-events --no-parity-mode > $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-events --no-parity-mode --no-eval-metric > $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
 cp /tmp/prof_stats/r_kernel_stats.csv $R/gpurun_out/prof_$TAG/kernel_stats.csv
 python3 - <<PY
 import csv
@@ -25,7 +25,7 @@ with open('$R/gpurun_out/prof_$TAG/one_step_trace.csv','w') as f:
         w.writerow([round((int(r['Start_Timestamp'])-t0)/1e3,1), round((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3,1), r['Grid_Size_X'], r['Kernel_Name'][:110]])
 print('step wall us', (int(rows[e]['Start_Timestamp'])-int(rows[s]['Start_Timestamp']))/1e3)
 PY
-cd /tmp && MN_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o r -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-events --no-parity-mode >> $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
+cd /tmp && MN_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o r -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-events --no-parity-mode --no-eval-metric >> $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
 cp /tmp/prof_serial/r_kernel_stats.csv $R/gpurun_out/prof_$TAG/kernel_stats_serial.csv
 python3 - <<PY
 import csv, collections
@@ -38,11 +38,11 @@ with open('$R/gpurun_out/prof_$TAG/serial_by_grid.csv','w') as f:
         w.writerow([k[0],k[1],k[2],len(v),round(sum(v)/len(v),1),round(min(v),1),round(sum(v),1)])
 PY
 if [ -n "$X3" ]; then
-cd /tmp && MN_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_x3 -o r -- python $R/bench.py --dtype fp32x3 --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-events >> $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
+cd /tmp && MN_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_x3 -o r -- python $R/bench.py --dtype fp32x3 --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-events --no-eval-metric >> $R/gpurun_out/prof_$TAG/rocprof.log 2>&1
 cp /tmp/prof_x3/r_kernel_stats.csv $R/gpurun_out/prof_$TAG/kernel_stats_serial_fp32x3.csv
 fi
 if [ -n "$PMC" ]; then for c in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp && MN_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-events --no-parity-mode > /dev/null 2>&1
+  cd /tmp && MN_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -o r -- python $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-events --no-parity-mode --no-eval-metric > /dev/null 2>&1
   python3 - <<PY
 import csv, collections
 agg=collections.defaultdict(lambda:[0,0.0])

@@ -56,6 +56,7 @@ _PROTOS = {
     "mn_get_loss_scale": (c_i, [c_void, C.POINTER(c_f), C.POINTER(c_i64)]),
     "mn_debug_tensor": (c_i, [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(c_i64), C.POINTER(C.c_int32)]),
     "mn_set_dropout": (c_i, [c_void, c_f, C.c_uint64]),
+    "mn_set_dropout_calls": (c_i, [c_void, C.c_uint32]),
     "mn_set_input_u8": (c_i, [c_void, c_i, C.POINTER(c_f), C.POINTER(c_f)]),
     "mn_forward": (c_i, [c_void, c_void, c_void, c_i, c_void]),
     "mn_loss": (c_i, [c_void, c_void, c_void, c_void, c_void]),
@@ -70,6 +71,7 @@ _PROTOS = {
     "mn_op_igemm": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_void, c_i, c_void, c_void,
                           c_f, c_void, c_void]),
     "mn_op_igemm_grid_m": (c_i, [c_i]),
+    "mn_op_igemm_fbn": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_void, c_i, c_void]),
     "mn_op_wgrad": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_i, c_void, c_void, c_i, c_void, c_f, c_i, c_void, c_void]),
     "mn_op_wgrad_ws_floats": (c_i64, []),
     "mn_op_wgrad_ws": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_i, c_void, c_void, c_i, c_f, c_void, c_i64, c_void, c_void]),

@@ -82,7 +82,7 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
 static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
                                                                         half* __restrict__ out, unsigned char* __restrict__ idx,
                                                                         int B, int H, int W, int C, int Po, int Qo,
-                                                                        half* __restrict__ out16) {
+                                                                        half* __restrict__ out16, half* __restrict__ y16) {
   constexpr int VEC = 8;
   const int cpr = C / VEC;
   float s_scale[VEC], s_shift[VEC];
@@ -130,6 +130,9 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const fl
         v0.p = src[0];
         v1.p = src[1];
         const float raw[VEC] = {v0.e[0], v0.e[1], v0.e[2], v0.e[3], v1.e[0], v1.e[1], v1.e[2], v1.e[3]};
+        // y16 (fp16x2m): plain fp16 copy of the conv output for the stem's fp16 backward kernels (stem_bwd.h).  Every pixel is
+        // written exactly once: by the window whose taps r, s in {1, 2} cover it (pixel (h, w) -> window (h >> 1, w >> 1))
+        if (y16 && r >= 1 && s >= 1) f16_store8(y16, (long)(b * H + h) * W + w, C, cp * VEC, raw);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float f = fmaxf(raw[e] * s_scale[e] + s_shift[e], 0.f);

@@ -57,6 +57,9 @@ struct GatherGeom {
   // matrix-core arithmetic for fp32 tensors (common.h MMA_*; not part of the C ABI of the operator entry points, which
   // set it from their dtype argument): ignored by the fp16 kernels
   int mma = MMA_NATIVE;
+  // EXPERIMENT (round 5, igemm_halo.h FBN; not part of the C ABI): per-channel (scale | shift) [2][C] of a BatchNorm whose
+  // normalise + ReLU is applied to the A operand INSIDE the convolution -- A is then the raw conv output of the layer below
+  const float* a_bn = nullptr;
 };
 
 // n / d for 0 <= n < 2^31 without the ~35-instruction software division (Granlund-Montgomery round-up

@@ -48,7 +48,13 @@ namespace mn {
 // requested when the last K-step of the current chunk has been read (one barrier, its latency exposed once per chunk) -- so that
 // a 192-row tile of 4 waves needs 63 KB of LDS and TWO workgroups share a CU: each one's prologue, image reload and epilogue run
 // under the other's MFMAs.
-template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4, bool A1 = false>
+// FBN (round 5, an experiment the reviews of rounds 2-4 asked for; fp16 only): the consumer-side BatchNorm fusion.  A is the RAW conv
+// output of the layer below and the BatchNorm apply + ReLU that would have produced this convolution's input runs on every A
+// FRAGMENT after its LDS read: per-channel (scale, shift) as fp16 pairs in a small LDS table (g.a_bn; two broadcast ds_read_b128 per
+// 16-k sub-step), 4 v_pk_fma_f16 + 4 v_pk_max_f16 + 4 selects per fragment -- the select because an out-of-image tap must be zero
+// AFTER the affine map (the zero slot would otherwise read as relu(shift)).  Measured per launch against conv + bn_apply launches:
+// profiles/r05 (consumer-side BatchNorm fusion); not used by the plan.
+template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4, bool A1 = false, bool FBN = false>
 static __global__ void __launch_bounds__(WM* WN * 64, (A1 ? 2 : 1) * WM* WN / 4) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
@@ -57,11 +63,13 @@ static __global__ void __launch_bounds__(WM* WN * 64, (A1 ? 2 : 1) * WM* WN / 4)
   static_assert(TN == 1 || TN == 2, "wave tiles of 96 x 32 or 96 x 64");
   constexpr int NBS = 2, NIMG = A1 ? 1 : 2, A_IMG = kAH * NP, B_SLOT = BN * NP, RING = NIMG * A_IMG + NBS * B_SLOT;  // pieces
   constexpr int SC = BN < 128 ? BN : 128;  // columns staged per epilogue round
-  static_assert((RING + 1 + WM * BN / 2) * 16 <= (A1 ? 80 : 160) * 1024, "LDS");
+  constexpr int FTAB = FBN ? (BN == 256 ? 64 : 128) : 0;  // (scale piece, shift piece) per 8 channels: C <= 256 / 512
+  static_assert(!FBN || !H2, "fp16 only");
+  static_assert((RING + 1 + WM * BN / 2 + FTAB) * 16 <= (A1 ? 80 : 160) * 1024, "LDS");
   static_assert(RING * 16 >= WM * 32 * SC * 4, "epilogue staging (the ring is free by then)");
   constexpr int A_PASSES = (kAH + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;   // 4, 3
   static_assert(A1 || A_PASSES <= 9, "one image pass per K-step of the chunk before");
-  __shared__ piece_t smem[RING + 1 + WM * BN / 2];
+  __shared__ piece_t smem[RING + 1 + WM * BN / 2 + FTAB];
   float* red = reinterpret_cast<float*>(&smem[RING + 1]);  // [WM][BN][2]
 
   const int t = threadIdx.x, lane = t & 63;
@@ -73,6 +81,18 @@ static __global__ void __launch_bounds__(WM* WN * 64, (A1 ? 2 : 1) * WM* WN / 4)
   const int W = g.Wi, halo = W + 1;
   const int NCH = g.C / 64, KT = (ABL & 2) ? 1 : 9 * NCH;
   if (t == 0) smem[RING] = zero_piece();
+  if constexpr (FBN) {  // table[2 p] = scale of channels 8p .. 8p+7, table[2 p + 1] = their shift (fp16)
+    if (t < g.C / 8) {
+      PieceView<half> sc, sh;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc.e[e] = (half)g.a_bn[t * 8 + e];
+        sh.e[e] = (half)g.a_bn[g.C + t * 8 + e];
+      }
+      smem[RING + 1 + WM * BN / 2 + 2 * t] = sc.p;
+      smem[RING + 1 + WM * BN / 2 + 2 * t + 1] = sh.p;
+    }
+  }
   // lgkmcnt(0): the store has reached LDS before this wave arrives at the K loop's first barrier (a raw s_barrier does
   // not wait for outstanding LDS writes), after which every wave may read the slot
   __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -231,6 +251,18 @@ static __global__ void __launch_bounds__(WM* WN * 64, (A1 ? 2 : 1) * WM* WN / 4)
     for (int ks = 0; ks < NP / 2; ++ks) {
       if (ks + 1 < NP / 2 && ((ABL & 8) == 0 || kt == 0)) load_frags(ks + 1, (ks + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (FBN) {  // BatchNorm apply + ReLU of the layer below, on this sub-step's A fragments
+        PieceView<half> sc, sh;
+        const int tp = (chunk * 8 + ks * 2 + hi) * 2;
+        sc.p = smem[RING + 1 + WM * BN / 2 + tp];
+        sh.p = smem[RING + 1 + WM * BN / 2 + tp + 1];
+        const half8 zero8 = {(half)0, (half)0, (half)0, (half)0, (half)0, (half)0, (half)0, (half)0};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          half8 v = __builtin_elementwise_max(__builtin_elementwise_fma(fa[ks & 1][i].v, sc.v, sh.v), zero8);
+          fa[ks & 1][i].v = ainv[i] ? zero8 : v;
+        }
+      }
       if constexpr ((ABL & 16) == 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -436,6 +468,19 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
   static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
 #endif
   static const int a1 = getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1;
+  if (g.a_bn) {  // FBN experiment: the two 12-wave shapes only (256 columns with C <= 256, else 128 columns with C <= 512)
+    if (g.N % 256 == 0 && g.C <= 256 && igemm_halo_applies(g, ep, 256, 352)) {
+      hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, false, 3, 4, false, true>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A,
+                         Bw, ep, g.N / 256, rd);
+      return gm;
+    }
+    if (g.C <= 512 && igemm_halo_applies(g, ep, 128, 384)) {
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, false, 3, 4, false, true>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A,
+                         Bw, ep, g.N / 128, rd);
+      return gm;
+    }
+    return -1;
+  }
   if (level >= 1 && tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) {
 #ifdef MN_ABLATION_BUILD
 #define MN_HALO_ABL(BN_, AH_, V_)                                                                                          \

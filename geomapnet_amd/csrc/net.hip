@@ -337,6 +337,7 @@ struct Plan : PlanBase {
   Unit stem;
   T *a0, *ga0, *p0, *gp0;
   half* p0_16 = nullptr;  // fp16x2m: plain fp16 copy of the pooled stem activation
+  half* xpad16 = nullptr;   // fp16x2m: fp16 copy of the padded NHWC4 input (the stem's fp16 backward kernels, stem_bwd.h)
   int H0, W0, H1, W1;  // stem conv output, pooled output
   std::vector<Block> blocks;
   int Hl, Wl;  // last feature map
@@ -428,7 +429,10 @@ struct Plan : PlanBase {
     p0 = (T*)A(n1 * sizeof(T));
     gp0 = (T*)A(n1 * sizeof(T));
     pool_idx = (unsigned char*)A(n1);
-    if (mixed) p0_16 = (half*)A(n1 * sizeof(half));
+    if (mixed) {
+      p0_16 = (half*)A(n1 * sizeof(half));
+      xpad16 = (half*)A((size_t)B * Hp * Wp * 4 * sizeof(half));
+    }
     const T* x = p0;
     T* gx = gp0;
     const half* x16 = p0_16;
@@ -779,6 +783,14 @@ struct Plan : PlanBase {
     else
       hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
                          (const float*)images, xpad, B, H, W, Hp, Wp);
+    if (stem_bwd_f16() && training) {  // fp16x2m: the stem's backward kernels read an fp16 image of the input
+      if (input_u8)
+        hipLaunchKernelGGL((u8nhwc_to_padded_nhwc4_kernel<half>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
+                           (const unsigned char*)images, xpad16, B, H, W, Hp, Wp, input_norm);
+      else
+        hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<half>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
+                           (const float*)images, xpad16, B, H, W, Hp, Wp);
+    }
     // forked AFTER the (HBM-bound) input conversion, so that the side stream's copies run beside the stem's MFMA-bound
     // convolution instead of competing with the conversion for bandwidth (step time: equal within noise)
     if (dirty || zero_grads) {
@@ -791,7 +803,7 @@ struct Plan : PlanBase {
       bn_finalize(stem, s);
       hipLaunchKernelGGL(bn_relu_maxpool_h2_kernel, dim3(ew_grid((long)B * H1 * W1 * 64 / 8)), dim3(256), 0, s,
                          (const float*)stem.y, (const float*)stem.coef_f, (half*)p0, pool_idx, B, H0, W0, 64, H1, W1,
-                         training ? p0_16 : (half*)nullptr);
+                         training ? p0_16 : (half*)nullptr, training && stem_bwd_f16() ? (half*)a0 : (half*)nullptr);
     } else if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
       bn_finalize(stem, s);
       hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
@@ -975,7 +987,8 @@ struct Plan : PlanBase {
     // (fp16x2m: gates and the weight gradients' X operands are the plain fp16 copies; typed T* for the shared call sites)
     const T* bx = mixed ? (const T*)blk.x16 : blk.x;
     const T* ba1 = mixed ? (const T*)blk.a1_16 : blk.a1;
-    const T* below = &blk == &blocks.front() ? nullptr : bx;
+    // (fp16x2m with the fp16 stem kernels: the gradient of the pooled stem activation leaves layer1.0 gated by that activation)
+    const T* below = &blk == &blocks.front() ? (stem_bwd_f16() ? bx : nullptr) : bx;
     const T* og = nullptr;  // (bn2 / the projection / the identity path take `gout` as stored: already gated)
     if (wgrad_sched == 2) {
       flush_wgrads(s);
@@ -1058,15 +1071,24 @@ struct Plan : PlanBase {
   }
   // (MN_DETERMINISTIC: the stem's backward goes through bn_bwd + the split-slice weight gradient instead)
   bool use_stem_bwd = DT == MN_F16 && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
+  // fp16x2m: the same two kernels on fp16 COPIES of the fp32 conv output (written by the stem's BatchNorm + max-pool pass) and of
+  // the padded input, with the pooled gradient arriving already gated (StemBwdArgs::pre_gated); MN_STEM_BWD=0 / MN_DETERMINISTIC
+  // keep the fp32 chain of fp16x2
+  bool stem_bwd_f16() const {
+    return mixed && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
+  }
   void stem_backward(hipStream_t s) {
-    if (use_stem_bwd) {
+    if (use_stem_bwd || stem_bwd_f16()) {
+      const bool mx = stem_bwd_f16();
       // two tile-walking launches (stem_bwd.h): BatchNorm sums, then the weight gradient with d(conv output) computed tile
       // by tile in LDS -- neither the max-pool's input gradient nor d(conv output) is stored
       StemBwdArgs a;
-      a.y = (const half*)stem.y; a.idx = pool_idx; a.gp = (const half*)gp0; a.gamma = params + stem.bp.gamma;
+      a.y = mx ? (const half*)a0 : (const half*)stem.y; a.idx = pool_idx; a.gp = (const half*)gp0; a.gamma = params + stem.bp.gamma;
       a.beta = params + stem.bp.beta; a.coef = stem.coef_b; a.mean = stem.mean; a.invstd = stem.invstd; a.accum = stem.accum_b;
-      a.accum_rows = stem.rows_b; a.xpad = (const half*)xpad; a.dW = grads + stem.cp.w; a.colmap = stem_colmap; a.ldw = stem.ldw;
+      a.accum_rows = stem.rows_b; a.xpad = mx ? (const half*)xpad16 : (const half*)xpad; a.dW = grads + stem.cp.w;
+      a.colmap = stem_colmap; a.ldw = stem.ldw;
       a.alpha = 1.f / cur_scale;
+      a.pre_gated = mx ? 1 : 0;
       launch_stem_bn_reduce(a, B, H, W, Wp, s);
       hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(64 / kBnFinalizeChannels), dim3(256), 0, s, (const double*)stem.accum_b, (double)stem.M,
                          (const float*)(params + stem.bp.gamma), (const float*)stem.mean, (const float*)stem.invstd,
@@ -1371,6 +1393,11 @@ extern "C" int mn_set_dropout(mn_handle* h, float p, uint64_t seed) {
   P.drop_p = p;
   P.drop_seed = seed;
   P.drop_calls = 0;
+  return 0;
+}
+extern "C" int mn_set_dropout_calls(mn_handle* h, uint32_t calls) {
+  MN_H(h);
+  P.drop_calls = calls;
   return 0;
 }
 extern "C" int mn_set_input_u8(mn_handle* h, int enable, const float* mean, const float* std) {

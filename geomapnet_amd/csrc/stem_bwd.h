@@ -44,6 +44,10 @@ struct StemBwdArgs {
   const int* colmap;         // wgrad: [224] compute column -> dense column or -1
   int ldw;
   float alpha;               // wgrad: 1 / loss scale
+  // gp arrives ALREADY multiplied by the stem's ReLU gate (fp16x2m: the producer of gp -- layer1.0's data gradient -- gates it with
+  // the pooled activation, gate(window) = pooled value > 0 = the activation at the window's argmax > 0, which is exact; y is then an
+  // fp16 COPY of the fp32 conv output, whose recomputed sign would flip for values within 2^-12 of the threshold): do not recompute
+  int pre_gated = 0;
   int B, Hp, Wp2, H0, W0, Po, Qo, tiles_x, tiles_y;
 };
 
@@ -200,7 +204,7 @@ static __global__ void __launch_bounds__(512, 2) stem_bn_reduce_kernel(StemBwdAr
       const int r = (tap * 11) >> 5, sx = tap - 3 * r;  // tap = 3 r + s, tap <= 8
       const float yv = (float)yt[base + (r * kSrCW + sx) * 64 + e];
       float gv = cur.ok ? (float)cur.g.e[e] : 0.f;
-      if (!(yv * sc[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
+      if (!a.pre_gated && !(yv * sc[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
       s1[e] += gv;
       s2[e] += gv * (yv - mu[e]) * is[e];
     }
@@ -338,7 +342,7 @@ static __global__ void __launch_bounds__(256, 2) stem_wgrad_kernel(StemBwdArgs a
       for (int e = 0; e < 8; ++e) {
         const float yv = (float)vy[i].e[e];
         float gv = g[e];
-        if (!(yv * k1[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
+        if (!a.pre_gated && !(yv * k1[e] + sh[e] > 0.f)) gv = 0.f;  // ReLU gate recomputed from the conv output (the forward's arithmetic)
         const float xh = (yv - mu[e]) * is[e];
         o.e[e] = ok ? (half)(k1[e] * (gv - mg[e] - xh * mgx[e])) : (half)0.f;
       }

@@ -136,6 +136,8 @@ class Engine:
             return
         self._read_step()
         self.lib.check(self.lib.set_step_count(p["handle"], self.step_count))
+        if self.dropout[0] > 0.0:  # the mask sequence continues from the model's step count, not from this plan's call 0
+            self.lib.check(self.lib.set_dropout_calls(p["handle"], self.step_count & 0xffffffff))
         self._step_owner = p
 
     def __del__(self):

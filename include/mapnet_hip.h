@@ -155,6 +155,11 @@ int mn_forward(mn_handle* h, const void* images, float* poses_out, int training,
  * and counter (element / 4, number of training forward passes since this call): reproducible, independent of launch shapes, and
  * readable after a step as mn_debug_tensor "dropmask" ([images][feat_dim] floats, 0 or 1 / (1 - p)). */
 int mn_set_dropout(mn_handle* h, float p, uint64_t seed);
+/* The Philox counter's "training forward passes so far" of this plan (mn_set_dropout resets it to 0).  A host that runs several
+ * plans of one model (another batch size for the last partial batch of an epoch) or resumes from a checkpoint sets it to its own
+ * count of steps when a plan takes over, so that no plan replays the mask sequence from 0; data-parallel ranks pass different
+ * seeds (scripts/train.py: seed ^ rank << 32) so that replicas do not drop the same features. */
+int mn_set_dropout_calls(mn_handle* h, uint32_t calls);
 
 /* Device-side input pipeline (replaces torchvision's ToTensor + Normalize of the reference's transforms,
  * scripts/train.py:120-128): with enable != 0 the `images` argument of mn_forward / mn_train_step /
@@ -226,6 +231,10 @@ typedef struct mn_gather_geom {
  * the image are zero-filled by the hardware bounds check.  zero_page: >= 16 zero bytes in device memory,
  * 16-byte aligned; required (the weight-gradient kernels that gather strided convolutions read their
  * out-of-image taps from it; mn_op_igemm accepts it for symmetry). */
+/* EXPERIMENT (round 5, not used by the plans): out = conv3x3 stride 1 (relu(A * scale[c] + shift[c]), Bw) in fp16 with the
+ * BatchNorm apply + ReLU of the producing layer fused into the convolution's operand path; coef = [2][C] floats (scale | shift).
+ * The consumer-side fusion of SURVEY.md section 7 step 5, measured against the conv + bn_apply launches it would replace. */
+int mn_op_igemm_fbn(const mn_gather_geom* g, const void* A, const float* coef, const void* Bw, void* out, int ldc, void* stream);
 int mn_op_igemm(int dtype, const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
                 const float* bias, int relu, const void* res, const void* res_gate, float alpha, const void* zero_page,
                 void* stream);

@@ -78,6 +78,12 @@ def _init_distributed():
     return world
 
 
+def _rank():
+    """data-parallel rank (0 outside a launcher): mixed into the dropout key so that replicas do not draw identical masks"""
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else int(os.environ.get("RANK", "0"))
+
+
 def run(args, datasets=None, _binding=None, log=print):
     """builds everything the reference's script builds and runs Trainer.train_val; returns the Trainer.
     `_binding` (tests) substitutes another build of the kernel library for libmapnet_hip.so."""
@@ -130,7 +136,7 @@ def run(args, datasets=None, _binding=None, log=print):
     print("ResNet-34 weights: %s" % ("ImageNet (%s)" % zoo_file if pretrained else "random initialisation"))
     feature_extractor = G.resnet34(pretrained=pretrained, **kw)
     posenet = G.PoseNet(feature_extractor, droprate=dropout, pretrained=pretrained, filter_nans=(args.model == "mapnet++"),
-                        dropout_active=args.dropout_active, dropout_seed=seed, **kw)
+                        dropout_active=args.dropout_active, dropout_seed=seed ^ (_rank() << 32), **kw)
     model = posenet if args.model == "posenet" else G.MapNet(mapnet=posenet)
 
     if args.u8_input:  # the DataLoader ships decoded frames; normalisation happens in the input-conversion kernel

@@ -133,6 +133,33 @@ def check_conv_fwd(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, seed=0):
     assert ((s2 - (ref ** 2).sum((0, 2, 3))).abs() / (ref ** 2).sum((0, 2, 3))).max().item() <= 1e-4
 
 
+def check_conv_fbn(lib, dev, B, H, W, Cin, Cout, seed=31):
+    """igemm_halo.h FBN (experiment): conv3x3(relu(y * scale + shift), w) with the BatchNorm apply + ReLU fused into the
+    convolution's operand path, against torch fp64 on the fp16 activation the unfused path would have stored.  Border taps
+    must be zero AFTER the affine map (a positive shift would otherwise leak relu(shift) into the halo)."""
+    _fresh()
+    gen = torch.Generator().manual_seed(seed)
+    y = torch.randn(B, Cin, H, W, generator=gen).half().float()
+    scale = (0.5 + torch.rand(Cin, generator=gen)) * torch.where(torch.rand(Cin, generator=gen) < 0.2, -1.0, 1.0)
+    shift = torch.randn(Cin, generator=gen) * 0.5 + 0.3  # mostly positive: relu(shift) != 0 at the borders if unmasked
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * (2.0 / (Cin * 9)) ** 0.5).half().float()
+    sc16, sh16 = scale.half().float(), shift.half().float()
+    a = torch.relu(y * sc16.view(1, -1, 1, 1) + sh16.view(1, -1, 1, 1)).half().float()  # what an fp16 FMA + max produces (up to double rounding)
+    ref = F.conv2d(a.double(), w.double(), padding=1)
+    g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, 3, 1, 1)
+    yn = y.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    wn = w.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    coef = torch.cat((scale, shift)).float().to(dev)
+    out = torch.zeros(B, Ho, Wo, Cout, dtype=torch.float16, device=dev)
+    lib.check(lib.op_igemm_fbn(C.byref(g), K(yn), K(coef), K(wn), K(out), Cout, None))
+    dev_sync(dev)
+    o = out.cpu().double().permute(0, 3, 1, 2)
+    sc = ref.abs().max().item()
+    err = (o - ref).abs().max().item()
+    assert err <= 4e-3 * sc + 1e-6, (err, sc)
+    return err / sc
+
+
 def check_conv_dgrad(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, with_res=True, seed=1):
     _fresh()
     td = TD[dtype]

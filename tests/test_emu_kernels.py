@@ -24,6 +24,15 @@ def test_conv_forward(lib, dtype, shape):
     checks.check_conv_fwd(lib, DEV, dtype, *shape)
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 6, 7, 128, 256),    # 256-column shape, two 64-channel chunks
+    (1, 5, 9, 192, 128),    # 128-column shape, three chunks
+])
+def test_conv_with_the_batchnorm_apply_fused_into_its_operand_path(lib, shape):
+    """igemm_halo.h FBN (round-5 experiment, not used by the plan)"""
+    checks.check_conv_fbn(lib, DEV, *shape)
+
+
 @pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1),

@@ -299,25 +299,31 @@ def test_dropout_on_the_device_with_the_oracle_applying_the_same_mask(lib, dtype
 
 def test_fp16_trains_to_the_accuracy_of_the_parity_mode():
     """BASELINE's metric names "median t/q err": a learnable synthetic scene (data.RenderedFrames) trained for 1280 steps through
-    scripts/train.py -> scripts/eval.py in fp16 and in fp16x2 from identical seeds; both must learn (errors below 0.6 of what
-    predicting the mean training pose scores: 1.00 / 35.6 deg) and fp16 must stay within 4x of the parity mode on both numbers.
-    The margins are those of ONE run per mode: the step is not bit-reproducible and Adam at lr 1e-3 amplifies that, so single
-    runs of either mode spread over 0.12-0.26 / 5.7-14.5 deg (twelve runs: profiles/r04/c23_*, and the eval_metric legs of
-    c27 / c37 / c43_bench_default.json, where one pair came out 14.5 against 5.7 deg); over three seeds the two modes are
-    indistinguishable, 0.19 / 7.9 deg against 0.17 / 8.2 deg."""
+    scripts/train.py -> scripts/eval.py in fp16 and in the parity mode (fp16x2m), FIVE seeds each, under MN_DETERMINISTIC=1 -- every
+    step is bit-reproducible, so a (mode, seed) pair always trains to the same numbers and the two modes differ by their arithmetic
+    only, not by the summation order of atomics (rounds 3-4 compared single irreproducible runs with a 4x margin).  Asserted on the
+    MEANS over the seeds: both modes learn (below 0.4 of what predicting the mean training pose scores: 1.00 / 35.6 deg) and fp16 stays
+    within 1.3x of the parity mode on both numbers.  The margin is 1.5 sigma of the ratio of two five-seed means (single seeds spread
+    with a standard deviation of ~30 % in either mode; recorded run, profiles/r05/accuracy_deterministic_five_seeds.json: fp16
+    0.216 / 10.1 deg, fp16x2m 0.205 / 10.7 deg, fp16x2 0.253 / 13.2 deg)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import accuracy_eval
-    res = {}
-    for d in ("fp16", "fp16x2"):
-        res[d], base = accuracy_eval.train_and_eval(d, 40, 512, 128, 64, 85, 16, 1e-3)
+    seeds = (7, 8, 9, 10, 11)
+    res, mean = {}, {}
+    for d in ("fp16", "fp16x2m"):
+        res[d] = []
+        for sd in seeds:
+            r, base = accuracy_eval.train_and_eval(d, 40, 512, 128, 64, 85, 16, 1e-3, seed=sd, deterministic=True)
+            res[d].append(dict(r, seed=sd))
+        mean[d] = {k: sum(r[k] for r in res[d]) / len(seeds) for k in ("median_t", "median_q")}
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "accuracy_fp16_vs_fp16x2.json"), "w") as f:
-            json.dump({"fp16": res["fp16"], "fp16x2": res["fp16x2"], "baseline_predict_mean": base}, f)
-    for d in res:
-        assert res[d]["median_t"] < 0.6 * base["median_t"] and res[d]["median_q"] < 0.6 * base["median_q"], (d, res[d], base)
-    assert res["fp16"]["median_t"] <= 4.0 * res["fp16x2"]["median_t"], res
-    assert res["fp16"]["median_q"] <= 4.0 * res["fp16x2"]["median_q"], res
+        with open(os.path.join(out, "accuracy_fp16_vs_fp16x2m_five_seeds.json"), "w") as f:
+            json.dump({"runs": res, "means": mean, "baseline_predict_mean": base}, f)
+    for d in mean:
+        assert mean[d]["median_t"] < 0.4 * base["median_t"] and mean[d]["median_q"] < 0.4 * base["median_q"], (d, mean[d], base)
+    assert mean["fp16"]["median_t"] <= 1.3 * mean["fp16x2m"]["median_t"], mean
+    assert mean["fp16"]["median_q"] <= 1.3 * mean["fp16x2m"]["median_q"], mean
 
 
 def test_fp16_overflow_skips_the_step_and_lowers_the_scale(lib):

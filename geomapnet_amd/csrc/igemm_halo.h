@@ -54,10 +54,14 @@ namespace mn {
 // 16-k sub-step), 4 v_pk_fma_f16 + 4 v_pk_max_f16 + 4 selects per fragment -- the select because an out-of-image tap must be zero
 // AFTER the affine map (the zero slot would otherwise read as relu(shift)).  Measured per launch against conv + bn_apply launches:
 // profiles/r05 (consumer-side BatchNorm fusion); not used by the plan.
-// OCC (round 5): workgroups per CU the shape is built for.  A1 with OCC = 1 = the BIG single-image tiles: 576 rows x 128 (64)
-// columns of 12 waves (6 x 2 of 96 x 64 / 96 x 32).  Why: the B slices of a tile are the layer's WHOLE weight matrix, re-streamed
-// through LDS-DMA by every tile -- for layer2 590 KB (h2) / 295 KB (fp16) per 192-row tile against 147 / 74 KB of A image -- and
-// these launches run at the ~20 B/clk/CU the DMA path sustains; twice to three times the rows per tile halve the bytes per MFMA.
+// OCC: workgroups per CU the shape is built for (LDS budget, register cap).
+// (Measured and removed, round 5: BIG single-image tiles -- A1 with OCC = 1, 576 rows x 128 / 64 columns of 12 waves, 6 x 2 of
+// 96 x 64 / 96 x 32, and 384 rows of 8 waves for layer1.  The idea: the B slices of a tile are the layer's WHOLE weight matrix,
+// re-streamed through LDS-DMA by every tile -- for layer2 590 KB (h2) / 295 KB (fp16) per 192-row tile against 147 / 74 KB of A
+// image -- so three times the rows per tile cut the DMA bytes per MFMA by 40-58 %.  Per launch at 192 images
+// (profiles/r05/c4_big_single_image_tiles_per_launch.txt): fp16 layer2 90.2 -> 104.3 us forward, 87.1 -> 93.2 data gradient; h2
+// layer2 213 -> 224, h2 layer1 305 -> 331 (576 rows) / 341 (384 rows); layer4's 120 tiles are half a round, 83 -> 127 us.  DMA
+// bytes are not what bounds these launches; a single image exposes its reload once per chunk with nothing beside it on the CU.)
 template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4, bool A1 = false, bool FBN = false,
           int OCC = (A1 ? 2 : 1)>
 static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
@@ -109,9 +113,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
   static_assert(RPP % 16 == 0, "swizzle");
 
   // DMA state: byte offset of this thread's row in every pass (all ones = outside the tensor: the bounds check returns 0)
-  // (images of more than four passes -- the big single-image tiles -- recompute a pass's offset when it is issued, once per chunk,
-  //  instead of holding seven of them: the 6 x 2 shapes spilled 40 registers with the array)
-  constexpr bool A_OFF_REGS = A_PASSES <= 4;
+  // (a shape whose image takes more than twelve passes would recompute a pass's offset when it is issued instead of holding it)
+  constexpr bool A_OFF_REGS = A_PASSES <= 12;
   unsigned a_off[A_OFF_REGS ? A_PASSES : 1], b_off[B_PASSES];
   auto a_offset = [&](int i) -> unsigned {
     const int pix = m0 - halo + lrow + i * RPP;
@@ -508,19 +511,6 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A, Bw, ep, g.N / 256, rd);
     return gm;
   }
-  // BIG single-image tiles (see OCC above), MN_HALO_BIG bit 0: the 128-column layers with rows of <= 47 pixels (layer2: 672-row image),
-  // bit 1: rows of <= 23 pixels (layer3: 624-row image, 118 x 2 = 236 tiles = one round)
-  static const int big = getenv("MN_HALO_BIG") ? atoi(getenv("MN_HALO_BIG")) : 0;
-  if (level >= 2 && (big & 2) && igemm_halo_applies(g, ep, 128, 624, 576)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<128, 624, 0, 1, false, 6, 2, true, false, 1>), dim3(cdiv(g.M, 576) * (g.N / 128)), dim3(768), 0,
-                       stream, g, A, Bw, ep, g.N / 128, rd);
-    return cdiv(g.M, 576);
-  }
-  if (level >= 2 && (big & 1) && igemm_halo_applies(g, ep, 128, 672, 576)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<128, 672, 0, 1, false, 6, 2, true, false, 1>), dim3(cdiv(g.M, 576) * (g.N / 128)), dim3(768), 0,
-                       stream, g, A, Bw, ep, g.N / 128, rd);
-    return cdiv(g.M, 576);
-  }
   // 192-row tiles of 4 waves (2 x 2 of 96 x 64) with ONE A image (the next chunk's image requested after the chunk's last K-step):
   // 70 KB of LDS, so two workgroups share a CU and each one's prologue / image reload / epilogue runs under the other's MFMAs --
   // for the 128-column layers with at least two rounds of such tiles (layer2 at 192 images: 1376 tiles).  Round 4, same-box A/B
@@ -584,29 +574,6 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
     hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 256, rd);
     return gm;
-  }
-  // BIG single-image tiles (igemm_halo_kernel OCC), MN_H2_HALO_BIG bit 0: layer2 (128 columns, rows <= 47 pixels), bit 1: layer3
-  // (rows <= 23 pixels), bit 2: layer1 (64 columns, rows <= 87 pixels, 576-row tiles), bit 3: layer1 on 384-row tiles of 8 waves
-  static const int big = getenv("MN_H2_HALO_BIG") ? atoi(getenv("MN_H2_HALO_BIG")) : 0;
-  if ((big & 2) && g2.N % 128 == 0 && igemm_halo_applies(g2, ep, 128, 624, 576)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<128, 624, 0, 1, true, 6, 2, true, false, 1>), dim3(cdiv(g2.M, 576) * (g2.N / 128)), dim3(768), 0,
-                       stream, g2, A, Bw, ep, g2.N / 128, rd);
-    return cdiv(g2.M, 576);
-  }
-  if ((big & 1) && g2.N % 128 == 0 && igemm_halo_applies(g2, ep, 128, 672, 576)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<128, 672, 0, 1, true, 6, 2, true, false, 1>), dim3(cdiv(g2.M, 576) * (g2.N / 128)), dim3(768), 0,
-                       stream, g2, A, Bw, ep, g2.N / 128, rd);
-    return cdiv(g2.M, 576);
-  }
-  if ((big & 4) && g2.N == 64 && igemm_halo_applies(g2, ep, 64, 752, 576)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<64, 752, 0, 1, true, 6, 2, true, false, 1>), dim3(cdiv(g2.M, 576)), dim3(768), 0, stream, g2, A, Bw,
-                       ep, 1, rd);
-    return cdiv(g2.M, 576);
-  }
-  if ((big & 8) && g2.N == 64 && igemm_halo_applies(g2, ep, 64, 560, 384)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<64, 560, 0, 1, true, 4, 2, true, false, 1>), dim3(cdiv(g2.M, 384)), dim3(512), 0, stream, g2, A, Bw,
-                       ep, 1, rd);
-    return cdiv(g2.M, 384);
   }
   // layer1 (64 -> 64 channels, rows of up to 87 pixels): 192-row tiles of 4 waves, one A image, two workgroups per CU
   static const bool halo64 = !(getenv("MN_H2_HALO64") && atoi(getenv("MN_H2_HALO64")) == 0);

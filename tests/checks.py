@@ -1540,8 +1540,9 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
     return rec
 
 
-def check_loss_trajectory(lib, dev, N=8, H=256, W=341, steps=50, lr=1e-4, envelope=0.25):
-    """Does the fp16 build TRAIN like the parity mode?  Two HIP models (fp16 and fp32x3), identical initial weights and one
+def check_loss_trajectory(lib, dev, N=8, H=256, W=341, steps=50, lr=1e-4, envelope=0.25, modes=("fp16", "fp32x3"), extra=()):
+    """(modes = (tested, reference); `extra`: further modes whose curves are only recorded, with their gap to the reference.)
+    Does the fp16 build TRAIN like the parity mode?  Two HIP models (fp16 and fp32x3), identical initial weights and one
     fixed batch, `steps` Adam steps each on the same device; the loss curves are compared point by point, relative to
     the total descent of the fp32x3 curve.  (Single steps are pinned against the oracle elsewhere; steps after the first
     can only be compared loosely -- Adam's first updates are sign-like and the random-init network amplifies any
@@ -1556,7 +1557,7 @@ def check_loss_trajectory(lib, dev, N=8, H=256, W=341, steps=50, lr=1e-4, envelo
     x, t = oracle.make_batch("mapnet", N, H, W, seed=7)
     x, t = x.to(dev), t.to(dev)
     curves = {}
-    for dtype_name in ("fp16", "fp32x3"):
+    for dtype_name in tuple(modes) + tuple(extra):
         G.set_compute_dtype(dtype_name)
         net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, _binding=lib))
         net.load_state_dict(sd0)
@@ -1568,13 +1569,15 @@ def check_loss_trajectory(lib, dev, N=8, H=256, W=341, steps=50, lr=1e-4, envelo
         net.train()
         curves[dtype_name] = [G.step_feedfwd(x, net, dev != "cpu", t, c, opt, True)[0] for _ in range(steps)]
         del net, c, opt
-    a, b = np.array(curves["fp16"]), np.array(curves["fp32x3"])
+    a, b = np.array(curves[modes[0]]), np.array(curves[modes[1]])
     assert np.isfinite(a).all() and np.isfinite(b).all()
     descent = b[0] - b.min()
     assert descent > 0.5 * abs(b[0]), (b[0], b.min())  # the fixed batch is being fitted
     gap = float(np.abs(a - b).max() / descent)
     assert gap <= envelope, (gap, curves)
-    return curves["fp16"], curves["fp32x3"], gap
+    if extra:
+        return curves, gap, {e: float(np.abs(np.array(curves[e]) - b).max() / descent) for e in extra}
+    return curves[modes[0]], curves[modes[1]], gap
 
 
 def check_dense(lib, dev, B, Cin, F, seed=11):

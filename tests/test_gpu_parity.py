@@ -259,6 +259,21 @@ def test_fp16_loss_trajectory_tracks_the_parity_mode(lib):
     print("trajectory gap / descent:", gap)
 
 
+def test_fp16x2m_loss_trajectory_tracks_fp16x2(lib, monkeypatch):
+    """the same 50 steps in fp16x2m against fp16x2 under MN_DETERMINISTIC=1 (no summation-order noise: the curves differ by the
+    backward pass's arithmetic only): within the envelope the fp16 mode is held to; fp32x3 against fp16x2 -- two fp32-CLASS evaluations
+    of the same steps -- is recorded beside it as the scale of what any change of arithmetic does to a trajectory"""
+    monkeypatch.setenv("MN_DETERMINISTIC", "1")
+    curves, gap, other = checks.check_loss_trajectory(lib, DEV, N=8, H=256, W=341, steps=50, modes=("fp16x2m", "fp16x2"),
+                                                      extra=("fp32x3",))
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "loss_trajectory_fp16x2m_vs_fp16x2.json"), "w") as f:
+            json.dump({"curves": curves, "fp16x2m_vs_fp16x2_max_gap_over_descent": gap, "vs_fp16x2": other}, f)
+    print("trajectory gap / descent: fp16x2m vs fp16x2", gap, "| fp32x3 vs fp16x2", other)
+
+
 def test_posenet_train_step_fp32_parity(lib):
     checks.check_train_step(lib, DEV, "fp32", mode="posenet", N=5, H=96, W=128, steps=1)
 
@@ -384,6 +399,8 @@ def test_mapnet_staged_step_fp32_parity_with_rccl(lib, monkeypatch):
         started = True
     try:
         import geomapnet_amd.dp as dp
+        # the parity mode of round 5 first (fp16x2m: loss scale, stage joins of its fp16 backward launches), unprofiled
+        checks.check_train_step(lib, DEV, "fp16x2m", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
         dp.set_profiling(True)
         checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
         # the measurement hooks bench.py --gpus N reports: exposed communication per step and the per-bucket timeline

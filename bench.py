@@ -385,7 +385,7 @@ def main():
             ach = flops_G / rec["conv_ms_per_step"]  # GFLOP / ms = TFLOP/s per GPU; fp32x3: fp32-EQUIVALENT flops
             traffic, src, whole_bytes = None, None, 0  # HBM bytes of the same launches: separate rocprofv3 --pmc passes (profiles/), static
             if rec["dtype"] == "fp16" and n == 64:
-                for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
+                for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
                     path = os.path.join(ROOT, "profiles", rnd, "pmc_conv_traffic.json")
                     if os.path.exists(path):
                         with open(path) as f:

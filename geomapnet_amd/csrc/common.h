@@ -176,6 +176,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// compile-time loop: f(StaticIndex<0>{}), ..., f(StaticIndex<N - 1>{}) -- for bodies whose register or immediate operands must be
+// constants of the iteration (hand-counted waits, register-ring slots)
+template <int I>
+struct StaticIndex {
+  static constexpr int value = I;
+};
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(StaticIndex<I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ float to_f(T v) {
   return (float)v;

@@ -237,17 +237,7 @@ __device__ __forceinline__ v4s16 ds_read_tr16_at(const void* lds_base, unsigned 
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt_for(TrFrag&) {}
 #endif
-template <int I>
-struct StaticIndex {
-  static constexpr int value = I;
-};
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(StaticIndex<I>{});
-    static_for<N, I + 1>(f);
-  }
-}
+// (StaticIndex / static_for: common.h)
 
 //
 // FAST (stride-1 "same" convolutions, the bulk of the network): the source address of tap (dh, dw) of pixel

@@ -742,7 +742,11 @@ def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps
         lt, pt = (loss_rtol, pose_atol) if step == 0 or adam_eps is not None else (max(loss_rtol, 5e-3), max(pose_atol, 2e-2))
         assert abs(l - lo) <= lt * max(1.0, abs(lo)), (step, l, lo)
         assert pose_err <= pt * max(1.0, po.abs().max().item()), (step, pose_err)
-        if step == 0 and pose_abs is not None:  # the north-star bar as written: max abs over all predicted components
+        # the north-star bar as written -- max abs over all predicted components, not relative to the pose scale -- for the first
+        # step of every fp32-class mode whatever the shape, and wherever a caller asks for it
+        if pose_abs is None and dtype_name in ("fp32", "fp32x3", "fp16x2", "fp16x2m") and pose_atol <= 2e-3:
+            pose_abs = 1e-3
+        if step == 0 and pose_abs is not None:
             assert pose_err <= pose_abs, (step, pose_err)
         if step == 0 and grad_l2_rtol is not None and max_grad_norm == 0.0:
             eng = (net.mapnet if hasattr(net, "mapnet") else net)._engine

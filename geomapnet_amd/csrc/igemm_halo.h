@@ -62,21 +62,22 @@ namespace mn {
 // (profiles/r05/c4_big_single_image_tiles_per_launch.txt): fp16 layer2 90.2 -> 104.3 us forward, 87.1 -> 93.2 data gradient; h2
 // layer2 213 -> 224, h2 layer1 305 -> 331 (576 rows) / 341 (384 rows); layer4's 120 tiles are half a round, 83 -> 127 us.  DMA
 // bytes are not what bounds these launches; a single image exposes its reload once per chunk with nothing beside it on the CU.)
-// BG (round 5, experiment; fp16): the B operand -- the weights -- does not pass through LDS at all.  A lane's MFMA B fragment (8
-// consecutive k of one output channel) is 16 contiguous bytes of the [N][K] weight matrix, so each wave loads its fragments straight
-// from L2 into registers, three 16-k sub-steps ahead (a four-slot register ring, waits counted by the compiler): no B slice DMA, no
-// B fragment reads from LDS, and -- the point -- no `s_waitcnt vmcnt(0)` + barrier per K-step: the workgroup only meets where the A
-// image changes, once per 64-channel chunk (nine K-steps).  Measured: profiles/r05 (B from L2).
+// (Measured and removed, round 5: "BG" -- the B operand never passes through LDS: a lane's MFMA B fragment is 16 contiguous bytes of
+// the [N][K] weight matrix, so each wave loaded its fragments straight from L2 into a four-slot register ring three 16-k sub-steps
+// ahead; no B slice DMA, no B fragment reads, and only ONE barrier per 64-channel chunk instead of one per K-step.  Parity-green in
+// the emulator; per launch at 192 images layer2 90 -> 129 us, layer4 82 -> 115, layer3 77 -> 144 (that shape also spilled):
+// a 16-byte-per-lane load whose 64 lanes touch 32 different cache lines runs at the texture addresser's rate, far below what the
+// LDS-DMA + ds_read_b128 path delivers.  The per-K-step barrier is cheaper than any way around it that was tried in five rounds.
+// profiles/r05/c8_weights_from_l2_into_registers_per_launch.txt)
 template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4, bool A1 = false, bool FBN = false,
-          int OCC = (A1 ? 2 : 1), bool BG = false>
+          int OCC = (A1 ? 2 : 1)>
 static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
   constexpr int VEC = 8, NP = 8, TM = 3, TN = BN / (WN * 32), NT = WM * WN * 64;
   constexpr int BM = WM * 96, WTM = 96, WTN = BN / WN, RPP = NT / NP;  // rows per DMA pass
   static_assert(TN == 1 || TN == 2, "wave tiles of 96 x 32 or 96 x 64");
-  constexpr int NBS = BG ? 0 : 2, NIMG = A1 ? 1 : 2, A_IMG = kAH * NP, B_SLOT = BN * NP, RING = NIMG * A_IMG + NBS * B_SLOT;  // pieces
-  static_assert(!BG || (!H2 && !FBN && ABL == 0), "BG: the plain fp16 kernel only");
+  constexpr int NBS = 2, NIMG = A1 ? 1 : 2, A_IMG = kAH * NP, B_SLOT = BN * NP, RING = NIMG * A_IMG + NBS * B_SLOT;  // pieces
   constexpr int SC = BN < 128 ? BN : 128;  // columns staged per epilogue round
   constexpr int FTAB = FBN ? (BN == 256 ? 64 : 128) : 0;  // (scale piece, shift piece) per 8 channels: C <= 256 / 512
   static_assert(!FBN || !H2, "fp16 only");
@@ -190,85 +191,6 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
     if (j < KT) issue_b(j);
 
   int chunk = 0, tap = 0, tr = 0, ts = 0;
-  if constexpr (BG) {
-    // this lane's weight rows: output channel n0 + wn WTN + 32 j + l31, its 8-k half `hi` of every 16-k sub-step
-    const half* bptr[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bptr[j] = Bw + (long)(n0 + wn * WTN + j * 32 + l31) * g.K + hi * 8;
-    PieceView<half> fbq[4][TN];  // sub-step ks of a K-step lives in slot ks
-    auto load_b = [&](auto S, int koff) {
-      constexpr int slot = decltype(S)::value;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fbq[slot][j].p = *reinterpret_cast<const piece_t*>(bptr[j] + koff);
-    };
-    load_b(StaticIndex<0>{}, 0);
-    load_b(StaticIndex<1>{}, 16);
-    load_b(StaticIndex<2>{}, 32);
-    for (int kt = 0; kt < KT; ++kt) {
-      if (tap == 0) {  // a chunk begins: its image has landed for every wave, and every wave is done with the chunk before
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-      }
-      const piece_t* img = &smem[(A1 ? 0 : (chunk & 1)) * A_IMG];
-      const int shift = halo + (g.off_h + g.rsign * tr) * W + g.off_w + g.ssign * ts;  // scalar
-      int arow[TM], aswz[TM];
-      bool ainv[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        arow[i] = wm * WTM + i * 32 + l31 + shift;
-        aswz[i] = lds_swz<NP>(arow[i]);
-        ainv[i] = ((inv_mask >> (9 * i + tap)) & 1u) != 0;
-      }
-      const int kb_cur = tap * g.C + chunk * 64;
-      const int kb_nxt = tap == 8 ? (chunk + 1) * 64 : (tap + 1) * g.C + chunk * 64;
-      const bool has_next = kt + 1 < KT;
-      PieceView<half> fa[2][TM];
-      auto load_a = [&](int ks, int slot) {
-        const int piece = ks * 2 + hi;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const piece_t* p = ainv[i] ? &smem[RING] : img + arow[i] * NP + (piece ^ aswz[i]);
-          fa[slot][i].p = *p;
-        }
-      };
-      load_a(0, 0);
-      static_for<4>([&](auto KS) {
-        constexpr int ks = decltype(KS)::value;
-        // the weights of the sub-step three ahead: slot 3 of this K-step, or slots 0..2 of the next one
-        if constexpr (ks == 0)
-          load_b(StaticIndex<3>{}, kb_cur + 48);
-        else if (has_next)
-          load_b(StaticIndex<(ks + 3) % 4>{}, kb_nxt + (ks - 1) * 16);
-        if constexpr (ks + 1 < 4) load_a(ks + 1, (ks + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) mma_piece<half>(fa[ks & 1][i], fbq[ks][j], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DP > 0 && !A1)
-          if (ks + 1 == DP) {
-            if (tap < A_PASSES && chunk + 1 < NCH) issue_a(chunk + 1, tap);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-      });
-      if constexpr (A1) {  // the chunk's last K-step has been read by this wave: once every wave is here the image may be replaced
-        if (tap == 8 && chunk + 1 < NCH) {
-          __builtin_amdgcn_s_barrier();
-#pragma unroll
-          for (int p = 0; p < A_PASSES; ++p) issue_a(chunk + 1, p);
-        }
-      }
-      if (++ts == 3) {
-        ts = 0;
-        ++tr;
-      }
-      if (++tap == 9) {
-        tap = tr = ts = 0;
-        ++chunk;
-      }
-    }
-  } else
   for (int kt = 0; kt < KT; ++kt) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // this step's B slice (and any image pass in flight) landed; last step's reads are done
@@ -568,27 +490,6 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
   static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
 #endif
   static const int a1 = getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1;
-  // MN_HALO_BG (experiment): the B operand straight from L2 (BG above) -- bit 0: the two-workgroup 192-row shape (layer2), bit 1: the
-  // 256-column shape (layer3), bit 2: the 128-column 288-row shape (layer4)
-  static const int bg = getenv("MN_HALO_BG") ? atoi(getenv("MN_HALO_BG")) : 0;
-  if (bg && !g.a_bn && g.ldb == 0) {
-    if ((bg & 2) && level >= 1 && tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) {
-      hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, false, 3, 4, false, false, 1, true>), dim3(gm * (g.N / 256)), dim3(768), 0,
-                         stream, g, A, Bw, ep, g.N / 256, rd);
-      return gm;
-    }
-    if ((bg & 1) && level >= 2 && (a1 == 2 || (long)cdiv(g.M, 192) * (g.N / 128) >= 2L * device_cus()) &&
-        igemm_halo_applies(g, ep, 128, 288, 192)) {
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, false, 2, 2, true, false, 2, true>), dim3(cdiv(g.M, 192) * (g.N / 128)), dim3(256),
-                         0, stream, g, A, Bw, ep, g.N / 128, rd);
-      return cdiv(g.M, 192);
-    }
-    if ((bg & 4) && level >= 2 && !(tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) && igemm_halo_applies(g, ep, 128, 384)) {
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, false, 3, 4, false, false, 1, true>), dim3(gm * (g.N / 128)), dim3(768), 0,
-                         stream, g, A, Bw, ep, g.N / 128, rd);
-      return gm;
-    }
-  }
   if (g.a_bn) {  // FBN experiment: the two 12-wave shapes only (256 columns with C <= 256, else 128 columns with C <= 512)
     if (g.N % 256 == 0 && g.C <= 256 && igemm_halo_applies(g, ep, 256, 352)) {
       hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, false, 3, 4, false, true>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A,

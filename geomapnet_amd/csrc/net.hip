@@ -531,6 +531,7 @@ struct Plan : PlanBase {
   // with fp16 conv operands in the backward pass) -- a fifth of the 4.9e-3 / 1.1e-2 by which two correct fp32 evaluations of this
   // network differ through ReLU gate flips.  The stem's backward stays on the fp32 chain of fp16x2.
   bool mixed = false;
+  std::string stage_error;  // set by a launch helper of a backward stage that cannot return a status itself
   Plan(const mn_config& c) {
     cfg = c;
     cur_scale = c.loss_scale;
@@ -889,8 +890,8 @@ struct Plan : PlanBase {
     if (h2 && &u != &stem && gate && !self_gate) {
       // (the h2 / fp16x2m apply kernels have no gate input -- block-output gradients arrive already gated -- so a
       //  caller that passes a real gate must not get ungated gradients silently)
-      fail("bn_bwd: the fp16x2 / fp16x2m modes take block-output gradients as stored (already gated); only self_gate exists");
-      return;
+      stage_error = "bn_bwd: the fp16x2 / fp16x2m modes take block-output gradients as stored (already gated); only self_gate exists";
+      return;  // (reported by backward_stage: this call site has no status to return)
     }
     if (mixed && &u != &stem) {  // fp16 gradient, fp32 conv output in; plain fp16 d(conv output) out
       launch_bn_bwd<half, float>((const half*)g, (const half*)nullptr, (const float*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean,
@@ -1134,6 +1135,11 @@ struct Plan : PlanBase {
     }
     flush_wgrads(s);
     join_wgrad(s);  // the stage's gradient bucket is complete when this call's work on s is
+    if (!stage_error.empty()) {  // a launch helper refused its arguments (bn_bwd): the stage is incomplete
+      const std::string e = stage_error;
+      stage_error.clear();
+      return fail(e);
+    }
     return check_launch("backward_stage");
   }
 

@@ -1007,12 +1007,13 @@ def check_checkpoint_interop(lib, dev, H=40, W=53, resume_step=True):
         pass
 
 
-def check_u8_input(lib, dev, N=1, H=40, W=53):
+def check_u8_input(lib, dev, N=1, H=40, W=53, dtype_name="fp32"):
     """device-side ToTensor + Normalize: uint8 NHWC input vs the same images normalised on the host (fp32 NCHW),
-    forward and one training step against the oracle"""
+    forward and one training step against the oracle (fp16x2m: the stem's backward kernels read a second, fp16 image of the input
+    produced by the same conversion -- the stem's weight gradient is compared as well)"""
     _fresh()
     import geomapnet_amd as G
-    G.set_compute_dtype("fp32")
+    G.set_compute_dtype(dtype_name)
     onet, net = build_pair(lib, dev)
     g = torch.Generator().manual_seed(5)
     u8 = torch.randint(0, 256, (N, 3, H, W, 3), generator=g, dtype=torch.uint8)
@@ -1043,6 +1044,9 @@ def check_u8_input(lib, dev, N=1, H=40, W=53):
     l, p = G.step_feedfwd(u8.to(dev), net, dev != "cpu", t.to(dev), c, opt, True)
     assert abs(l - lo) <= 1e-4 * max(1.0, abs(lo)), (l, lo)
     assert (p.cpu() - po.detach()).abs().max().item() <= 2e-3 * max(1.0, po.abs().max().item())
+    gw = grad_views(net)["feature_extractor.conv1.weight"].cpu().double()
+    rw = dict(onet.named_parameters())["mapnet.feature_extractor.conv1.weight"].grad.double()
+    assert ((gw - rw).norm() / rw.norm()).item() <= 2e-2, ((gw - rw).norm() / rw.norm()).item()
     net.set_input_u8(None)
     assert net.mapnet._engine.input_u8 is None
 

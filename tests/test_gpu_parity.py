@@ -428,6 +428,7 @@ def test_checkpoint_interop_and_resume(lib):
 
 def test_uint8_input_pipeline(lib):
     checks.check_u8_input(lib, DEV, N=2, H=128, W=171)
+    checks.check_u8_input(lib, DEV, N=2, H=128, W=171, dtype_name="fp16x2m")
 
 
 def test_eval_flow_and_metric(lib):

@@ -537,6 +537,7 @@ struct Plan : PlanBase {
     cur_scale = c.loss_scale;
     mixed = DT == MN_F32 && c.dtype == MN_DTYPE_F16X2M;
     h2 = DT == MN_F32 && (c.dtype == MN_DTYPE_F16X2 || mixed);
+    stem_f16 = mixed && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
     if (c.dtype == MN_DTYPE_F32X3 || h2) {  // (fp16x2m: the stem's backward and its fp32 tensors)
       mma_fwd = MMA_F16X3;
       mma_bwd = MMA_BF16X3;
@@ -1075,9 +1076,8 @@ struct Plan : PlanBase {
   // fp16x2m: the same two kernels on fp16 COPIES of the fp32 conv output (written by the stem's BatchNorm + max-pool pass) and of
   // the padded input, with the pooled gradient arriving already gated (StemBwdArgs::pre_gated); MN_STEM_BWD=0 / MN_DETERMINISTIC
   // keep the fp32 chain of fp16x2
-  bool stem_bwd_f16() const {
-    return mixed && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
-  }
+  bool stem_f16 = false;  // (set in the constructor, once `mixed` is known)
+  bool stem_bwd_f16() const { return stem_f16; }
   void stem_backward(hipStream_t s) {
     if (use_stem_bwd || stem_bwd_f16()) {
       const bool mx = stem_bwd_f16();

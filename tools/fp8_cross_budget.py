@@ -47,6 +47,12 @@ def q8(x, dim):
     return q.movedim(-1, dim)
 
 
+def q8t(x):
+    """fp8 e4m3 with ONE power-of-two scale per tensor (the maximum lands in [128, 256)): what constant scale operands would give"""
+    s = torch.exp2(torch.floor(torch.log2(x.abs().amax().clamp_min(1e-30))) - 7.0)
+    return (x / s).to(torch.float8_e4m3fn).float() * s
+
+
 def conv(x, w, stride, pad):
     if MODE["cross"] == "fp32":
         return F.conv2d(x, w, None, stride, pad)
@@ -57,6 +63,8 @@ def conv(x, w, stride, pad):
         y = y + F.conv2d(xl, wh, None, stride, pad) + F.conv2d(xh, wl, None, stride, pad)
     elif MODE["cross"] == "fp8":
         y = y + F.conv2d(q8(xl, 1), q8(wh, 1), None, stride, pad) + F.conv2d(q8(xh, 1), q8(wl, 1), None, stride, pad)
+    elif MODE["cross"] == "fp8t":
+        y = y + F.conv2d(q8t(xl), q8t(wh), None, stride, pad) + F.conv2d(q8t(xh), q8t(wl), None, stride, pad)
     return y
 
 
@@ -95,6 +103,7 @@ def main():
         print("%-66s %10s %10s" % ("convolutions contracted as", "pose max", "pose rms"))
         for name, m in (("hi*hi + hi*lo + lo*hi, all fp16 (= fp16x2: 3 MFMAs per product)", "exact"),
                         ("hi*hi fp16 + both cross terms in MXFP8 e4m3 (2 MFMA-equivalents)", "fp8"),
+                        ("... with one power-of-two scale per TENSOR instead of per 32 channels", "fp8t"),
                         ("hi*hi only (fp16 operands, fp32 tensors: 1 MFMA)", "none")):
             MODE["cross"] = m
             d = forward(net, x) - ref

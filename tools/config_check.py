@@ -1,4 +1,5 @@
-"""Runs the other BASELINE.json configurations at their FULL sizes for a few steps (fp16, synthetic data): PoseNet
+"""usage: python tools/config_check.py [dtype ...]   (default: fp16 fp16x2m)
+Runs the other BASELINE.json configurations at their FULL sizes for a few steps (synthetic data): PoseNet
 batch 64 (configs[1]) and MapNet++ 64 windows x 2T = 384 images with MapNetOnlineCriterion, max_grad_norm 5 and the NaN
 filter (configs[4], per-GPU share).  Prints images/s; they are parity-test shapes, not bench lines."""
 import os
@@ -13,8 +14,8 @@ import geomapnet_amd as G  # noqa: E402
 import oracle  # noqa: E402
 
 
-def run(mode, n, steps=6):
-    G.set_compute_dtype("fp16")
+def run(mode, n, steps=6, dtype="fp16"):
+    G.set_compute_dtype(dtype)
     torch.manual_seed(7)
     pn = G.PoseNet(G.resnet34(), droprate=0.0, pretrained=False, filter_nans=(mode == "mapnet++"))
     if mode == "posenet":
@@ -42,10 +43,11 @@ def run(mode, n, steps=6):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     assert all(l == l and abs(l) < 1e6 for l in losses), losses
-    print("%-9s %3d images/step: %.2f ms/step = %.0f images/s; loss %.3f -> %.3f; output %s"
-          % (mode, images, dt * 1e3, images / dt, losses[0], losses[-1], tuple(out.shape)), flush=True)
+    print("%-8s %-9s %3d images/step: %.2f ms/step = %.0f images/s; loss %.3f -> %.3f; output %s"
+          % (dtype, mode, images, dt * 1e3, images / dt, losses[0], losses[-1], tuple(out.shape)), flush=True)
 
 
 if __name__ == "__main__":
-    run("posenet", 64)
-    run("mapnet++", 64)
+    for dt in (sys.argv[1:] or ["fp16", "fp16x2m"]):
+        run("posenet", 64, dtype=dt)
+        run("mapnet++", 64, dtype=dt)

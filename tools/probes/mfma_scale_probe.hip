@@ -5,7 +5,9 @@
 //   H1  k = 32 (l >> 5) + e                      (a lane holds one contiguous half of K)
 //   H2  k = 16 (l >> 5) + (e & 15) + 32 (e >> 4) (two 16-byte groups, as two consecutive 32x32x32 steps would read them)
 // The probe fills A and B with asymmetric small integers under each hypothesis, runs the instruction and compares D with the host's
-// product; then it checks that scale bytes multiply the result by powers of two and which byte of the scale VGPR `opsel` selects.
+// product; then it checks that scale bytes multiply the result by powers of two, which byte of the scale VGPR `opsel` selects, and
+// that the scale is taken PER LANE (a lane's 32 k values share its byte).  (A dot product does not care how k is numbered as long as
+// A and B agree, so H1 and H2 both pass: what the probe pins is row / column = l & 31, the K halves by l >> 5, the C/D map.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +17,11 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 __global__ void k(const unsigned char* A, const unsigned char* B, float* D, int scale_a, int scale_b, int opsel) {
   const int l = threadIdx.x;
+  if (opsel == 2) {  // per-lane scales: the A scale of lanes 0-31 (the first K half) is 2^1, everything else 2^0
+    scale_a = l < 32 ? 128 : 127;
+    scale_b = 127;
+    opsel = 0;
+  }
   intx8 a, b;
   for (int r = 0; r < 8; ++r) {
     a[r] = ((const int*)A)[l * 8 + r];
@@ -83,6 +90,21 @@ int main() {
       b2 = 0;
       for (int i = 0; i < 1024; ++i) b2 += hD[i] != 4.f * ref[i / 32][i % 32];
       printf("  the same scales in byte 1 of the scale registers, opsel = 1: %d outputs differ from 4 x the product\n", b2);
+      // one scale byte PER LANE: lanes 0-31 hold one half of K for every row, lanes 32-63 the other
+      hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, dA, dB, dD, 0, 0, 2);
+      hipMemcpy(hD, dD, 4096, hipMemcpyDeviceToHost);
+      b2 = 0;
+      for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+          float e2 = 0;
+          for (int l = 0; l < 64; l += 32)
+            for (int e = 0; e < 32; ++e) {
+              const int kk = kmap(hyp, l, e);
+              e2 += (l < 32 ? 2.f : 1.f) * (float)(Am[i][kk] * Bm[kk][j]);
+            }
+          b2 += hD[i * 32 + j] != e2;
+        }
+      printf("  A scale 2^1 in lanes 0-31 only: %d outputs differ from 2 x (the K half of lanes 0-31) + (the other half)\n", b2);
     }
   }
   return 0;

@@ -104,7 +104,8 @@ int main() {
             }
           b2 += hD[i * 32 + j] != e2;
         }
-      printf("  A scale 2^1 in lanes 0-31 only: %d outputs differ from 2 x (the K half of lanes 0-31) + (the other half)\n", b2);
+      printf("  A scale 2^1 in lanes 0-31 only: %d outputs differ from 2 x (the bytes of lanes 0-31) + (the other lanes' bytes)%s\n", b2,
+             b2 ? "  (expected to differ: a scale byte belongs to an MX block = bytes 16 b .. 16 b + 15 of BOTH lanes of a row, mfma_scale_probe2.hip)" : "");
     }
   }
   return 0;

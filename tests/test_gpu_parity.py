@@ -419,6 +419,7 @@ def test_mapnet_staged_step_fp32_parity_with_rccl(lib, monkeypatch):
 
 def test_eval_forward_parity(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=3, H=128, W=171)
+    checks.check_eval_forward(lib, DEV, "fp16x2m", B=3, H=128, W=171)  # (the scripts' default dtype: the split-operand forward pass)
     checks.check_eval_forward(lib, DEV, "fp16", B=3, H=128, W=171, atol=3e-2)
 
 

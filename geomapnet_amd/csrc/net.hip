@@ -785,21 +785,20 @@ struct Plan : PlanBase {
     else
       hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
                          (const float*)images, xpad, B, H, W, Hp, Wp);
+    if (stem_bwd_f16() && training) {  // fp16x2m: the stem's backward kernels read an fp16 image of the input
+      if (input_u8)
+        hipLaunchKernelGGL((u8nhwc_to_padded_nhwc4_kernel<half>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
+                           (const unsigned char*)images, xpad16, B, H, W, Hp, Wp, input_norm);
+      else
+        hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<half>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
+                           (const float*)images, xpad16, B, H, W, Hp, Wp);
+    }
     // forked AFTER the (HBM-bound) input conversion, so that the side stream's copies run beside the stem's MFMA-bound
     // convolution instead of competing with the conversion for bandwidth (step time: equal within noise)
-    const bool x16 = stem_bwd_f16() && training;  // fp16x2m: the stem's backward kernels read an fp16 image of the input
-    if (dirty || zero_grads || x16) {
+    if (dirty || zero_grads) {
       hipStream_t side = fork_wgrad(s);
       if (dirty) repack_tail(side);
       if (zero_grads) launch_zero_fill(grads, L.param_floats, side);
-      if (x16) {  // (needed by the stem's backward only: beside the stem convolution, not in front of it)
-        if (input_u8)
-          hipLaunchKernelGGL((u8nhwc_to_padded_nhwc4_kernel<half>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, side,
-                             (const unsigned char*)images, xpad16, B, H, W, Hp, Wp, input_norm);
-        else
-          hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<half>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, side,
-                             (const float*)images, xpad16, B, H, W, Hp, Wp);
-      }
     }
     conv_bn_stats(stem, xpad, training, s);
     if (h2) {  // (always the fused form: fp32 conv output in, h2 pooled activation out)

@@ -197,6 +197,8 @@ class Engine:
         if p.get("dropout", (0.0, 0)) != self.dropout:
             self.lib.check(self.lib.set_dropout(p["handle"], C.c_float(self.dropout[0]), C.c_uint64(self.dropout[1])))
             p["dropout"] = self.dropout
+            if self.dropout[0] > 0.0:  # (mn_set_dropout restarts the mask sequence at 0: continue from the model's step count)
+                self.lib.check(self.lib.set_dropout_calls(p["handle"], self.step_count & 0xffffffff))
         self._own_step(p)
         return p
 

@@ -43,7 +43,12 @@ enum { MN_F32 = 0, MN_F16 = 1 };
 //   MMA_H2      (fp16-PAIR tensors, "h2", round 4; kernels instantiated for `half`): the operands are ALREADY split -- every
 //               conv-consumed tensor is stored as hi + lo fp16 halves (layout below), so tiles travel HBM -> LDS by DMA like
 //               fp16 tiles and a product is the same three v_mfma_f32_32x32x16_f16, with no conversion in the K loop.
-enum { MMA_NATIVE = 0, MMA_F16X3 = 1, MMA_BF16X3 = 2, MMA_H2 = 3 };
+//   MMA_H2Q     (round 5, the fp16x2q mode's FORWARD convolutions; h2q tensors below): hi*hi on the fp16 pipe as MMA_H2, and BOTH cross
+//               terms of a 32-channel K-step in ONE v_mfma_scale_f32_32x32x64_f8f6f4 -- the block-scaled fp8 MFMA, twice the fp16
+//               rate -- from fp8 (e4m3) copies: [lo8 | hi8] of A against [hi8 | lo8] of B.  A cross term is a 2^-11 correction, so
+//               the 2^-4 of an fp8 operand leaves ~2^-15 per product: poses 3.1e-4 from the fp32 oracle at the benchmark shape
+//               (tools/fp8_cross_budget.py; bar 1e-3; MMA_H2: 1.6e-5), at 2 instead of 3 MFMA-equivalents per product.
+enum { MMA_NATIVE = 0, MMA_F16X3 = 1, MMA_BF16X3 = 2, MMA_H2 = 3, MMA_H2Q = 4 };
 
 // ---- the h2 ("fp16 pair") tensor layout ---------------------------------------------------------------------------------
 // A tensor [rows][C] of fp32-class values, C a multiple of 32, 4 bytes per element like fp32: per row and per GROUP of 32
@@ -56,6 +61,51 @@ enum { MMA_NATIVE = 0, MMA_F16X3 = 1, MMA_BF16X3 = 2, MMA_H2 = 3 };
 // hi*hi + hi*lo + lo*hi accumulate into ONE 32x32 tile.  To every DMA / gather path the tensor is simply an fp16 tensor
 // with 2C channels.
 __host__ __device__ inline long h2_index(long row, int C, int c) { return row * 2L * C + (long)(c >> 5) * 64 + (c & 31); }
+
+// ---- the h2q layout (round 5): an h2 tensor whose lo plane is fp8 -----------------------------------------------------------------
+// Same 128 bytes per row and 32-channel group, same position of the fp16 hi halves (h2_index): every reader of hi halves -- gates,
+// the backward pass's copies -- is unaffected.  The second 64 bytes hold two fp8 (OCP e4m3) planes of 32 bytes with FIXED exponents:
+//   activations:  bytes 64..95  lo8[c] = fp8((x - hi) * 2^kQA_LO),   bytes 96..127 hi8[c] = fp8(hi * 2^kQA_HI)
+//   weights:      bytes 64..95  hi8[c] = fp8(hi * 2^kQW_HI),         bytes 96..127 lo8[c] = fp8((w - hi) * 2^kQW_LO)
+// (planes swapped between the operands: a lane's scaled-MFMA operand is piece 4 + half followed by piece 6 + half of the group, and
+// block 0 of A -- lo8 -- must meet block 0 of B -- hi8; tools/probes/mfma_scale_probe2.hip.)  Ranges: |activation| < 896, |weight|
+// < 7 (values beyond saturate in the fp8 copies only; the activation lo plane from |x| = 448 on); below 2^-6 of the scaled value the fp8 copy is subnormal, an absolute error
+// that is negligible against the product it corrects.  E8M0 scale bytes of the MFMA: 127 - exponent.
+constexpr int kQA_LO = 9, kQA_HI = -1, kQW_HI = 6, kQW_LO = 16;  // (kQA_LO: the device splits with round-toward-zero hi halves, lo < 2^-10 |x|)
+constexpr float pow2c(int e) { return e >= 0 ? (float)(1ll << e) : 1.f / (float)(1ll << -e); }
+__host__ __device__ inline long h2q_byte(long row, int C, int c, int plane) {  // byte offset of fp8 plane 0 / 1 of element (row, c)
+  return row * 4L * C + (long)(c >> 5) * 128 + 64 + plane * 32 + (c & 31);
+}
+// fp32 -> fp8 e4m3 (OCP, round to nearest even, saturating at +-448), portable form (host, emulator)
+__host__ __device__ inline unsigned char fp8_e4m3_from_float(float f) {
+  unsigned u;
+  __builtin_memcpy(&u, &f, 4);
+  const unsigned sign = (u >> 24) & 0x80u;
+  float a = f < 0.f ? -f : f;
+  if (!(a == a)) return (unsigned char)(sign | 0x7f);
+  if (a >= 448.f) return (unsigned char)(sign | 0x7e);
+  if (a < 0.0009765625f) return (unsigned char)sign;  // below half the smallest subnormal (2^-10): zero
+  int e;
+  (void)__builtin_frexpf(a, &e);  // a = m * 2^e, m in [0.5, 1)
+  int ex = e - 1;                 // a = 1.xxx * 2^ex
+  if (ex < -6) ex = -6;           // subnormals share the exponent of the smallest normal
+  const float q = __builtin_ldexpf(a, 3 - ex);  // units of the last place
+  float r = __builtin_rintf(q);                 // round to nearest even
+  int mant = (int)r;
+  if (ex == -6 && mant < 8) return (unsigned char)(sign | mant);  // subnormal: exponent field 0
+  if (mant == 16) {
+    mant = 8;
+    ex += 1;
+  }
+  if (ex > 8 || (ex == 8 && mant > 14)) return (unsigned char)(sign | 0x7e);
+  return (unsigned char)(sign | ((ex + 7) << 3) | (mant - 8));
+}
+__host__ __device__ inline float fp8_e4m3_to_float(unsigned char b) {
+  const int ef = (b >> 3) & 15, m = b & 7;
+  float v = ef == 0 ? __builtin_ldexpf((float)m, -9) : __builtin_ldexpf((float)(8 + m), ef - 10);
+  if (ef == 15 && m == 7) v = __builtin_nanf("");
+  return (b & 0x80) ? -v : v;
+}
 
 template <typename T>
 struct ElemTraits;

@@ -27,6 +27,51 @@ __device__ __forceinline__ void h2_load8(const half* __restrict__ base, long row
   for (int e = 0; e < 8; ++e) x[e] = (float)hi.e[e] + (float)lo.e[e];
 }
 
+// ---- h2q (common.h): fp16 hi halves where h2 has them, the lo halves and a copy of the hi halves as fp8 with fixed exponents ----
+// four floats -> four fp8 e4m3 bytes (saturating at +-448)
+__device__ __forceinline__ unsigned q8_pack4(float a, float b, float c, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  a = fminf(fmaxf(a, -448.f), 448.f);
+  b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f);
+  d = fminf(fmaxf(d, -448.f), 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);  // bytes 0, 1
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);       // bytes 2, 3
+  return (unsigned)w;
+#else
+  return (unsigned)fp8_e4m3_from_float(a) | ((unsigned)fp8_e4m3_from_float(b) << 8) | ((unsigned)fp8_e4m3_from_float(c) << 16) |
+         ((unsigned)fp8_e4m3_from_float(d) << 24);
+#endif
+}
+// 8 channels c .. c + 7 of an ACTIVATION row: the hi piece where h2 has it, 8 bytes of lo8 and 8 bytes of hi8 behind the group's hi halves
+__device__ __forceinline__ void h2q_store8(half* __restrict__ base, long row, int C, int c, const float (&x)[8]) {
+  PieceView<half> hi, lo;
+  split8_f16(x, hi.v, lo.v);
+  half* p = base + h2_index(row, C, c);
+  *reinterpret_cast<piece_t*>(p) = hi.p;
+  float l[8], h[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float hf = (float)hi.e[e];
+    l[e] = (x[e] - hf) * pow2c(kQA_LO);
+    h[e] = hf * pow2c(kQA_HI);
+  }
+  unsigned char* q = reinterpret_cast<unsigned char*>(base) + h2q_byte(row, C, c, 0);
+  u32x2 lo8 = {q8_pack4(l[0], l[1], l[2], l[3]), q8_pack4(l[4], l[5], l[6], l[7])};
+  u32x2 hi8 = {q8_pack4(h[0], h[1], h[2], h[3]), q8_pack4(h[4], h[5], h[6], h[7])};
+  *reinterpret_cast<u32x2*>(q) = lo8;
+  *reinterpret_cast<u32x2*>(q + 32) = hi8;
+}
+// what a reader of the stored activation gets: hi + lo8 * 2^-kQA_LO
+__device__ __forceinline__ void h2q_load8(const half* __restrict__ base, long row, int C, int c, float (&x)[8]) {
+  PieceView<half> hi;
+  hi.p = *reinterpret_cast<const piece_t*>(base + h2_index(row, C, c));
+  const u32x2 lo8 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(base) + h2q_byte(row, C, c, 0));
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    x[e] = (float)hi.e[e] + fp8_e4m3_to_float((unsigned char)(lo8[e >> 2] >> (8 * (e & 3)))) * pow2c(-kQA_LO);
+}
+
 // 8 channels of row `row` as ONE plain fp16 piece (round-to-nearest) of a [rows][C] fp16 tensor: the copy of an activation the
 // single-fp16 backward pass of the fp16x2m mode reads (weight-gradient operand, ReLU gates), written by the kernel that
 // produces the h2 tensor
@@ -41,7 +86,7 @@ __device__ __forceinline__ void f16_store8(half* __restrict__ base, long row, in
 // fp16 copy of the same values (fp16x2m)
 static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
                                                                  const half* __restrict__ res, half* __restrict__ out,
-                                                                 long nitems, int C, int relu, half* __restrict__ out16) {
+                                                                 long nitems, int C, int relu, half* __restrict__ out16, int q) {
   constexpr int VEC = 8;
   const int cpr = C / VEC;
   __shared__ floatx2 tab[512];  // [e][piece] -> (scale, shift)
@@ -65,14 +110,22 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
     v1.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(y) + 2 * i + 1);
     float f[VEC] = {v0.e[0], v0.e[1], v0.e[2], v0.e[3], v1.e[0], v1.e[1], v1.e[2], v1.e[3]};
     float r[VEC];
-    if (res) h2_load8(res, row, C, cp * VEC, r);
+    if (res) {
+      if (q)
+        h2q_load8(res, row, C, cp * VEC, r);
+      else
+        h2_load8(res, row, C, cp * VEC, r);
+    }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       f[e] = f[e] * sc[e] + sh[e];
       if (res) f[e] += r[e];
       if (relu) f[e] = fmaxf(f[e], 0.f);
     }
-    h2_store8(out, row, C, cp * VEC, f);
+    if (q)
+      h2q_store8(out, row, C, cp * VEC, f);
+    else
+      h2_store8(out, row, C, cp * VEC, f);
     if (out16) f16_store8(out16, row, C, cp * VEC, f);
   }
 }
@@ -82,7 +135,7 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
 static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
                                                                         half* __restrict__ out, unsigned char* __restrict__ idx,
                                                                         int B, int H, int W, int C, int Po, int Qo,
-                                                                        half* __restrict__ out16, half* __restrict__ y16) {
+                                                                        half* __restrict__ out16, half* __restrict__ y16, int q) {
   constexpr int VEC = 8;
   const int cpr = C / VEC;
   float s_scale[VEC], s_shift[VEC];
@@ -143,7 +196,10 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const fl
         }
       }
     }
-    h2_store8(out, orow, C, cp * VEC, best);
+    if (q)
+      h2q_store8(out, orow, C, cp * VEC, best);
+    else
+      h2_store8(out, orow, C, cp * VEC, best);
     if (out16) f16_store8(out16, orow, C, cp * VEC, best);
     if (idx) {
       unsigned long long packed = 0;
@@ -236,14 +292,18 @@ static __global__ void __launch_bounds__(256) widen_f16_kernel(const half* __res
 
 // global average pool of an h2 activation
 static __global__ void __launch_bounds__(256) avgpool_fwd_h2_kernel(const half* __restrict__ in, float* __restrict__ out, int B,
-                                                                    int HW, int C) {
+                                                                    int HW, int C, int q) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int c = i % C, b = i / C;
   float s = 0.f;
   for (int p = 0; p < HW; ++p) {
-    const half* q = in + h2_index((long)b * HW + p, C, c);
-    s += (float)q[0] + (float)q[32];
+    const half* ph = in + h2_index((long)b * HW + p, C, c);
+    if (q)
+      s += (float)ph[0] + fp8_e4m3_to_float(reinterpret_cast<const unsigned char*>(in)[h2q_byte((long)b * HW + p, C, c, 0)]) *
+                              pow2c(-kQA_LO);
+    else
+      s += (float)ph[0] + (float)ph[32];
   }
   out[i] = s / (float)HW;
 }

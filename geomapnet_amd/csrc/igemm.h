@@ -228,7 +228,8 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
   constexpr int VEC = ElemTraits<T>::VEC;
   // h2 (MM = MMA_H2, T = half): g.C / g.K / g.ldb count the 2C fp16 "channels" of the pair layout (common.h) -- every gather
   // and DMA below is the fp16 kernel's; what differs is the MFMA order of a K-step and the epilogue (fp32 output)
-  constexpr bool H2 = MM == MMA_H2;
+  constexpr bool H2 = MM == MMA_H2 || MM == MMA_H2Q;
+  constexpr bool HQ = MM == MMA_H2Q;  // h2q operands: both cross terms of a K-step in one scaled fp8 MFMA (igemm_halo.h Q)
   static_assert(!H2 || (sizeof(T) == 2 && NP == 8 && UNI), "h2: fp16 pieces, one 32-channel group per K-step");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -570,6 +571,58 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
         if constexpr (SPL) {
           if (more) issue_part(nxt, kp * IPT / NKP, (kp + 1) * IPT / NKP);
         }
+      }
+    } else if constexpr (HQ) {
+      typedef int intx8 __attribute__((ext_vector_type(8)));
+      union QFrag {
+        piece_t p[2];
+        intx8 v;
+      };
+      const int lh = ln >> 5;
+      const int sa = lh ? 127 - kQA_HI : 127 - kQA_LO, sb = lh ? 127 - kQW_LO : 127 - kQW_HI;
+      const int sw = lds_swz<NP>(ln & 31);
+      const piece_t* pa = ta + (wm * WTM + (ln & 31)) * NP;
+      const piece_t* pb = ta + (BM + wn * WTN + (ln & 31)) * NP;
+      QFrag qa[TM], qb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        qa[i].p[0] = pa[i * 32 * NP + ((4 + lh) ^ sw)];
+        qa[i].p[1] = pa[i * 32 * NP + ((6 + lh) ^ sw)];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        qb[j].p[0] = pb[j * 32 * NP + ((4 + lh) ^ sw)];
+        qb[j].p[1] = pb[j * 32 * NP + ((6 + lh) ^ sw)];
+      }
+      PieceView<half> ha[2][TM], hb[2][TN];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ha[h][i].p = pa[i * 32 * NP + ((2 * h + lh) ^ sw)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) hb[h][j].p = pb[j * 32 * NP + ((2 * h + lh) ^ sw)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[i].v, qb[j].v, acc[i][j], 0, 0, 0, sa, 0, sb);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SPL) {
+        if (more) issue_part(nxt, 0, IPT / 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma_piece<half>(ha[h][i], hb[h][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SPL) {
+        if (more) issue_part(nxt, IPT / 2, IPT);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else if constexpr (H2) {
       // h2 operands (common.h): the K-step's eight pieces are one 32-channel group, pieces 0-3 its hi halves, 4-7 its lo
@@ -977,13 +1030,14 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
 // h2 weight matrix [N][taps][C] (row pitch ldb real elements), out / res fp32, gates h2.  The kernels see fp16 tensors with 2C
 // channels.  128x128 / 128x64 tiles of four waves, two workgroups per CU (3x3 stride-1 shapes go to igemm_halo.h).
 inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream);
+// q: A and Bw are h2q tensors (common.h), the cross terms run on the scaled fp8 MFMA (MMA_H2Q)
 inline int launch_igemm_h2(const GatherGeom& g_in, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
-                           const half* zero_page) {
+                           const half* zero_page, bool q = false) {
   GatherGeom g = g_in;
   g.C = 2 * g_in.C;
   g.K = 2 * g_in.K;
   g.ldb = 2 * g_in.ldb;
-  g.mma = MMA_H2;
+  g.mma = q ? MMA_H2Q : MMA_H2;
   g.tap_inner = (g.R * g.S > 1 || g.bt_on) ? 1 : 0;
   RowDiv rd;
   rd.q = make_fastdiv(g.Q);
@@ -997,8 +1051,12 @@ inline int launch_igemm_h2(const GatherGeom& g_in, const half* A, const half* Bw
   {                                                                                                                        \
     constexpr int BM = WM_ * TM_ * 32, BN = WN_ * TN_ * 32;                                                                \
     const int gm = cdiv(g.M, BM), gn = cdiv(g.N, BN);                                                                      \
-    hipLaunchKernelGGL((igemm_kernel<half, WM_, WN_, TM_, TN_, NP_, NBUF_, MINW_, true, false, 0, MMA_H2>), dim3(gm * gn), \
-                       dim3(WM_ * WN_ * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd);                                  \
+    if (q)                                                                                                                 \
+      hipLaunchKernelGGL((igemm_kernel<half, WM_, WN_, TM_, TN_, NP_, NBUF_, MINW_, true, false, 0, MMA_H2Q>), dim3(gm * gn), \
+                         dim3(WM_ * WN_ * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd);                                \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((igemm_kernel<half, WM_, WN_, TM_, TN_, NP_, NBUF_, MINW_, true, false, 0, MMA_H2>), dim3(gm * gn), \
+                         dim3(WM_ * WN_ * 64), 0, stream, g, A, Bw, ep, gn, zero_page, rd);                                \
     return gm;                                                                                                             \
   }
   if (g.N <= 64) MN_H2_CFG(2, 2, 2, 1, 8, 2, 2)

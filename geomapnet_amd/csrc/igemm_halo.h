@@ -69,8 +69,12 @@ namespace mn {
 // a 16-byte-per-lane load whose 64 lanes touch 32 different cache lines runs at the texture addresser's rate, far below what the
 // LDS-DMA + ds_read_b128 path delivers.  The per-K-step barrier is cheaper than any way around it that was tried in five rounds.
 // profiles/r05/c8_weights_from_l2_into_registers_per_launch.txt)
+// Q (round 5, with H2: the fp16x2q mode's forward convolutions): h2q operands (common.h MMA_H2Q) -- per K-step and tile pair ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 contracts both cross terms from the group's fp8 planes ([lo8 | hi8] of A against [hi8 | lo8] of B:
+// a lane's operand is piece 4 + half followed by piece 6 + half; scale bytes are constants of the lane half), then the two fp16
+// MFMAs of hi*hi: 128 instead of 192 matrix-pipe cycles per K-step and tile pair, the same LDS-DMA bytes and fragment reads.
 template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4, bool A1 = false, bool FBN = false,
-          int OCC = (A1 ? 2 : 1)>
+          int OCC = (A1 ? 2 : 1), bool Q = false>
 static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
                                                                    RowDiv rd) {
@@ -81,6 +85,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
   constexpr int SC = BN < 128 ? BN : 128;  // columns staged per epilogue round
   constexpr int FTAB = FBN ? (BN == 256 ? 64 : 128) : 0;  // (scale piece, shift piece) per 8 channels: C <= 256 / 512
   static_assert(!FBN || !H2, "fp16 only");
+  static_assert(!Q || H2, "Q: an h2 variant");
   static_assert((RING + 1 + WM * BN / 2 + FTAB) * 16 <= (OCC == 2 ? 80 : 160) * 1024, "LDS");
   static_assert(RING * 16 >= WM * 32 * SC * 4, "epilogue staging (the ring is free by then)");
   constexpr int A_PASSES = (kAH + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;   // 4, 3
@@ -215,7 +220,60 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
       ainv[i] = ((inv_mask >> (9 * i + tap)) & 1u) != 0;
     }
     const int brow = wn * WTN + l31, bswz = lds_swz<NP>(l31);  // B rows: multiples of 32 plus l31
-    if constexpr (H2) {
+    if constexpr (H2 && Q) {
+      typedef int intx8 __attribute__((ext_vector_type(8)));
+      union QFrag {
+        piece_t p[2];
+        intx8 v;
+      };
+      const int sa = hi ? 127 - kQA_HI : 127 - kQA_LO, sb = hi ? 127 - kQW_LO : 127 - kQW_HI;  // E8M0 scales of block `hi`
+      QFrag qa[TM], qb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const piece_t* p0 = ainv[i] ? &smem[RING] : img + arow[i] * NP + ((4 + hi) ^ aswz[i]);
+        const piece_t* p1 = ainv[i] ? &smem[RING] : img + arow[i] * NP + ((6 + hi) ^ aswz[i]);
+        qa[i].p[0] = *p0;
+        qa[i].p[1] = *p1;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        qb[j].p[0] = tb[(brow + j * 32) * NP + ((4 + hi) ^ bswz)];
+        qb[j].p[1] = tb[(brow + j * 32) * NP + ((6 + hi) ^ bswz)];
+      }
+      PieceView<half> ha[TM], hb[TN];
+      auto load_hi = [&](int h) {  // the fp16 hi halves of 16-k half h: piece 2 h + {0, 1}
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const piece_t* p = ainv[i] ? &smem[RING] : img + arow[i] * NP + ((2 * h + hi) ^ aswz[i]);
+          ha[i].p = *p;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) hb[j].p = tb[(brow + j * 32) * NP + ((2 * h + hi) ^ bswz)];
+      };
+      constexpr bool EARLY = !(NT == 768 && TN == 2);  // (the 256-column shape has no registers for both groups at once)
+      if constexpr (EARLY) load_hi(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[i].v, qb[j].v, acc[i][j], 0, 0, 0, sa, 0, sb);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DP > 0) {
+        issue_step();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 || !EARLY) load_hi(h);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma_piece<half>(ha[i], hb[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (H2) {
       // fragment (plane pl, 16-k half h of the group) = pieces 4 pl + 2 h + {0, 1}.  The 128-column shape (48 accumulator
       // registers) keeps both halves' fragments in registers -- the second half's reads fly under the first half's MFMAs --
       // the 256-column shape (96 accumulator registers of the 168 a wave may have) one half at a time.
@@ -571,6 +629,7 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
 // kernels cover, the 256-column shape when it fills the chip in one round (layer3), the 128-column shape otherwise
 inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream) {
   const int gm = cdiv(g2.M, 288);
+  const bool q = g2.mma == MMA_H2Q;  // h2q operands: the scaled-fp8 cross terms (igemm_halo_kernel Q)
   RowDiv rd;
   rd.q = make_fastdiv(g2.Q);
   rd.p = make_fastdiv(g2.P);
@@ -578,7 +637,11 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   static const bool force256 = getenv("MN_H2_HALO256") && atoi(getenv("MN_H2_HALO256")) != 0;  // (parity tests on small problems)
   static const int a1 = getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1;  // (see launch_igemm_halo)
   if (g2.N % 256 == 0 && ((tiles288 > 192 && tiles288 <= device_cus()) || force256) && igemm_halo_applies(g2, ep, 256, 352)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
+    if (q)
+      hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true, 3, 4, false, false, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
+                       g2.N / 256, rd);
+    else
+      hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 256, rd);
     return gm;
   }
@@ -587,14 +650,22 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   // (measured: 338 -> 304 us forward, 356 -> 326 data gradient, step 29.69 -> 29.52 ms; 288-row tiles of 6 waves at two workgroups
   //  per CU -- 27 % less DMA per row -- 409 us: six waves do not spread over four SIMDs; profiles/r04/c15_*, c16_*)
   if (halo64 && g2.N == 64 && igemm_halo_applies(g2, ep, 64, 368, 192)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<64, 368, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192)), dim3(256), 0, stream, g2, A, Bw, ep, 1,
+    if (q)
+      hipLaunchKernelGGL((igemm_halo_kernel<64, 368, 0, 1, true, 2, 2, true, false, 2, true>), dim3(cdiv(g2.M, 192)), dim3(256), 0, stream, g2, A, Bw, ep, 1,
+                       rd);
+    else
+      hipLaunchKernelGGL((igemm_halo_kernel<64, 368, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192)), dim3(256), 0, stream, g2, A, Bw, ep, 1,
                        rd);
     return cdiv(g2.M, 192);
   }
   // layer1's two-workgroup shape for the 128-column layers with at least two rounds of 192-row tiles (layer2): see launch_igemm_halo
   if (a1 > 0 && g2.N % 128 == 0 && (a1 == 2 || (long)cdiv(g2.M, 192) * (g2.N / 128) >= 2L * device_cus()) &&
       igemm_halo_applies(g2, ep, 128, 288, 192)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192) * (g2.N / 128)), dim3(256), 0, stream,
+    if (q)
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, true, 2, 2, true, false, 2, true>), dim3(cdiv(g2.M, 192) * (g2.N / 128)), dim3(256), 0, stream,
+                       g2, A, Bw, ep, g2.N / 128, rd);
+    else
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192) * (g2.N / 128)), dim3(256), 0, stream,
                        g2, A, Bw, ep, g2.N / 128, rd);
     return cdiv(g2.M, 192);
   }
@@ -606,13 +677,21 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
     const int cus = device_cus();
     const double e384 = (double)t384 / ((double)cdiv(t384, cus) * cus), e288 = (double)t288 / ((double)cdiv(t288, cus) * cus);
     if (bm384 == 2 || e384 >= e288 - 0.03) {
+    if (q)
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 480, 0, 1, true, 4, 2, false, false, 1, true>), dim3(cdiv(g2.M, 384) * (g2.N / 128)), dim3(512), 0, stream, g2,
+                         A, Bw, ep, g2.N / 128, rd);
+    else
       hipLaunchKernelGGL((igemm_halo_kernel<128, 480, 0, 1, true, 4, 2>), dim3(cdiv(g2.M, 384) * (g2.N / 128)), dim3(512), 0, stream, g2,
                          A, Bw, ep, g2.N / 128, rd);
       return cdiv(g2.M, 384);
     }
   }
   if (igemm_halo_applies(g2, ep, 128, 384)) {
-    hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,
+    if (q)
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true, 3, 4, false, false, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,
+                       g2.N / 128, rd);
+    else
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 128, rd);
     return gm;
   }

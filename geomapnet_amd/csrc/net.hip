@@ -531,11 +531,16 @@ struct Plan : PlanBase {
   // with fp16 conv operands in the backward pass) -- a fifth of the 4.9e-3 / 1.1e-2 by which two correct fp32 evaluations of this
   // network differ through ReLU gate flips.  The stem's backward stays on the fp32 chain of fp16x2.
   bool mixed = false;
+  // MN_DTYPE_F16X2Q (round 5; Plan<float> only): fp16x2m whose FORWARD convolutions take both cross terms of a split-operand product
+  // from fp8 copies on the block-scaled MFMA (common.h MMA_H2Q, h2q tensors): 2 instead of 3 MFMA-equivalents per forward product,
+  // poses ~3e-4 from the fp32 reference instead of 1.6e-5 (bar 1e-3)
+  bool q8 = false;
   std::string stage_error;  // set by a launch helper of a backward stage that cannot return a status itself
   Plan(const mn_config& c) {
     cfg = c;
     cur_scale = c.loss_scale;
-    mixed = DT == MN_F32 && c.dtype == MN_DTYPE_F16X2M;
+    q8 = DT == MN_F32 && c.dtype == MN_DTYPE_F16X2Q;
+    mixed = DT == MN_F32 && (c.dtype == MN_DTYPE_F16X2M || q8);
     h2 = DT == MN_F32 && (c.dtype == MN_DTYPE_F16X2 || mixed);
     stem_f16 = mixed && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
     if (c.dtype == MN_DTYPE_F32X3 || h2) {  // (fp16x2m: the stem's backward and its fp32 tensors)
@@ -663,6 +668,11 @@ struct Plan : PlanBase {
     const int hj = repack_head_jobs > 0 ? repack_head_jobs : repack_njobs;
     const int hb = repack_head_jobs > 0 ? repack_head_blocks : repack_blocks;
     if constexpr (DT == MN_F32) {
+      if (q8) {  // forward operand h2q, data-gradient operand plain fp16
+        hipLaunchKernelGGL((repack_all_kernel<float, true, true, true>), dim3(hb), dim3(256), 0, s, (const RepackJob*)repack_jobs, hj,
+                           (const float*)params, 0);
+        return;
+      }
       if (mixed) {  // forward operand h2, data-gradient operand plain fp16
         hipLaunchKernelGGL((repack_all_kernel<float, true, true>), dim3(hb), dim3(256), 0, s, (const RepackJob*)repack_jobs, hj,
                            (const float*)params, 0);
@@ -682,7 +692,11 @@ struct Plan : PlanBase {
     if (repack_blocks > hb) {
       bool done = false;
       if constexpr (DT == MN_F32) {
-        if (mixed) {
+        if (q8) {
+          hipLaunchKernelGGL((repack_all_kernel<float, true, true, true>), dim3(repack_blocks - hb), dim3(256), 0, s,
+                             (const RepackJob*)repack_jobs, repack_njobs, (const float*)params, hb);
+          done = true;
+        } else if (mixed) {
           hipLaunchKernelGGL((repack_all_kernel<float, true, true>), dim3(repack_blocks - hb), dim3(256), 0, s,
                              (const RepackJob*)repack_jobs, repack_njobs, (const float*)params, hb);
           done = true;
@@ -723,7 +737,7 @@ struct Plan : PlanBase {
     }
     auto* tp = timer.begin(0, s);
     if (h2 && &u != &stem)  // h2 activation and weights in, fp32 conv output + statistics out
-      launch_igemm_h2(u.gf, (const half*)x, (const half*)u.wf, ep, s, (const half*)zero_page);
+      launch_igemm_h2(u.gf, (const half*)x, (const half*)u.wf, ep, s, (const half*)zero_page, q8);
     else if (&u == &stem && DT == MN_F32 && mma_fwd == MMA_F16X3 && use_stem_kernel)  // the split-operand form of the stem kernel
       launch_stem_conv_x3((const float*)x, (const float*)u.wf, (float*)u.y, training ? u.accum_f : nullptr, u.rows_f, B, H, W, Wp, s);
     else if (&u == &stem && DT == MN_F16 && use_stem_kernel)  // weights in registers, input pairs read straight from LDS (stem.h)
@@ -758,7 +772,7 @@ struct Plan : PlanBase {
     if (h2) {  // fp32 conv output in, h2 activation out (residual: an h2 activation)
       const long ni = u.M * u.cp.cout / 8;
       hipLaunchKernelGGL(bn_apply_h2_kernel, dim3(ew_grid(ni)), dim3(256), 0, s, (const float*)u.y, (const float*)u.coef_f,
-                         (const half*)res, (half*)out, ni, u.cp.cout, relu, cur_training ? out16 : (half*)nullptr);
+                         (const half*)res, (half*)out, ni, u.cp.cout, relu, cur_training ? out16 : (half*)nullptr, q8 ? 1 : 0);
       return;
     }
     hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const float*)u.coef_f, res, out,
@@ -805,7 +819,7 @@ struct Plan : PlanBase {
       bn_finalize(stem, s);
       hipLaunchKernelGGL(bn_relu_maxpool_h2_kernel, dim3(ew_grid((long)B * H1 * W1 * 64 / 8)), dim3(256), 0, s,
                          (const float*)stem.y, (const float*)stem.coef_f, (half*)p0, pool_idx, B, H0, W0, 64, H1, W1,
-                         training ? p0_16 : (half*)nullptr, training && stem_bwd_f16() ? (half*)a0 : (half*)nullptr);
+                         training ? p0_16 : (half*)nullptr, training && stem_bwd_f16() ? (half*)a0 : (half*)nullptr, q8 ? 1 : 0);
     } else if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
       bn_finalize(stem, s);
       hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
@@ -833,7 +847,7 @@ struct Plan : PlanBase {
     int F = cfg.feat_dim;
     if (h2)
       hipLaunchKernelGGL(avgpool_fwd_h2_kernel, dim3(cdiv((long)B * 512, 256)), dim3(256), 0, s, (const half*)last.out, pooled,
-                         B, Hl * Wl, 512);
+                         B, Hl * Wl, 512, q8 ? 1 : 0);
     else
       hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(cdiv((long)B * 512, 256)), dim3(256), 0, s, (const T*)last.out, pooled,
                          B, Hl * Wl, 512);
@@ -1156,7 +1170,7 @@ struct Plan : PlanBase {
     if (n == "xpad") return give(xpad, (long)B * Hp * Wp * 4, DT);
     if (n == "stem.y") return give(stem.y, n0, DT);
     if (n == "stem.gy") return give(stem.gy, n0, DT);
-    const int AT = h2 ? MN_DTYPE_F16X2 : DT;  // dtype code of the tensors the convolutions consume (h2 in the fp16x2 mode)
+    const int AT = q8 ? MN_DTYPE_F16X2Q : h2 ? MN_DTYPE_F16X2 : DT;  // dtype code of the tensors the convolutions consume (h2 / h2q)
     // fp16x2m: d(conv output) and the data gradients are plain fp16 (in buffers carved for 4 bytes per element)
     const int GT = mixed ? MN_F16 : AT, GD = mixed ? MN_F16 : DT;
     if (n == "p0") return give(p0, n1, AT);
@@ -1256,7 +1270,7 @@ static int validate(const mn_config* c) {
   if (!c) return fail("null config");
   if (c->mode < 0 || c->mode > 3) return fail("config: bad mode");
   if (c->dtype != MN_DTYPE_F32 && c->dtype != MN_DTYPE_F16 && c->dtype != MN_DTYPE_F32X3 && c->dtype != MN_DTYPE_F16X2 &&
-      c->dtype != MN_DTYPE_F16X2M)
+      c->dtype != MN_DTYPE_F16X2M && c->dtype != MN_DTYPE_F16X2Q)
     return fail("config: bad dtype");
   if (c->windows < 1 || c->T < 1 || c->T > kMaxT) return fail("config: windows >= 1 and 1 <= T <= 8 required");
   if (c->mode == MN_MODE_POSENET && c->T != 1) return fail("config: PoseNet mode requires T = 1");
@@ -1379,7 +1393,8 @@ extern "C" int64_t mn_stuck_overflow_steps(mn_handle* h) { return (h && h->plan)
 extern "C" int mn_set_loss_scale(mn_handle* h, float scale, int growth_interval) {
   MN_H(h);
   if (!(scale > 0.f)) return fail("mn_set_loss_scale: scale must be positive");
-  if (P.cfg.dtype != MN_DTYPE_F16 && P.cfg.dtype != MN_DTYPE_F16X2 && P.cfg.dtype != MN_DTYPE_F16X2M && scale != 1.f)
+  if (P.cfg.dtype != MN_DTYPE_F16 && P.cfg.dtype != MN_DTYPE_F16X2 && P.cfg.dtype != MN_DTYPE_F16X2M &&
+      P.cfg.dtype != MN_DTYPE_F16X2Q && scale != 1.f)
     return fail("mn_set_loss_scale: fp32 plans do not scale the loss");
   P.cur_scale = scale;
   P.scale_set_at = P.attempts;

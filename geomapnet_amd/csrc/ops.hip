@@ -42,7 +42,8 @@ static GatherGeom to_geom(const mn_gather_geom* g) {
 
 static int check_geom(const GatherGeom& g, int dtype) {
   int vec = dtype == MN_F16 ? 8 : 4;
-  if (dtype == MN_DTYPE_F16X2 && (g.C % 32 != 0 || g.N % 4 != 0)) return fail("igemm: h2 operands need C % 32 == 0");
+  if ((dtype == MN_DTYPE_F16X2 || dtype == MN_DTYPE_F16X2Q) && (g.C % 32 != 0 || g.N % 4 != 0))
+    return fail("igemm: h2 operands need C % 32 == 0");
   if (g.C % vec != 0) return fail("igemm: C must be a multiple of the 16-byte piece");
   if (g.K != g.R * g.S * g.C) return fail("igemm: K != R*S*C");
   if (g.K % (4 * vec) != 0) return fail("igemm: K must be a multiple of the 64-byte K-step");
@@ -72,8 +73,8 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   ep.out = out; ep.ldc = ldc; ep.stats = stats; ep.bias = bias; ep.relu = relu; ep.res = res; ep.res_gate = res_gate;
   ep.alpha = alpha;
   if (dtype == MN_DTYPE_F32X3) g.mma = MMA_F16X3;  // fp32 tensors, f16 matrix pipe with split operands
-  if (dtype == MN_DTYPE_F16X2) {  // h2 operands (A, Bw, res_gate), fp32 out / res
-    launch_igemm_h2(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, (const half*)zero_page);
+  if (dtype == MN_DTYPE_F16X2 || dtype == MN_DTYPE_F16X2Q) {  // h2 / h2q operands (A, Bw, res_gate), fp32 out / res
+    launch_igemm_h2(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, (const half*)zero_page, dtype == MN_DTYPE_F16X2Q);
     return check_launch("igemm");
   }
   if (dtype == MN_F16)

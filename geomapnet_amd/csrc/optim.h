@@ -232,10 +232,20 @@ __device__ __forceinline__ void h2_put(void* base, long row, int C, int c, float
   p[0] = hi;
   p[32] = (half)(v - (float)hi);
 }
+// one weight element -> (row, c) of an h2q WEIGHT matrix (common.h): fp16 hi half where h2 has it, then the fp8 planes hi8 | lo8
+__device__ __forceinline__ void h2q_put_w(void* base, long row, int C, int c, float v) {
+  half* p = reinterpret_cast<half*>(base) + h2_index(row, C, c);
+  const half hi = (half)v;
+  p[0] = hi;
+  unsigned char* q = reinterpret_cast<unsigned char*>(base) + h2q_byte(row, C, c, 0);
+  q[0] = fp8_e4m3_from_float((float)hi * pow2c(kQW_HI));
+  q[32] = fp8_e4m3_from_float((v - (float)hi) * pow2c(kQW_LO));
+}
 // H2 (T = float): mode-0 destinations are h2 matrices -- the forward operand [O][R][S][I] split along I, the data-gradient
 // operand [I][R][S][O] along O (MN_DTYPE_F16X2); modes 2 and 3 (stem, fc) stay fp32.  B16 (with H2, the fp16x2m mode): the
 // data-gradient operand is a plain fp16 matrix -- the backward pass contracts single fp16 operands
-template <typename T, bool H2 = false, bool B16 = false>
+// AQ (with H2 and B16, the fp16x2q mode): the forward operand is an h2q weight matrix
+template <typename T, bool H2 = false, bool B16 = false, bool AQ = false>
 static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob* __restrict__ jobs, int njobs,
                                                                 const float* __restrict__ params, int blk_base) {
   const int bid = (int)blockIdx.x + blk_base;  // a launch may cover a sub-range of the table's workgroups
@@ -262,7 +272,9 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
       const long idx = ((long)(ot * 64 + row) * RS + rs) * I + it * 64 + col;
       const float v = src[idx];
       if (job.mode == 0 && job.dst_a) {
-        if constexpr (H2)
+        if constexpr (H2 && AQ)
+          h2q_put_w(job.dst_a, (long)(ot * 64 + row) * RS + rs, I, it * 64 + col, v);
+        else if constexpr (H2)
           h2_put(job.dst_a, (long)(ot * 64 + row) * RS + rs, I, it * 64 + col, v);
         else
           reinterpret_cast<T*>(job.dst_a)[idx] = (T)v;
@@ -302,7 +314,12 @@ static __global__ void __launch_bounds__(256) repack_all_kernel(const RepackJob*
       const int r = (int)(t % R);
       const int o = (int)(t / R);
       if constexpr (H2) {
-        if (job.dst_a) h2_put(job.dst_a, idx / I, I, i, v);
+        if (job.dst_a) {
+          if constexpr (AQ)
+            h2q_put_w(job.dst_a, idx / I, I, i, v);
+          else
+            h2_put(job.dst_a, idx / I, I, i, v);
+        }
         if constexpr (B16)
           reinterpret_cast<half*>(job.dst_b)[(((long)i * R + r) * S + s) * O + o] = (half)v;
         else

@@ -52,8 +52,14 @@ extern "C" {
  *                 that the h2 producers write beside the h2 tensor).  Gates and BatchNorm's backward statistics come from the
  *                 exact forward values (fp32 conv outputs), so the gradients differ from MN_DTYPE_F16X2's by operand rounding
  *                 only: 1.1e-3 relative L2 overall (tools/mixed_budget.py), below the 4.9e-3 by which two fp32 evaluations of
- *                 the reference's step differ through ReLU gate flips.  Loss scale + overflow guard as MN_DTYPE_F16. */
-enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1, MN_DTYPE_F32X3 = 2, MN_DTYPE_F16X2 = 3, MN_DTYPE_F16X2M = 4 };
+ *                 the reference's step differ through ReLU gate flips.  Loss scale + overflow guard as MN_DTYPE_F16.
+ * MN_DTYPE_F16X2Q: (round 5, plans only; experimental) MN_DTYPE_F16X2M whose forward convolutions take BOTH cross terms of a
+ *                 split-operand product from fp8 (e4m3) copies with fixed exponents on gfx950's block-scaled MFMA
+ *                 (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate): conv-consumed tensors are "h2q" -- fp16 hi halves where
+ *                 h2 has them, then an fp8 lo plane and an fp8 copy of the hi plane (geomapnet_amd/csrc/common.h) -- still 4 bytes
+ *                 per element.  2 instead of 3 MFMA-equivalents per forward product; poses ~3e-4 from the fp32 reference (bar
+ *                 1e-3) instead of 1.6e-5 (tools/fp8_cross_budget.py). */
+enum { MN_DTYPE_F32 = 0, MN_DTYPE_F16 = 1, MN_DTYPE_F32X3 = 2, MN_DTYPE_F16X2 = 3, MN_DTYPE_F16X2M = 4, MN_DTYPE_F16X2Q = 5 };
 /* criterion / batch-layout modes */
 enum {
   MN_MODE_POSENET = 0,      /* PoseNetCriterion,        common/criterion.py:33-52   */

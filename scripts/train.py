@@ -45,7 +45,7 @@ def build_parser():
     parser.add_argument("--dropout_active", action="store_true",
                         help="apply the config's dropout on the device in training mode (default: identity, the reference's "
                              "behaviour under its pinned PyTorch 0.4.1)")
-    parser.add_argument("--dtype", choices=("fp16", "fp16x2m", "fp16x2", "fp32x3", "fp32"), default="fp16x2m",
+    parser.add_argument("--dtype", choices=("fp16", "fp16x2m", "fp16x2q", "fp16x2", "fp32x3", "fp32"), default="fp16x2m",
                         help="compute precision of the HIP kernels.  Default fp16x2m: the reference computes in fp32 "
                              "(common/train.py:322-363) and this is the fastest mode whose loss and poses match it to 1e-4 / 1e-3 "
                              "(split-fp16 forward pass, single-fp16 backward pass).  fp16 is 1.5x faster and trains to the same "

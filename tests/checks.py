@@ -16,7 +16,7 @@ from geomapnet_amd.posenet import _view
 
 # dtype 2 = MN_DTYPE_F32X3: fp32 tensors, contraction on the f16 / bf16 matrix pipe with split (hi + lo) operands
 # dtype 3 = MN_DTYPE_F16X2: conv operands / gates are h2 tensors (fp16 pairs, helpers below), everything else fp32
-TD = {0: torch.float32, 1: torch.float16, 2: torch.float32, 3: torch.float32}
+TD = {0: torch.float32, 1: torch.float16, 2: torch.float32, 3: torch.float32, 5: torch.float32}
 # output rounding of the storage type relative to the largest output magnitude (x3: 2^-22 per product with fp16 halves,
 # 2^-16 with the bf16 halves of the backward operators)
 OUT_TOL = {0: 2e-5, 1: 2e-3, 2: 5e-5, 3: 2e-5}
@@ -98,6 +98,64 @@ def from_h2(h):
     Cc = h.shape[-1] // 2
     g = h.reshape(*h.shape[:-1], Cc // 32, 2, 32).float()
     return (g[..., 0, :] + g[..., 1, :]).reshape(*h.shape[:-1], Cc)
+
+
+# ---- h2q tensors (geomapnet_amd/csrc/common.h): the h2 layout with fp8 planes behind the fp16 hi halves ----------------------------
+QA_LO, QA_HI, QW_HI, QW_LO = 9, -1, 6, 16  # fixed exponents of the fp8 planes (common.h kQA_LO ...)
+
+
+def _fp8(x, e):
+    """fp8 e4m3 of x * 2^e, saturating; -> (uint8 codes, the values they stand for)"""
+    q = (x.float() * 2.0 ** e).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), q.float() * 2.0 ** -e
+
+
+def to_h2q(x, weight=False):
+    """fp32 [..., C] (C % 32 == 0) -> (fp16 [..., 2C] buffer in the h2q layout, hi values, plane-0 values, plane-1 values): activation
+    planes lo8 | hi8, weight planes hi8 | lo8"""
+    x = x.float()
+    Cc = x.shape[-1]
+    assert Cc % 32 == 0
+    hi = x.to(torch.float16)
+    lo = x - hi.float()
+    if weight:
+        c0, v0 = _fp8(hi.float(), QW_HI)
+        c1, v1 = _fp8(lo, QW_LO)
+    else:
+        c0, v0 = _fp8(lo, QA_LO)
+        c1, v1 = _fp8(hi.float(), QA_HI)
+    g = Cc // 32
+    hib = hi.reshape(*x.shape[:-1], g, 32).contiguous().view(torch.uint8).reshape(*x.shape[:-1], g, 64)
+    buf = torch.cat((hib, c0.reshape(*x.shape[:-1], g, 32), c1.reshape(*x.shape[:-1], g, 32)), dim=-1)  # [..., g, 128] bytes
+    return buf.reshape(*x.shape[:-1], 4 * Cc).contiguous().view(torch.float16), hi.float(), v0, v1
+
+
+def check_conv_fwd_h2q(lib, dev, B, H, W, Cin, Cout, k, stride, pad, seed=0):
+    """h2q operands (dtype 5): hi*hi on the fp16 pipe + both cross terms from the fp8 planes in one scaled MFMA per K-step, against
+    torch fp64 on EXACTLY the values the planes stand for (so the bar is accumulation rounding, not the fp8 approximation)"""
+    _fresh()
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) * (2.0 / (Cin * k * k)) ** 0.5
+    xb, xhi, xlo8, xhi8 = to_h2q(x.permute(0, 2, 3, 1))
+    wb, whi, whi8, wlo8 = to_h2q(w.permute(0, 2, 3, 1), weight=True)
+    nchw = lambda t: t.permute(0, 3, 1, 2).double()  # noqa: E731
+    ref = (F.conv2d(nchw(xhi), nchw(whi), stride=stride, padding=pad) + F.conv2d(nchw(xlo8), nchw(whi8), stride=stride, padding=pad) +
+           F.conv2d(nchw(xhi8), nchw(wlo8), stride=stride, padding=pad))
+    exact = F.conv2d(x.double(), w.double(), stride=stride, padding=pad)
+    g, Ho, Wo = fwd_geom(B, H, W, Cin, Cout, k, stride, pad)
+    out = torch.zeros(B, Ho, Wo, Cout, dtype=torch.float32, device=dev)
+    st = torch.zeros(lib.op_igemm_grid_m(g.M), 2, Cout, device=dev)
+    lib.check(lib.op_igemm(5, C.byref(g), K(xb.to(dev)), K(wb.to(dev)), K(out), Cout, K(st), None, 0, None, None, f32(1),
+                           K(zero_page(dev)), None))
+    dev_sync(dev)
+    o = out.cpu().double().permute(0, 3, 1, 2)
+    scale = ref.abs().max().item()
+    err = (o - ref).abs().max().item()
+    assert err <= 2e-5 * scale + 1e-6, (err, scale)
+    approx = (o - exact).abs().max().item() / scale  # what the fp8 cross terms cost this product: ~2^-15 per term
+    assert approx <= 2e-4, approx
+    return err / scale, approx
 
 
 def q_op(x, dtype):
@@ -1475,7 +1533,7 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
     rec = {"mode": mode, "windows": N, "images": N * frames, "H": H, "W": W, "oracle_step_s": round(oracle_s, 1),
            "loss_oracle": lo, "pose_scale": po.abs().max().item()}
     del omodel, oopt
-    for dtype_name in ("fp16x2m", "fp16x2", "fp32x3", "fp32", "fp16"):
+    for dtype_name in ("fp16x2m", "fp16x2", "fp16x2q", "fp32x3", "fp32", "fp16"):
         G.set_compute_dtype(dtype_name)
         net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, filter_nans=filter_nans, _binding=lib))
         net.load_state_dict(sd0)
@@ -1540,6 +1598,14 @@ def check_full_size_parity(lib, dev, mode, N, H=256, W=341, max_grad_norm=0.0, l
         assert rec[name]["pose_abs_max"] <= fp32_pose_atol, (name, rec)
         if rec[name]["grad_l2_rel_all"] is not None:  # (gate flips: DESIGN.md section 6)
             assert rec[name]["grad_l2_rel_all"] <= 2e-2 and rec[name]["grad_l2_rel_worst_tensor"] <= 5e-2, (name, rec)
+    # fp16x2q (experimental: fp8 cross terms in the forward convolutions): the POSES stay inside the north-star bar and the loss inside
+    # its relative reading, at a margin of 1.5-2.5x instead of fp16x2m's 60x; the gradients are off by percents (the 1e-4-relative forward
+    # error moves ReLU gates and BatchNorm statistics: measured 2.9 % / 6.8 % at configs[2]) -- between fp16x2m (0.5 % / 1.3 %) and fp16
+    # (15.8 % / 38.9 %): NOT a parity mode
+    q = rec["fp16x2q"]
+    assert q["loss_rel"] <= 1e-4 and q["pose_abs_max"] <= 1e-3, rec
+    if q["grad_l2_rel_all"] is not None:
+        assert q["grad_l2_rel_all"] <= 0.06 and q["grad_l2_rel_worst_tensor"] <= 0.15, rec
     env = FP16_ENVELOPE
     assert rec["fp16"]["loss_rel"] <= env["loss_rel"] and rec["fp16"]["pose_abs_max"] <= env["pose_abs_max"], rec
     if rec["fp16"]["grad_l2_rel_all"] is not None:

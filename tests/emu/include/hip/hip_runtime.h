@@ -279,6 +279,62 @@ inline emu_floatx16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf
   return emu_mfma_32x32x16(a, b, c);
 }
 
+// v_mfma_scale_f32_32x32x64_f8f6f4 with fp8 (e4m3) operands (cbsz = blgp = 0), as probed on MI355X (tools/probes/mfma_scale_probe*.hip,
+// profiles/r05/c12_mfma_scale_probe.txt): lane l holds row / column l & 31; its 32 bytes are bytes 0-15 = 16 k values of MX block 0,
+// bytes 16-31 = 16 k values of MX block 1 (the two lanes of a row complete a block's 32 values); block b of a row is scaled by
+// 2^(byte - 127) of the scale register of lane (row + 32 b), `opsel` choosing the byte; C/D in the f16 forms' map.
+struct emu_mfma_slot_q {
+  unsigned char a[32], b[32];
+  unsigned char sa, sb;
+};
+inline float emu_fp8_e4m3(unsigned char v) {
+  const int ef = (v >> 3) & 15, m = v & 7;
+  float f = ef == 0 ? ldexpf((float)m, -9) : ldexpf((float)(8 + m), ef - 10);
+  if (ef == 15 && m == 7) f = NAN;
+  return (v & 0x80) ? -f : f;
+}
+template <typename V8>
+inline emu_floatx16 __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(V8 a, V8 b, emu_floatx16 c, int, int, int opsel_a, int scale_a,
+                                                                    int opsel_b, int scale_b) {
+  static_assert(sizeof(V8) == 32, "8 dwords per operand");
+  int l = emu::cur->lane;
+  emu_mfma_slot_q s;
+  memcpy(s.a, &a, 32);
+  memcpy(s.b, &b, 32);
+  s.sa = (unsigned char)((unsigned)scale_a >> (8 * opsel_a));
+  s.sb = (unsigned char)((unsigned)scale_b >> (8 * opsel_b));
+  memcpy(emu::wave_slot(l), &s, sizeof(s));
+  emu::wave_sync();
+  const int j = l & 31;
+  const emu_mfma_slot_q* b0 = reinterpret_cast<const emu_mfma_slot_q*>(emu::wave_slot(j));
+  const emu_mfma_slot_q* b1 = reinterpret_cast<const emu_mfma_slot_q*>(emu::wave_slot(j + 32));
+  float bv[2][32];  // [block][k in block]: k < 16 from the lane of half 0, k >= 16 from the lane of half 1
+  for (int blk = 0; blk < 2; ++blk)
+    for (int e = 0; e < 16; ++e) {
+      bv[blk][e] = emu_fp8_e4m3(b0->b[16 * blk + e]);
+      bv[blk][16 + e] = emu_fp8_e4m3(b1->b[16 * blk + e]);
+    }
+  const float sbf[2] = {ldexpf(1.f, (int)b0->sb - 127), ldexpf(1.f, (int)b1->sb - 127)};
+  for (int reg = 0; reg < 16; ++reg) {
+    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
+    const emu_mfma_slot_q* a0 = reinterpret_cast<const emu_mfma_slot_q*>(emu::wave_slot(i));
+    const emu_mfma_slot_q* a1 = reinterpret_cast<const emu_mfma_slot_q*>(emu::wave_slot(i + 32));
+    const float saf[2] = {ldexpf(1.f, (int)a0->sa - 127), ldexpf(1.f, (int)a1->sa - 127)};
+    float acc = c[reg];
+    for (int blk = 0; blk < 2; ++blk) {
+      float sum = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        sum += emu_fp8_e4m3(a0->a[16 * blk + e]) * bv[blk][e];
+        sum += emu_fp8_e4m3(a1->a[16 * blk + e]) * bv[blk][16 + e];
+      }
+      acc += sum * saf[blk] * sbf[blk];
+    }
+    c[reg] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
 // v_mfma_f32_16x16x32_f16: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15],
 // D: col=l&15, row=4*(l>>4)+reg
 inline emu_floatx4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu_half8 a, emu_half8 b, emu_floatx4 c, int, int, int) {

@@ -25,6 +25,17 @@ def test_conv_forward(lib, dtype, shape):
 
 
 @pytest.mark.parametrize("shape", [
+    (2, 9, 11, 64, 64, 3, 1, 1),     # layer1-like (chunk-resident 64-column shape)
+    (2, 9, 11, 64, 128, 3, 2, 1),    # stride-2 3x3 (generic kernel)
+    (1, 8, 10, 64, 128, 1, 2, 0),    # 1x1 projection
+    (3, 5, 6, 128, 256, 3, 1, 1),    # chunk-resident 128-column shapes
+])
+def test_conv_forward_with_fp8_cross_terms(lib, shape):
+    """h2q operands (round 5, the fp16x2q mode's forward convolutions): one scaled fp8 MFMA per K-step for both cross terms"""
+    checks.check_conv_fwd_h2q(lib, DEV, *shape)
+
+
+@pytest.mark.parametrize("shape", [
     (2, 6, 7, 128, 256),    # 256-column shape, two 64-channel chunks
     (1, 5, 9, 192, 128),    # 128-column shape, three chunks
 ])

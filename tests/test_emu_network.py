@@ -38,6 +38,17 @@ def test_mapnet_train_step_fp16x2m_parity(lib):
     assert rep[0][2] < 1e-3
 
 
+def test_mapnet_train_step_fp16x2q_fp8_cross_terms(lib):
+    """fp16x2q (experimental): fp16x2m with both cross terms of every forward product from fp8 copies on the block-scaled MFMA.  The
+    poses stay inside the north-star bar (1e-3; the approximation costs ~5e-4 at this small shape, ~4e-4 at the benchmark shape,
+    tools/fp8_cross_budget.py), the loss inside 1e-3 relative here (1e-5 at the benchmark shape) -- NOT the 1e-4 the parity modes are
+    held to -- and the gradients inside 15 % per tensor (measured 7 % here, 2.9 % / 6.8 % overall / worst at the benchmark shape: the
+    1e-4-relative forward error moves ReLU gates and BatchNorm statistics; fp16x2m: 1.5 % here, 0.5 % / 1.3 % there)"""
+    rep = checks.check_train_step(lib, DEV, "fp16x2q", mode="mapnet", N=2, H=64, W=85, steps=1, loss_rtol=1e-3, pose_atol=1e-3,
+                                  grad_l2_rtol=0.15)
+    assert rep[0][2] < 1e-3
+
+
 def test_dropout_on_the_device_with_the_oracle_applying_the_same_mask(lib):
     checks.check_dropout(lib, DEV, "fp32", N=1, H=32, W=40, wiring=False)
 

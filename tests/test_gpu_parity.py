@@ -224,6 +224,24 @@ def test_posenet_train_step_fp16x2m(lib):
     checks.check_train_step(lib, DEV, "fp16x2m", mode="posenet", N=5, H=64, W=85, steps=1)
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 9, 11, 64, 64, 3, 1, 1), (2, 9, 11, 64, 128, 3, 2, 1), (1, 8, 10, 64, 128, 1, 2, 0), (3, 5, 6, 128, 256, 3, 1, 1),
+    (7, 16, 22, 256, 256, 3, 1, 1), (4, 32, 43, 128, 128, 3, 1, 1), (5, 8, 11, 512, 512, 3, 1, 1), (1, 64, 86, 64, 64, 3, 1, 1),
+])
+def test_conv_forward_with_fp8_cross_terms(lib, shape):
+    """h2q operands (the experimental fp16x2q mode's forward convolutions): hi*hi on the fp16 pipe + both cross terms of a K-step in one
+    v_mfma_scale_f32_32x32x64_f8f6f4 from the fp8 planes, against torch fp64 on exactly the values the planes stand for -- this pins
+    the instruction's operand layout and scale semantics as probed (tools/probes/mfma_scale_probe*.hip) on real layer geometries"""
+    checks.check_conv_fwd_h2q(lib, DEV, *shape)
+
+
+def test_mapnet_train_step_fp16x2q_fp8_cross_terms(lib):
+    """the experimental mode's whole step at full resolution: poses inside the north-star bar (at a 2x margin instead of fp16x2m's
+    60x), loss inside 1e-3 relative at this 6-image batch (7e-6 at the benchmark batch), gradients inside 15 % per tensor"""
+    checks.check_train_step(lib, DEV, "fp16x2q", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-3, pose_atol=1e-3,
+                            pose_abs=1e-3, grad_l2_rtol=0.15)
+
+
 def test_mapnet_train_step_fp16x2_two_steps_small(lib):
     checks.check_train_step(lib, DEV, "fp16x2", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
 

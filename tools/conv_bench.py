@@ -15,11 +15,13 @@ from geomapnet_amd._binding import ptr  # noqa: E402
 
 # MN_LIB: an alternative build of the library (the ablation build, `make -C geomapnet_amd/csrc ablation`)
 lib = _binding.Binding(C.CDLL(os.environ["MN_LIB"])) if os.environ.get("MN_LIB") else _binding.hip()
-dtype = {"fp16": 1, "fp32": 0, "fp32x3": 2, "fp16x2": 3}[sys.argv[1] if len(sys.argv) > 1 else "fp16"]
-H2 = dtype == 3
+dtype = {"fp16": 1, "fp32": 0, "fp32x3": 2, "fp16x2": 3, "fp16x2q": 5}[sys.argv[1] if len(sys.argv) > 1 else "fp16"]
+H2 = dtype in (3, 5)
 
 
-def up(t):  # a channels-last operand in the storage form of `dtype` (dtype 3: h2 pairs, split on the device)
+def up(t, weight=False):  # a channels-last operand in the storage form of `dtype` (dtype 3: h2 pairs, split on the device)
+    if dtype == 5:
+        return checks.to_h2q(t.cpu(), weight)[0].cuda()
     return checks.to_h2(t) if H2 else t.to(td)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 td = checks.TD[dtype]
@@ -45,8 +47,8 @@ def bench(name, H, W, Ci, Co, k, stride, pad):
     gd, _, _ = checks.dgrad_geom(B, H, W, Ci, Co, k, stride, pad)
     w32 = torch.randn(Co, k, k, Ci, device="cuda") * 0.05
     x = up(torch.randn(B, H, W, Ci, device="cuda"))
-    w = up(w32)
-    wt = up(w32.permute(3, 1, 2, 0).contiguous())
+    w = up(w32, True)
+    wt = up(w32.permute(3, 1, 2, 0).contiguous(), True)
     gy = up(torch.randn(B, Ho, Wo, Co, device="cuda"))
     y = torch.empty(B, Ho, Wo, Co, dtype=td, device="cuda")
     gx = torch.empty(B, H, W, Ci, dtype=td, device="cuda")

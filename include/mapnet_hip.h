@@ -213,7 +213,8 @@ int64_t mn_stuck_overflow_steps(mn_handle* h);
  * (+ "yd", "zd", "gyd" for blocks with a projection); NHWC.  In the fp16x2 mode the tensors the convolutions consume ("p0",
  * "a1", "out", "zd", "gy1", "gy2", "gyd") are h2 tensors and report dtype MN_DTYPE_F16X2; in the fp16x2m mode the forward ones
  * of these are h2 and every gradient tensor of the blocks ("gp0", "gy1", "ga1", "gy2", "gout", "gyd") is plain fp16 (MN_DTYPE_F16),
- * and "p0.f16" / "b<i>.a1.f16" / "b<i>.out.f16" name the plain fp16 copies of the activations.  Read-only for the caller. */
+ * and "p0.f16" / "b<i>.a1.f16" / "b<i>.out.f16" name the plain fp16 copies of the activations; in the fp16x2q mode the forward ones are
+ * h2q tensors (geomapnet_amd/csrc/common.h) and report MN_DTYPE_F16X2Q.  Read-only for the caller. */
 int mn_debug_tensor(mn_handle* h, const char* name, void** ptr, int64_t* numel, int32_t* dtype);
 
 /* parameters changed behind the library's back (load_state_dict): refresh compute copies */

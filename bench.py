@@ -10,10 +10,12 @@ path and the N > 1 code path are the same function.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): MapNet, ResNet-34, 256x341,
 window T=3, 64 windows = 192 images per GPU per step, fp16 operands / fp32 accumulate; the same run then times the
-parity mode (fp16x2: every conv operand an fp16 PAIR, hi + lo halves split once by the producing kernel, three fp16 MFMAs per
-product on DMA-fed operands, fp32 everything else -- the mode the north-star tolerance is met in) and reports it as
-`parity_mode`; --dtype fp32x3 / fp32 time the round-3 parity mode (operands split inside the conv kernels) / the exact-fp32
-MFMA build.
+parity mode (fp16x2m: every conv operand of the FORWARD pass an fp16 PAIR, hi + lo halves split once by the producing kernel,
+three fp16 MFMAs per product on DMA-fed operands, fp32 everything else -- so loss and poses meet the north-star tolerance -- and
+the fp16 mode's one-MFMA backward pass on exact gates) and reports it as `parity_mode`, then the experimental fp16x2q mode (the
+forward cross terms on the block-scaled fp8 MFMA: `experimental_mode`) and round 4's parity mode fp16x2 (three MFMAs per
+product in the backward pass too: `parity_mode_full`); --dtype fp32x3 / fp32 time the round-3 parity mode (operands split inside
+the conv kernels) / the exact-fp32 MFMA build.
 MapNetCriterion with learned beta/gamma, Adam lr 1e-4 wd 5e-4; synthetic inputs
 resident in HBM before the timed region; random-init weights.  One "step" = one call of
 geomapnet_amd.step_feedfwd(train=True) = forward + criterion + backward + Adam, including the blocking loss
@@ -25,7 +27,9 @@ Prints ONE JSON line on rank 0 with
   `cpu_baseline`  the oracle (a port of the reference path) timed on this host on a bounded sample;
   `parity`        loss / pose deviation of the TIMED dtype from the oracle on one step of the full workload
                   (identical batch and weights; the oracle is the checker, never the thing measured);
-  `parity_mode`   images/s, roofline and parity of the fp16x2 mode, timed by the same code in the same run.
+  `parity_mode`   images/s, roofline and parity (loss, poses, gradients against the oracle and against fp16x2) of the fp16x2m mode,
+                  timed by the same code in the same run; `experimental_mode`, `parity_mode_full`: the same records for fp16x2q / fp16x2;
+  `eval_metric`   median translation / rotation error of models trained in the timed dtype and in the parity mode (five seeds).
 """
 import argparse
 import json

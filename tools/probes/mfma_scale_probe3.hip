@@ -2,6 +2,8 @@
 // Integer data, scale of lane half 0 / 1: A 2^-1 / 2^1, B 2^2 / 2^-2.  Models for "which lane's byte scales MX block b":
 //   M1  A: lane (row + 32 b), B: lane (col + 32 b)      M2  A as M1, B: lane (col + 32 (1 - b))
 //   M3  A: lane (row + 32 (1 - b)), B as M1             M4  both swapped
+// Measured on MI355X: M1 (0 of 1024 outputs differ; M2-M4: > 1000) -- also with the fp16x2q kernels' own scale bytes (118 / 128 on A,
+// 121 / 111 on B: products of 2^-15 in both blocks), profiles/r05/c12_mfma_scale_probe.txt.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

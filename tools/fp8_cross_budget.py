@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 import oracle  # noqa: E402  (tooling, not product)
 from tools.fp16_budget_backward import bn_train  # noqa: E402
 
-MODE = {"cross": "exact"}
+MODE = {"cross": "exact", "from_layer": 0, "layer": 0}  # "fp8f" from_layer = L: fp8 cross terms from layer L on, fp16 ones before
 
 
 def hi_lo(x):
@@ -65,7 +65,7 @@ def conv(x, w, stride, pad):
     xh, xl = hi_lo(x)
     wh, wl = hi_lo(w)
     y = F.conv2d(xh, wh, None, stride, pad)
-    if MODE["cross"] == "exact":
+    if MODE["cross"] == "exact" or (MODE["cross"] == "fp8f" and MODE["layer"] < MODE["from_layer"]):
         y = y + F.conv2d(xl, wh, None, stride, pad) + F.conv2d(xh, wl, None, stride, pad)
     elif MODE["cross"] == "fp8":
         y = y + F.conv2d(q8(xl, 1), q8(wh, 1), None, stride, pad) + F.conv2d(q8(xh, 1), q8(wl, 1), None, stride, pad)
@@ -83,12 +83,14 @@ def forward(net, x):
     y = conv(x, fe.conv1.weight, 2, 3)
     a = F.max_pool2d(F.relu(bn_train(y, fe.bn1)), 3, 2, 1)
     for li in range(1, 5):
+        MODE["layer"] = li
         for blk in getattr(fe, "layer%d" % li):
             st = blk.conv1.stride[0]
             a1 = F.relu(bn_train(conv(a, blk.conv1.weight, st, 1), blk.bn1))
             z = bn_train(conv(a1, blk.conv2.weight, 1, 1), blk.bn2)
             # what a reader of the STORED activation gets (residual add, average pool): hi + lo, with lo an fp8 in the fixed-exponent form
-            stored = (lambda t: hi_lo(t)[0] + q8f(hi_lo(t)[1], 9)) if MODE["cross"] == "fp8f" else (lambda t: t)
+            stored = ((lambda t: hi_lo(t)[0] + q8f(hi_lo(t)[1], 9)) if MODE["cross"] == "fp8f" and li >= MODE["from_layer"]
+                      else (lambda t: t))
             sc = bn_train(conv(a, blk.downsample[0].weight, st, 0), blk.downsample[1]) if blk.downsample is not None else stored(a)
             a = F.relu(z + sc)
     p = (stored(a) if MODE["cross"] == "fp8f" else a).mean((2, 3))
@@ -111,6 +113,13 @@ def main():
         ref = forward(net, x)
         print("batch %d windows x 3 = %d images %dx%d, pose scale %.2f" % (n, n * 3, H, W, ref.abs().max().item()), flush=True)
         print("%-66s %10s %10s" % ("convolutions contracted as", "pose max", "pose rms"))
+        for name, m, L in (("... FIXED exponents, fp8 cross terms from layer2 on (stem, layer1: fp16 cross terms)", "fp8f", 2),
+                           ("... FIXED exponents, fp8 cross terms from layer3 on", "fp8f", 3),
+                           ("... FIXED exponents, fp8 cross terms in layer4 only", "fp8f", 4)):
+            MODE["cross"], MODE["from_layer"] = m, L
+            d = forward(net, x) - ref
+            print("%-66s %10.3e %10.3e" % (name, d.abs().max().item(), d.pow(2).mean().sqrt().item()), flush=True)
+        MODE["from_layer"] = 0
         for name, m in (("hi*hi + hi*lo + lo*hi, all fp16 (= fp16x2: 3 MFMAs per product)", "exact"),
                         ("hi*hi fp16 + both cross terms in MXFP8 e4m3 (2 MFMA-equivalents)", "fp8"),
                         ("... with one power-of-two scale per TENSOR instead of per 32 channels", "fp8t"),

@@ -458,6 +458,10 @@ def main():
                 "value": round(images_per_step / (pms / 1e3), 2), "unit": "images/s", "ms_per_step": round(pms, 3),
                 "region_ms_per_step": r_["region_ms_per_step"], "comm_exposed_ms": r_["comm_exposed_ms"],
                 "loss_first": r_["loss_first"], "loss_last": r_["loss_last"], "roofline": roofline(r_, pms)}
+            if key == "parity_mode_full":
+                out[key]["note"] = ("timed as the FOURTH model of this process, which measures ~1-1.5 ms per step slow whichever mode it is "
+                                    "(profiles/r05/c16_*: fp16x2 28.4 ms as the third model, 30.0-30.5 ms as the fourth; neither the allocator "
+                                    "cache nor thermal)")
         if args.emu:
             out["data"] = "synthetic (CPU emulator dry-run: NOT a measurement)"
         if world == 1 and not args.no_cpu_baseline:

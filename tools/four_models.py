@@ -1,0 +1,11 @@
+"""Diagnostic: `bench.timed_mode` for several models in ONE process, e.g. `python tools/four_models.py fp16 fp16 fp16 fp16 fp16 fp16`.
+Measured on MI355X (profiles/r05/c16_*): the FOURTH model of a process runs ~5-10 % slow whichever mode it is -- the fifth and sixth are
+normal again -- so it is a property of where that model's freshly allocated arenas land, not of the kernels."""
+import sys, types, torch
+sys.path.insert(0, '/root/repo')
+import bench
+args = types.SimpleNamespace(windows=64, height=256, width=341, warmup=5, steps=50, no_events=True, emu=False)
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+for i, dt in enumerate(sys.argv[1:]):
+    r = bench.timed_mode(args, dt, dev, None, 1, 0, 2)
+    print(i + 1, dt, r["region_ms_per_step"], "mem reserved GB %.1f" % (torch.cuda.memory_reserved() / 1e9), flush=True)

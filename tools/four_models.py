@@ -6,6 +6,11 @@ sys.path.insert(0, '/root/repo')
 import bench
 args = types.SimpleNamespace(windows=64, height=256, width=341, warmup=5, steps=50, no_events=True, emu=False)
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+tiny = types.SimpleNamespace(windows=1, height=32, width=40, warmup=1, steps=1, no_events=True, emu=False)
 for i, dt in enumerate(sys.argv[1:]):
+    if dt == "tiny":  # a throw-away 3-image model between the real ones
+        bench.timed_mode(tiny, "fp32", dev, None, 1, 0, 1)
+        print(i + 1, "tiny", flush=True)
+        continue
     r = bench.timed_mode(args, dt, dev, None, 1, 0, 2)
     print(i + 1, dt, r["region_ms_per_step"], "mem reserved GB %.1f" % (torch.cuda.memory_reserved() / 1e9), flush=True)

@@ -1301,6 +1301,35 @@ def check_nan_filter(lib, dev, dtype_name="fp32", N=2, H=64, W=85):
 
 
 # ---- fp16 overflow: the step is skipped on the device, the host lowers the loss scale -----------------------------------
+def check_debug_tensor_decodes_pair_layouts(lib, dev, N=1, H=32, W=40):
+    """Engine.debug_tensor on the h2 / h2q tensors of the split-operand modes (dtype codes 3 / 5) returns VALUES, not the bytes of the
+    pair layout viewed as floats (round-4 ADVICE): the first block's `a1` of an fp16x2 / fp16x2m / fp16x2q forward pass against the
+    fp32 plan's on the same input and weights"""
+    _fresh()
+    import geomapnet_amd as G
+    x, _ = oracle.make_batch("mapnet", N, H, W, seed=7)
+    got = {}
+    sd0 = None
+    for dt in ("fp32", "fp16x2", "fp16x2m", "fp16x2q"):
+        G.set_compute_dtype(dt)
+        _, net = build_pair(lib, dev)
+        if sd0 is None:
+            sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        else:
+            net.load_state_dict(sd0)
+        net.train()
+        net(x.to(dev))
+        eng = net.mapnet._engine
+        plan = next(iter(eng.plans.values()))
+        got[dt] = {n: eng.debug_tensor(plan, n).float().cpu().clone() for n in ("p0", "b0.a1", "b0.out")}
+    for dt, tol in (("fp16x2", 1e-5), ("fp16x2m", 1e-5), ("fp16x2q", 5e-4)):
+        for n, ref in got["fp32"].items():
+            v = got[dt][n]
+            assert v.shape == ref.shape, (dt, n, v.shape, ref.shape)
+            err = ((v - ref).norm() / ref.norm()).item()
+            assert err <= tol, (dt, n, err)
+
+
 def check_overflow_skip(lib, dev, N=1, H=40, W=53, more=3, dtype_name="fp16"):
     """A loss scale far too large makes the fp16 activation gradients overflow: the step must leave parameters, Adam
     moments and the Adam step counter untouched (no inf/NaN anywhere), be counted, and the scale must come down; with a

@@ -53,6 +53,10 @@ def test_dropout_on_the_device_with_the_oracle_applying_the_same_mask(lib):
     checks.check_dropout(lib, DEV, "fp32", N=1, H=32, W=40, wiring=False)
 
 
+def test_debug_tensor_decodes_the_pair_layouts(lib):
+    checks.check_debug_tensor_decodes_pair_layouts(lib, DEV)
+
+
 def test_eval_forward_fp32(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=2, H=40, W=53)
 

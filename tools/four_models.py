@@ -6,6 +6,18 @@ sys.path.insert(0, '/root/repo')
 import bench
 args = types.SimpleNamespace(windows=64, height=256, width=341, warmup=5, steps=50, no_events=True, emu=False)
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+_empty = torch.empty
+PTRS = []
+
+
+def _logged_empty(*a, **k):  # where the big arenas land (work arena, optimiser state): address modulo 2 MiB / 1 GiB
+    t = _empty(*a, **k)
+    if t.is_cuda and t.numel() * t.element_size() > (1 << 28):
+        PTRS.append((t.numel() * t.element_size() / 1e9, t.data_ptr() % (2 << 20), (t.data_ptr() >> 30)))
+    return t
+
+
+torch.empty = _logged_empty
 tiny = types.SimpleNamespace(windows=1, height=32, width=40, warmup=1, steps=1, no_events=True, emu=False)
 for i, dt in enumerate(sys.argv[1:]):
     if dt == "tiny":  # a throw-away 3-image model between the real ones
@@ -13,4 +25,6 @@ for i, dt in enumerate(sys.argv[1:]):
         print(i + 1, "tiny", flush=True)
         continue
     r = bench.timed_mode(args, dt, dev, None, 1, 0, 2)
-    print(i + 1, dt, r["region_ms_per_step"], "mem reserved GB %.1f" % (torch.cuda.memory_reserved() / 1e9), flush=True)
+    print(i + 1, dt, r["region_ms_per_step"], "mem reserved GB %.1f" % (torch.cuda.memory_reserved() / 1e9),
+          "arenas (GB, address mod 2 MiB, address >> 30):", PTRS, flush=True)
+    PTRS.clear()

@@ -35,9 +35,9 @@ def _worker(rank, world, port, same_data, out_dir):
     dist.destroy_process_group()
 
 
-def _fp16_worker(rank, world, port, out_dir):
-    """three fp16 staged steps (loss scaling, overflow guard, fp16 kernels incl. the fused weight gradient) on
-    rank-specific windows; every rank saves its replica after each step"""
+def _fp16_worker(rank, world, port, out_dir, dtype="fp16", steps=3):
+    """`steps` staged steps in a loss-scaled mode (fp16: loss scaling, overflow guard, fp16 kernels incl. the fused weight gradient;
+    fp16x2m: the split-operand forward pass in front of them) on rank-specific windows; every rank saves its replica after each step"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MAPNET_EMU_THREADS"] = "4"
@@ -47,7 +47,7 @@ def _fp16_worker(rank, world, port, out_dir):
     import geomapnet_amd as G
     import oracle
     lib = emu_lib.load()
-    G.set_compute_dtype("fp16")
+    G.set_compute_dtype(dtype)
     torch.manual_seed(7)
     net = G.MapNet(G.PoseNet(G.resnet34(_binding=lib), droprate=0.0, pretrained=False, _binding=lib))
     crit = G.MapNetCriterion(sax=0.0, saq=-3.0, srx=0.0, srq=-3.0, learn_beta=True, learn_gamma=True, _binding=lib)
@@ -56,7 +56,7 @@ def _fp16_worker(rank, world, port, out_dir):
     net.train()
     eng = net.mapnet._engine
     snaps, losses = [], []
-    for step in range(3):
+    for step in range(steps):
         x, t = oracle.make_batch("mapnet", 1, 32, 40, seed=100 * step + rank)
         loss, _ = G.step_feedfwd(x, net, False, t, crit, opt, True)
         losses.append(loss)
@@ -66,17 +66,18 @@ def _fp16_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.slow
-def test_two_rank_fp16_replicas_stay_bit_identical_over_three_steps(tmp_path):
-    """the data-parallel fp16 step: gradients differ per rank before the all-reduce (different windows), parameters
-    must be bit-identical on both ranks after every one of three optimiser steps, the reported loss is the same mean on
-    both, and no step was skipped"""
-    port = 33500 + os.getpid() % 2000
-    mp.spawn(_fp16_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("dtype,steps", [("fp16", 3), ("fp16x2m", 2)])
+def test_two_rank_fp16_replicas_stay_bit_identical_over_three_steps(tmp_path, dtype, steps):
+    """the data-parallel step of the loss-scaled modes (fp16; fp16x2m, the scripts' default since round 5): gradients differ per rank
+    before the all-reduce (different windows), parameters must be bit-identical on both ranks after every optimiser step, the reported
+    loss is the same mean on both, and no step was skipped"""
+    port = 33500 + os.getpid() % 2000 + (0 if dtype == "fp16" else 2000)
+    mp.spawn(_fp16_worker, args=(2, port, str(tmp_path), dtype, steps), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "fp16_rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "fp16_rank1.pt"))
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
-    assert not torch.equal(r0["params"][0], r0["params"][2])  # the steps did move the weights
+    assert not torch.equal(r0["params"][0], r0["params"][-1])  # the steps did move the weights
     assert r0["losses"] == r1["losses"] and all(l == l for l in r0["losses"])
     assert r0["state"] == r1["state"] and r0["state"][1] == 0
 

@@ -329,6 +329,7 @@ def main():
     ap.add_argument("--no-eval-metric", action="store_true",
                     help="skip the accuracy leg (BASELINE's 'median t/q err': a learnable synthetic scene trained and evaluated "
                          "through scripts/train.py -> scripts/eval.py in the timed dtype and in the parity mode, five seeds each, ~6 s per run)")
+    ap.add_argument("--no-feed", action="store_true", help="skip the PCIe-inclusive legs (input fed from pinned host memory every step)")
     ap.add_argument("--emu", action="store_true",
                     help="TEST ONLY: run the same code on the CPU SIMT-emulator build of the kernels over gloo "
                          "(tests/test_bench_launch.py); never a measurement")

@@ -101,6 +101,7 @@ _PROTOS = {
                            c_void, c_f, c_void]),
     "mn_op_maxpool_fwd": (c_i, [c_i, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_void]),
     "mn_op_maxpool_bwd": (c_i, [c_i, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_void]),
+    "mn_op_occupy": (c_i, [c_i, c_i, c_f, c_void, c_void, c_i64, c_void]),
 }
 
 SYMBOLS = tuple(_PROTOS)

@@ -14,6 +14,7 @@
 #include "optim.h"
 #include "pgo.h"
 #include "pool.h"
+#include "rehearsal.h"
 #include "stem.h"
 #include "stem_bwd.h"
 #include "wgrad.h"
@@ -410,4 +411,14 @@ extern "C" int mn_op_maxpool_bwd(int dtype, const unsigned char* idx, const void
     hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid((long)B * H * W * C / 4)), dim3(256), 0,
                        (hipStream_t)stream, idx, (const float*)gout, (float*)gin, B, H, W, C, Po, Qo);
   return check_launch("maxpool_bwd");
+}
+
+extern "C" int mn_op_occupy(int workgroups, int threads, float microseconds, const void* src, void* dst, int64_t bytes, void* stream) {
+  begin_call();
+  if (workgroups < 1 || workgroups > 4096 || threads < 64 || threads > 1024 || threads % 64 != 0)
+    return fail("mn_op_occupy: 1..4096 workgroups of 64..1024 threads (a multiple of 64)");
+  if (!(microseconds >= 0.f) || microseconds > 1e6f) return fail("mn_op_occupy: 0 <= microseconds <= 1e6");
+  if (bytes < 0 || (bytes > 0 && (!src || !dst))) return fail("mn_op_occupy: bytes > 0 needs src and dst");
+  launch_occupy(workgroups, threads, microseconds, src, dst, (long)bytes, (hipStream_t)stream);
+  return check_launch("occupy");
 }

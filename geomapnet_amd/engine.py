@@ -30,6 +30,11 @@ SCALED_DTYPES = ("fp16", "fp16x2", "fp16x2m", "fp16x2q")  # modes whose gradient
 _default_dtype = "fp16"
 _default_loss_scale = 1024.0
 
+# Where a plan's work arena comes from: None = torch.empty (the caching allocator), or a callable (nbytes, device) -> uint8
+# tensor of at least nbytes (tools/arena_probe.py places arenas at chosen offsets of one pooled allocation with it).
+work_allocator = None
+_step_streams = {}  # device index -> the process-wide step stream (Engine.step_stream)
+
 
 def set_compute_dtype(name, loss_scale=None):
     """'fp16' (fp16 tensors, fp32 accumulate; the benchmark configuration), 'fp16x2' (fp16-pair conv operands, fp32
@@ -177,7 +182,8 @@ class Engine:
             nbytes = int(self.lib.plan_bytes(C.byref(cfg)))
             if nbytes < 0:
                 raise MapNetHipError(self.lib.last_error().decode())
-            work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            work = (work_allocator(nbytes, self.device) if work_allocator is not None
+                    else torch.empty(nbytes, dtype=torch.uint8, device=self.device))
             h = self.lib.create(C.byref(cfg), ptr(self.params), ptr(self.opt_state), ptr(self.buffers), ptr(work),
                                 _stream(self.params))
             if not h:
@@ -312,11 +318,20 @@ class Engine:
     #    into it: the library forks weight-gradient work onto a second (non-blocking) stream, which the legacy default
     #    stream's implicit synchronisation would serialise
     def step_stream(self):
+        """ONE step stream per device for the whole process, created before the library's weight-gradient side stream.
+        HIP streams are multiplexed onto a small number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and
+        two streams that land on the same queue execute in order: round 5's "every fourth model of a process is 7-11 % slow" was a
+        new torch stream per Engine walking round that ring until the step stream shared a queue with the library's side stream --
+        the step lost the overlap of its weight-gradient launches, exactly the ~1.3 ms the second stream buys
+        (tools/arena_probe.py, profiles/r06/c1_fourth_model_root_cause.txt: the slow model follows the stream count, not the
+        arena's address, offset or physical backing)."""
         if not self.params.is_cuda:
             return None
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
+        key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        s = _step_streams.get(key)
+        if s is None:
+            s = _step_streams[key] = torch.cuda.Stream(device=self.device)
+        return s
 
     def train_step(self, p, images, targets):
         if "poses" not in p:

@@ -6,7 +6,8 @@ and writes the reference's checkpoint dict (`epoch_NNN.pth.tar`).  Every step is
 i.e. one fused library call on the HIP path.
 
 Not carried over: visdom plotting (a `[logging] visdom = yes` config is accepted and ignored with a
-notice), the LSTM / VidLoc step.  New: under torch.distributed (one process per GPU) the training
+notice), the LSTM / VidLoc step.  New: batches are prefetched to the device one step ahead (feed.py; MN_PREFETCH=0: the
+reference's in-step copy); under torch.distributed (one process per GPU) the training
 windows are sharded with a DistributedSampler and rank 0 alone prints and writes checkpoints.
 """
 import configparser
@@ -19,6 +20,8 @@ import torch.utils.data
 from torch.utils.data.dataloader import default_collate
 
 from . import dp
+from .feed import DeviceFeed
+from .posenet import engine_of
 from .train import load_checkpoint, save_checkpoint, step_feedfwd
 
 
@@ -128,6 +131,12 @@ class Trainer:
             self.model.cuda()
             self.train_criterion.cuda()
             self.val_criterion.cuda()
+        # the reference copies each pinned batch with .cuda(async=True) inside step_feedfwd (common/train.py:341,347), in front of
+        # the step on its own stream; here the copy of batch k+1 is issued on a copy stream while step k runs (feed.py)
+        self.prefetch = self.config["cuda"] and os.environ.get("MN_PREFETCH", "1") != "0"
+
+    def _feed(self, loader):
+        return DeviceFeed(loader, engine_of(self.model).device) if self.prefetch else loader
 
     def save_checkpoint(self, epoch):
         filename = osp.join(self.logdir, "epoch_{:03d}.pth.tar".format(epoch))
@@ -147,7 +156,7 @@ class Trainer:
                 val_batch_time, val_data_time, val_loss = AverageMeter(), AverageMeter(), AverageMeter()
                 self.model.eval()
                 end = time.time()
-                for batch_idx, (data, target) in enumerate(self.val_loader):
+                for batch_idx, (data, target) in enumerate(self._feed(self.val_loader)):
                     val_data_time.update(time.time() - end)
                     vloss, _ = step_feedfwd(data, self.model, cfg["cuda"], target=target, criterion=self.val_criterion,
                                             optim=self.optimizer, train=False)
@@ -176,7 +185,7 @@ class Trainer:
                 self.train_sampler.set_epoch(epoch)
             train_data_time, train_batch_time = AverageMeter(), AverageMeter()
             end = time.time()
-            for batch_idx, (data, target) in enumerate(self.train_loader):
+            for batch_idx, (data, target) in enumerate(self._feed(self.train_loader)):
                 train_data_time.update(time.time() - end)
                 loss, _ = step_feedfwd(data, self.model, cfg["cuda"], target=target, criterion=self.train_criterion,
                                        optim=self.optimizer, train=True, max_grad_norm=cfg["max_grad_norm"])

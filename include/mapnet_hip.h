@@ -350,6 +350,16 @@ int mn_op_maxpool_fwd(int dtype, const void* in, void* out, unsigned char* idx, 
 int mn_op_maxpool_bwd(int dtype, const unsigned char* idx, const void* gout, void* gin, int B, int H, int W, int C,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (no counterpart in the reference, which is single-device: common/train.py:91-92).
+ * Stand-in for the reduction workgroups of an RCCL ring all-reduce on a one-GPU box: `workgroups` x `threads` stay resident
+ * for `microseconds`, streaming `bytes` of dst += src (fp32, 16-byte pieces) at an even pace over that time.  geomapnet_amd/dp.py
+ * launches it where a gradient bucket's all-reduce is issued (MN_DP_STANDIN) so that the CU contention between the collective and
+ * the backward convolutions -- one workgroup per CU, launches sized as one round of the chip -- can be measured without peers
+ * (tools/rccl_rehearsal.py, profiles/r06/rccl_rehearsal.txt).  src / dst may be NULL with bytes = 0 (residency only).
+ * ------------------------------------------------------------------------------------------ */
+int mn_op_occupy(int workgroups, int threads, float microseconds, const void* src, void* dst, int64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

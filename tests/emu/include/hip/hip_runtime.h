@@ -11,6 +11,7 @@
 // The product (geomapnet_amd) never loads the emulator build: geomapnet_amd/_binding.py
 // only ever dlopens libmapnet_hip.so and raises if it is missing.
 #pragma once
+#include <time.h>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -152,11 +153,19 @@ inline float atomicExch(float* p, float v) {
   return r;
 }
 inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
-enum { hipDeviceAttributeMultiprocessorCount = 63 };
-inline hipError_t hipDeviceGetAttribute(int* v, int, int) {
-  *v = 4;  // a small "chip": stream-K launches use 8 workgroups under the emulator
+enum { hipDeviceAttributeMultiprocessorCount = 63, hipDeviceAttributeWallClockRate = 10017 };
+inline hipError_t hipDeviceGetAttribute(int* v, int attr, int) {
+  *v = attr == hipDeviceAttributeWallClockRate ? 100000  // kHz: wall_clock64() below ticks at 100 MHz
+                                               : 4;     // a small "chip": stream-K launches use 8 workgroups under the emulator
   return hipSuccess;
 }
+// constant-rate device clock (100 MHz on the hardware): the host's steady clock in 10 ns ticks
+inline long long wall_clock64() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 100000000ll + ts.tv_nsec / 10;
+}
+inline void __builtin_amdgcn_s_sleep(int) {}
 
 inline double unsafeAtomicAdd(double* p, double v) { return emu_atomic_add(p, v); }
 

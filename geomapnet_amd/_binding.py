@@ -71,7 +71,6 @@ _PROTOS = {
     "mn_op_igemm": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_void, c_i, c_void, c_void,
                           c_f, c_void, c_void]),
     "mn_op_igemm_grid_m": (c_i, [c_i]),
-    "mn_op_igemm_fbn": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_void, c_i, c_void]),
     "mn_op_wgrad": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_i, c_void, c_void, c_i, c_void, c_f, c_i, c_void, c_void]),
     "mn_op_wgrad_ws_floats": (c_i64, []),
     "mn_op_wgrad_ws": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_i, c_void, c_void, c_i, c_f, c_void, c_i64, c_void, c_void]),
@@ -101,7 +100,7 @@ _PROTOS = {
                            c_void, c_f, c_void]),
     "mn_op_maxpool_fwd": (c_i, [c_i, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_void]),
     "mn_op_maxpool_bwd": (c_i, [c_i, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_void]),
-    "mn_op_occupy": (c_i, [c_i, c_i, c_f, c_void, c_void, c_i64, c_void]),
+    "mn_op_occupy": (c_i, [c_i, c_i, c_f, c_void, c_void, c_i64, c_i, c_void]),
 }
 
 SYMBOLS = tuple(_PROTOS)

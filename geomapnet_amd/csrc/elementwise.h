@@ -695,16 +695,17 @@ static __global__ void __launch_bounds__(256) avgpool_fwd_kernel(const T* __rest
 }
 
 // g[b][p][c] = gp[b][c] / HW, zeroed where gate[b][p][c] <= 0 (gate = the pooled activation: the ReLU that produced it)
+// gate_h2 (fp16 tensors): the gate is an h2 tensor (common.h) of which the hi halves are read
 template <typename T>
 static __global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float* __restrict__ gp, T* __restrict__ g, int B, int HW,
-                                                           int C, const T* __restrict__ gate) {
+                                                           int C, const T* __restrict__ gate, int gate_h2) {
   long total = (long)B * HW * C;
   float inv = 1.f / (float)HW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % C);
     int b = (int)(i / ((long)HW * C));
     float v = gp[b * C + c] * inv;
-    if (gate && !((float)gate[i] > 0.f)) v = 0.f;
+    if (gate && !((float)gate[gate_h2 ? h2_index(i / C, C, c) : i] > 0.f)) v = 0.f;
     g[i] = (T)v;
   }
 }

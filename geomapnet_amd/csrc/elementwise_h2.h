@@ -82,11 +82,11 @@ __device__ __forceinline__ void f16_store8(half* __restrict__ base, long row, in
   *reinterpret_cast<piece_t*>(base + row * C + c) = o.p;
 }
 
-// out(h2) = [relu]( y * scale[c] + shift[c] [+ res(h2)] );  bn_apply_kernel with 8 channels per thread; out16: optional plain
-// fp16 copy of the same values (fp16x2m)
+// out(h2) = [relu]( y * scale[c] + shift[c] [+ res(h2)] );  bn_apply_kernel with 8 channels per thread.  (Round 5 wrote a plain fp16
+// copy of the same values beside it for the fp16x2m mode's backward pass; its kernels now read the hi halves in place.)
 static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
                                                                  const half* __restrict__ res, half* __restrict__ out,
-                                                                 long nitems, int C, int relu, half* __restrict__ out16, int q) {
+                                                                 long nitems, int C, int relu, int q) {
   constexpr int VEC = 8;
   const int cpr = C / VEC;
   __shared__ floatx2 tab[512];  // [e][piece] -> (scale, shift)
@@ -126,7 +126,6 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
       h2q_store8(out, row, C, cp * VEC, f);
     else
       h2_store8(out, row, C, cp * VEC, f);
-    if (out16) f16_store8(out16, row, C, cp * VEC, f);
   }
 }
 
@@ -135,7 +134,7 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
 static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
                                                                         half* __restrict__ out, unsigned char* __restrict__ idx,
                                                                         int B, int H, int W, int C, int Po, int Qo,
-                                                                        half* __restrict__ out16, half* __restrict__ y16, int q) {
+                                                                        half* __restrict__ y16, int q) {
   constexpr int VEC = 8;
   const int cpr = C / VEC;
   float s_scale[VEC], s_shift[VEC];
@@ -200,7 +199,6 @@ static __global__ void __launch_bounds__(256) bn_relu_maxpool_h2_kernel(const fl
       h2q_store8(out, orow, C, cp * VEC, best);
     else
       h2_store8(out, orow, C, cp * VEC, best);
-    if (out16) f16_store8(out16, orow, C, cp * VEC, best);
     if (idx) {
       unsigned long long packed = 0;
 #pragma unroll

@@ -97,8 +97,11 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
   const __amdgpu_buffer_rsrc_t rsrc_out = make_rsrc(ep.out, tensor_bytes);
   // a null tensor has zero records: every load returns zeros, no branch
   const __amdgpu_buffer_rsrc_t rsrc_res = make_rsrc(ep.res, ep.res ? tensor_bytes : 0L);
-  const __amdgpu_buffer_rsrc_t rsrc_gate = make_rsrc(ep.res_gate, ep.res_gate ? tensor_bytes : 0L);
-  const __amdgpu_buffer_rsrc_t rsrc_ogate = make_rsrc(ep.out_gate, ep.out_gate ? tensor_bytes : 0L);
+  // (Epilogue::gate_h2: the gate is an h2 tensor of which the hi halves are read -- rows of 4 ldc bytes, 32-channel group j of a
+  //  row at byte 128 j instead of 64 j)
+  const int gmul = ep.gate_h2 ? 2 : 1;
+  const __amdgpu_buffer_rsrc_t rsrc_gate = make_rsrc(ep.res_gate, ep.res_gate ? tensor_bytes * gmul : 0L);
+  const __amdgpu_buffer_rsrc_t rsrc_ogate = make_rsrc(ep.out_gate, ep.out_gate ? tensor_bytes * gmul : 0L);
   const __amdgpu_buffer_rsrc_t rsrc_g1 = ep.res_gate ? rsrc_gate : rsrc_ogate;
   // the statistics form (forward) takes no residual / gates: 64 registers of column sums instead
   const bool has_res = !STATS && ep.res != nullptr, has_gate = !STATS && ep.res_gate != nullptr;
@@ -154,21 +157,22 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
 
   // residual and THE gate (res_gate or out_gate, never both: conv_halo_pp_applies) of a tile, in the store pattern
   Half4View rv[2][2][4], gv[2][2][4];
-  auto pixel_offsets = [&](int tile, unsigned (&voff)[2], bool (&okp)[2]) __attribute__((always_inline)) {
+  auto pixel_offsets = [&](int tile, unsigned (&voff)[2], bool (&okp)[2], int rowmul = 1) __attribute__((always_inline)) {
     int b, y0, x0;
     tile_coords(tile, b, y0, x0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int y = y0 + (2 * wq + i) * RM + l31 / TW, x = x0 + l31 % TW;
       okp[i] = y < gP && x < gQ;
-      voff[i] = okp[i] ? (unsigned)((((b * gP + y) * gQ + x) * ldc) * 2 + kh * 8) : kOob;
+      voff[i] = okp[i] ? (unsigned)((((b * gP + y) * gQ + x) * ldc) * 2 * rowmul + kh * 8) : kOob;
     }
   };
   auto load_side = [&](int tile) __attribute__((always_inline)) {
     if ((ABL & 4) != 0 || !(has_res || has_gate || has_ogate)) return;
-    unsigned voff[2];
+    unsigned voff[2], goff[2];
     bool okp[2];
     pixel_offsets(tile, voff, okp);
+    pixel_offsets(tile, goff, okp, gmul);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -176,7 +180,7 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           rv[i][j][q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_res, (int)voff[i], j * 64 + q * 16, 0);
-          gv[i][j][q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_g1, (int)voff[i], j * 64 + q * 16, 0);
+          gv[i][j][q].p = __builtin_amdgcn_raw_buffer_load_b64(rsrc_g1, (int)goff[i], j * 64 * gmul + q * 16, 0);
         }
   };
 
@@ -345,7 +349,8 @@ static __global__ void __launch_bounds__(512, 1) conv_halo_pp_kernel(GatherGeom 
 inline bool conv_halo_pp_applies(const GatherGeom& g, const Epilogue& ep) {
   return conv_halo_applies(g) && g.N == 64 && ep.ldc == 64 && ep.stats == nullptr && ep.bias == nullptr && !ep.om_on &&
          (ep.stats_accum == nullptr || (ep.stats_rows > 0 && !ep.res && !ep.res_gate && !ep.out_gate)) &&
-         !(ep.res_gate && ep.out_gate) && (long)g.B * g.P * g.Q * ep.ldc * 2L < 0x7ffffff0l;  // (masked lanes use offset 2^31)
+         !(ep.res_gate && ep.out_gate) &&
+         (long)g.B * g.P * g.Q * ep.ldc * (ep.gate_h2 ? 4L : 2L) < 0x7ffffff0l;  // (masked lanes use offset 2^31)
 }
 
 // wgs: persistent workgroups (0 = one per CU, or MN_HALO_PP_WGS)

@@ -57,9 +57,6 @@ struct GatherGeom {
   // matrix-core arithmetic for fp32 tensors (common.h MMA_*; not part of the C ABI of the operator entry points, which
   // set it from their dtype argument): ignored by the fp16 kernels
   int mma = MMA_NATIVE;
-  // EXPERIMENT (round 5, igemm_halo.h FBN; not part of the C ABI): per-channel (scale | shift) [2][C] of a BatchNorm whose
-  // normalise + ReLU is applied to the A operand INSIDE the convolution -- A is then the raw conv output of the layer below
-  const float* a_bn = nullptr;
 };
 
 // n / d for 0 <= n < 2^31 without the ~35-instruction software division (Granlund-Montgomery round-up
@@ -93,6 +90,10 @@ struct Epilogue {
   // of a block's first conv leaves the kernel already multiplied by the ReLU gate of the block BELOW it, so that none
   // of that gradient's three consumers has to read the gating activation again
   const void* out_gate = nullptr;
+  // (round 6, the fp16x2m mode's fp16 backward launches) res_gate / out_gate are h2 tensors (common.h) of which the HI halves are
+  // read: fp16(x) exactly, so the sign test is the one the plain fp16 copy gave; rows of 2 ldc halves, channel c at h2_index.
+  // fp16 kernels (the h2 kernels always read their gates this way).
+  bool gate_h2 = false;
   // output row map (parity classes of a stride-2 data gradient): GEMM row m = (b, p, q) over an om_P x om_Q grid is
   // stored at pixel (2p + om_a, 2q + om_b) of an om_H x om_W image (also applies to res / res_gate / out_gate)
   int om_on = 0, om_P = 0, om_Q = 0, om_H = 0, om_W = 0, om_a = 0, om_b = 0;
@@ -794,10 +795,12 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
               for (int e = 0; e < 4; ++e) o.e[e] = v[e];
               *reinterpret_cast<piece_t*>(out + idx) = o.p;
             } else {
+            // (gate_h2: the gates are h2 tensors, hi halves of channels col .. col + 7 = one 16-byte piece of the row's group)
+            const long gix = (sizeof(T) == 2 && ep.gate_h2) ? h2_index(orow, ep.ldc, col) : idx;
             if (res) {
               PieceView<T> rv, gv;
               rv.p = *reinterpret_cast<const piece_t*>(res + idx);
-              if (gate) gv.p = *reinterpret_cast<const piece_t*>(gate + idx);
+              if (gate) gv.p = *reinterpret_cast<const piece_t*>(gate + gix);
 #pragma unroll
               for (int e = 0; e < VEC; ++e) {
                 float x = (float)rv.e[e];
@@ -808,7 +811,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, MINW) igemm_kernel(GatherG
             PieceView<T> o;
             if (ogate) {
               PieceView<T> ov;
-              ov.p = *reinterpret_cast<const piece_t*>(ogate + idx);
+              ov.p = *reinterpret_cast<const piece_t*>(ogate + gix);
 #pragma unroll
               for (int e = 0; e < VEC; ++e)
                 if (!((float)ov.e[e] > 0.f)) v[e] = 0.f;

@@ -48,12 +48,10 @@ namespace mn {
 // requested when the last K-step of the current chunk has been read (one barrier, its latency exposed once per chunk) -- so that
 // a 192-row tile of 4 waves needs 63 KB of LDS and TWO workgroups share a CU: each one's prologue, image reload and epilogue run
 // under the other's MFMAs.
-// FBN (round 5, an experiment the reviews of rounds 2-4 asked for; fp16 only): the consumer-side BatchNorm fusion.  A is the RAW conv
-// output of the layer below and the BatchNorm apply + ReLU that would have produced this convolution's input runs on every A
-// FRAGMENT after its LDS read: per-channel (scale, shift) as fp16 pairs in a small LDS table (g.a_bn; two broadcast ds_read_b128 per
-// 16-k sub-step), 4 v_pk_fma_f16 + 4 v_pk_max_f16 + 4 selects per fragment -- the select because an out-of-image tap must be zero
-// AFTER the affine map (the zero slot would otherwise read as relu(shift)).  Measured per launch against conv + bn_apply launches:
-// profiles/r05 (consumer-side BatchNorm fusion); not used by the plan.
+// (Round 5 built an FBN variant -- the consumer-side BatchNorm fusion the reviews of rounds 2-4 asked for: the producing layer's
+// normalise + ReLU applied to every A fragment after its LDS read -- and measured it: layer3 76 -> 109 us, layer4 81 -> 146 us per
+// convolution against the 7-11 us an elementwise pass over the same activation takes.  Removed from the library in round 6; the
+// record is profiles/r05/c3_consumer_side_batchnorm_fusion_per_launch.txt and DESIGN.md's history.)
 // OCC: workgroups per CU the shape is built for (LDS budget, register cap).
 // (Measured and removed, round 5: BIG single-image tiles -- A1 with OCC = 1, 576 rows x 128 / 64 columns of 12 waves, 6 x 2 of
 // 96 x 64 / 96 x 32, and 384 rows of 8 waves for layer1.  The idea: the B slices of a tile are the layer's WHOLE weight matrix,
@@ -73,7 +71,7 @@ namespace mn {
 // v_mfma_scale_f32_32x32x64_f8f6f4 contracts both cross terms from the group's fp8 planes ([lo8 | hi8] of A against [hi8 | lo8] of B:
 // a lane's operand is piece 4 + half followed by piece 6 + half; scale bytes are constants of the lane half), then the two fp16
 // MFMAs of hi*hi: 128 instead of 192 matrix-pipe cycles per K-step and tile pair, the same LDS-DMA bytes and fragment reads.
-template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4, bool A1 = false, bool FBN = false,
+template <int BN, int kAH, int ABL = 0, int DP = 1, bool H2 = false, int WM = 3, int WN = 4, bool A1 = false,
           int OCC = (A1 ? 2 : 1), bool Q = false>
 static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_halo_kernel(GatherGeom g, const half* __restrict__ A,
                                                                    const half* __restrict__ Bw, Epilogue ep, int grid_n,
@@ -83,14 +81,12 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
   static_assert(TN == 1 || TN == 2, "wave tiles of 96 x 32 or 96 x 64");
   constexpr int NBS = 2, NIMG = A1 ? 1 : 2, A_IMG = kAH * NP, B_SLOT = BN * NP, RING = NIMG * A_IMG + NBS * B_SLOT;  // pieces
   constexpr int SC = BN < 128 ? BN : 128;  // columns staged per epilogue round
-  constexpr int FTAB = FBN ? (BN == 256 ? 64 : 128) : 0;  // (scale piece, shift piece) per 8 channels: C <= 256 / 512
-  static_assert(!FBN || !H2, "fp16 only");
   static_assert(!Q || H2, "Q: an h2 variant");
-  static_assert((RING + 1 + WM * BN / 2 + FTAB) * 16 <= (OCC == 2 ? 80 : 160) * 1024, "LDS");
+  static_assert((RING + 1 + WM * BN / 2) * 16 <= (OCC == 2 ? 80 : 160) * 1024, "LDS");
   static_assert(RING * 16 >= WM * 32 * SC * 4, "epilogue staging (the ring is free by then)");
   constexpr int A_PASSES = (kAH + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;   // 4, 3
   static_assert(A1 || A_PASSES <= 9, "one image pass per K-step of the chunk before");
-  __shared__ piece_t smem[RING + 1 + WM * BN / 2 + FTAB];
+  __shared__ piece_t smem[RING + 1 + WM * BN / 2];
   float* red = reinterpret_cast<float*>(&smem[RING + 1]);  // [WM][BN][2]
 
   const int t = threadIdx.x, lane = t & 63;
@@ -102,18 +98,6 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
   const int W = g.Wi, halo = W + 1;
   const int NCH = g.C / 64, KT = (ABL & 2) ? 1 : 9 * NCH;
   if (t == 0) smem[RING] = zero_piece();
-  if constexpr (FBN) {  // table[2 p] = scale of channels 8p .. 8p+7, table[2 p + 1] = their shift (fp16)
-    if (t < g.C / 8) {
-      PieceView<half> sc, sh;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        sc.e[e] = (half)g.a_bn[t * 8 + e];
-        sh.e[e] = (half)g.a_bn[g.C + t * 8 + e];
-      }
-      smem[RING + 1 + WM * BN / 2 + 2 * t] = sc.p;
-      smem[RING + 1 + WM * BN / 2 + 2 * t + 1] = sh.p;
-    }
-  }
   // lgkmcnt(0): the store has reached LDS before this wave arrives at the K loop's first barrier (a raw s_barrier does
   // not wait for outstanding LDS writes), after which every wave may read the slot
   __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -331,18 +315,6 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
     for (int ks = 0; ks < NP / 2; ++ks) {
       if (ks + 1 < NP / 2 && ((ABL & 8) == 0 || kt == 0)) load_frags(ks + 1, (ks + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (FBN) {  // BatchNorm apply + ReLU of the layer below, on this sub-step's A fragments
-        PieceView<half> sc, sh;
-        const int tp = (chunk * 8 + ks * 2 + hi) * 2;
-        sc.p = smem[RING + 1 + WM * BN / 2 + tp];
-        sh.p = smem[RING + 1 + WM * BN / 2 + tp + 1];
-        const half8 zero8 = {(half)0, (half)0, (half)0, (half)0, (half)0, (half)0, (half)0, (half)0};
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          half8 v = __builtin_elementwise_max(__builtin_elementwise_fma(fa[ks & 1][i].v, sc.v, sh.v), zero8);
-          fa[ks & 1][i].v = ainv[i] ? zero8 : v;
-        }
-      }
       if constexpr ((ABL & 16) == 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -465,10 +437,11 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
             for (int e = 0; e < 4; ++e) o.e[e] = v[e];
             *reinterpret_cast<piece_t*>(out + idx) = o.p;
           } else {
+          const long gix = ep.gate_h2 ? h2_index(row, ep.ldc, col) : idx;  // (gate_h2: hi halves of an h2 gate tensor, igemm.h)
           if (res) {
             PieceView<half> rv, gv;
             rv.p = *reinterpret_cast<const piece_t*>(res + idx);
-            if (gate) gv.p = *reinterpret_cast<const piece_t*>(gate + idx);
+            if (gate) gv.p = *reinterpret_cast<const piece_t*>(gate + gix);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
               float x = (float)rv.e[e];
@@ -478,7 +451,7 @@ static __global__ void __launch_bounds__(WM* WN * 64, OCC * WM* WN / 4) igemm_ha
           }
           if (ogate) {
             PieceView<half> ov;
-            ov.p = *reinterpret_cast<const piece_t*>(ogate + idx);
+            ov.p = *reinterpret_cast<const piece_t*>(ogate + gix);
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
               if (!((float)ov.e[e] > 0.f)) v[e] = 0.f;
@@ -548,19 +521,6 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
   static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
 #endif
   static const int a1 = getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1;
-  if (g.a_bn) {  // FBN experiment: the two 12-wave shapes only (256 columns with C <= 256, else 128 columns with C <= 512)
-    if (g.N % 256 == 0 && g.C <= 256 && igemm_halo_applies(g, ep, 256, 352)) {
-      hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, false, 3, 4, false, true>), dim3(gm * (g.N / 256)), dim3(768), 0, stream, g, A,
-                         Bw, ep, g.N / 256, rd);
-      return gm;
-    }
-    if (g.C <= 512 && igemm_halo_applies(g, ep, 128, 384)) {
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, false, 3, 4, false, true>), dim3(gm * (g.N / 128)), dim3(768), 0, stream, g, A,
-                         Bw, ep, g.N / 128, rd);
-      return gm;
-    }
-    return -1;
-  }
   if (level >= 1 && tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) {
 #ifdef MN_ABLATION_BUILD
 #define MN_HALO_ABL(BN_, AH_, V_)                                                                                          \
@@ -638,7 +598,7 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   static const int a1 = getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1;  // (see launch_igemm_halo)
   if (g2.N % 256 == 0 && ((tiles288 > 192 && tiles288 <= device_cus()) || force256) && igemm_halo_applies(g2, ep, 256, 352)) {
     if (q)
-      hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true, 3, 4, false, false, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
+      hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true, 3, 4, false, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 256, rd);
     else
       hipLaunchKernelGGL((igemm_halo_kernel<256, 352, 0, 1, true>), dim3(gm * (g2.N / 256)), dim3(768), 0, stream, g2, A, Bw, ep,
@@ -651,7 +611,7 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   //  per CU -- 27 % less DMA per row -- 409 us: six waves do not spread over four SIMDs; profiles/r04/c15_*, c16_*)
   if (halo64 && g2.N == 64 && igemm_halo_applies(g2, ep, 64, 368, 192)) {
     if (q)
-      hipLaunchKernelGGL((igemm_halo_kernel<64, 368, 0, 1, true, 2, 2, true, false, 2, true>), dim3(cdiv(g2.M, 192)), dim3(256), 0, stream, g2, A, Bw, ep, 1,
+      hipLaunchKernelGGL((igemm_halo_kernel<64, 368, 0, 1, true, 2, 2, true, 2, true>), dim3(cdiv(g2.M, 192)), dim3(256), 0, stream, g2, A, Bw, ep, 1,
                        rd);
     else
       hipLaunchKernelGGL((igemm_halo_kernel<64, 368, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192)), dim3(256), 0, stream, g2, A, Bw, ep, 1,
@@ -662,7 +622,7 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   if (a1 > 0 && g2.N % 128 == 0 && (a1 == 2 || (long)cdiv(g2.M, 192) * (g2.N / 128) >= 2L * device_cus()) &&
       igemm_halo_applies(g2, ep, 128, 288, 192)) {
     if (q)
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, true, 2, 2, true, false, 2, true>), dim3(cdiv(g2.M, 192) * (g2.N / 128)), dim3(256), 0, stream,
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, true, 2, 2, true, 2, true>), dim3(cdiv(g2.M, 192) * (g2.N / 128)), dim3(256), 0, stream,
                        g2, A, Bw, ep, g2.N / 128, rd);
     else
       hipLaunchKernelGGL((igemm_halo_kernel<128, 288, 0, 1, true, 2, 2, true>), dim3(cdiv(g2.M, 192) * (g2.N / 128)), dim3(256), 0, stream,
@@ -678,7 +638,7 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
     const double e384 = (double)t384 / ((double)cdiv(t384, cus) * cus), e288 = (double)t288 / ((double)cdiv(t288, cus) * cus);
     if (bm384 == 2 || e384 >= e288 - 0.03) {
     if (q)
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 480, 0, 1, true, 4, 2, false, false, 1, true>), dim3(cdiv(g2.M, 384) * (g2.N / 128)), dim3(512), 0, stream, g2,
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 480, 0, 1, true, 4, 2, false, 1, true>), dim3(cdiv(g2.M, 384) * (g2.N / 128)), dim3(512), 0, stream, g2,
                          A, Bw, ep, g2.N / 128, rd);
     else
       hipLaunchKernelGGL((igemm_halo_kernel<128, 480, 0, 1, true, 4, 2>), dim3(cdiv(g2.M, 384) * (g2.N / 128)), dim3(512), 0, stream, g2,
@@ -688,7 +648,7 @@ inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half*
   }
   if (igemm_halo_applies(g2, ep, 128, 384)) {
     if (q)
-      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true, 3, 4, false, false, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,
+      hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true, 3, 4, false, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,
                        g2.N / 128, rd);
     else
       hipLaunchKernelGGL((igemm_halo_kernel<128, 384, 0, 1, true>), dim3(gm * (g2.N / 128)), dim3(768), 0, stream, g2, A, Bw, ep,

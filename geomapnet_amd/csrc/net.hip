@@ -323,9 +323,9 @@ struct Plan : PlanBase {
     T* zd;        // bn_d(conv_d x) when down
     T* out;       // block output
     T* gout;      // gradient w.r.t. block output (written by the consumer)
-    // fp16x2m: plain fp16 copies of the h2 activations for the single-fp16 backward pass (x16 = copy of the block input)
-    const half* x16 = nullptr;
-    half *a1_16 = nullptr, *out16 = nullptr;
+    // (fp16x2m, round 5: plain fp16 COPIES of the h2 activations fed the single-fp16 backward pass; round 6: its kernels read the hi
+    //  halves of the h2 tensors themselves -- WgradArgs::x_h2, Epilogue::gate_h2 -- and the copies are gone: 2 bytes per activation
+    //  element less written by every BatchNorm apply, 2.5 GB less arena at 192 images)
   };
 
   float *params, *grads, *m1, *m2;
@@ -336,7 +336,6 @@ struct Plan : PlanBase {
   T* xpad;
   Unit stem;
   T *a0, *ga0, *p0, *gp0;
-  half* p0_16 = nullptr;  // fp16x2m: plain fp16 copy of the pooled stem activation
   half* xpad16 = nullptr;   // fp16x2m: fp16 copy of the padded NHWC4 input (the stem's fp16 backward kernels, stem_bwd.h)
   int H0, W0, H1, W1;  // stem conv output, pooled output
   std::vector<Block> blocks;
@@ -429,17 +428,12 @@ struct Plan : PlanBase {
     p0 = (T*)A(n1 * sizeof(T));
     gp0 = (T*)A(n1 * sizeof(T));
     pool_idx = (unsigned char*)A(n1);
-    if (mixed) {
-      p0_16 = (half*)A(n1 * sizeof(half));
-      xpad16 = (half*)A((size_t)B * Hp * Wp * 4 * sizeof(half));
-    }
+    if (mixed) xpad16 = (half*)A((size_t)B * Hp * Wp * 4 * sizeof(half));
     const T* x = p0;
     T* gx = gp0;
-    const half* x16 = p0_16;
     for (auto& blk : blocks) {
       blk.x = x;
       blk.gx = gx;
-      blk.x16 = x16;
       Unit* us[3] = {&blk.u1, &blk.u2, blk.down ? &blk.ud : nullptr};
       for (Unit* u : us) {
         if (!u) continue;
@@ -457,13 +451,8 @@ struct Plan : PlanBase {
       blk.zd = blk.down ? (T*)A(no * sizeof(T)) : nullptr;
       blk.out = (T*)A(no * sizeof(T));
       blk.gout = (T*)A(no * sizeof(T));
-      if (mixed) {
-        blk.a1_16 = (half*)A(no * sizeof(half));
-        blk.out16 = (half*)A(no * sizeof(half));
-      }
       x = blk.out;
       gx = blk.gout;
-      x16 = blk.out16;
     }
     int F = cfg.feat_dim;
     pooled = (float*)A((size_t)B * 512 * 4);
@@ -765,14 +754,13 @@ struct Plan : PlanBase {
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(u.cp.cout, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)u.accum_f, (double)u.M,
                        bn_params(u), cur_training, u.coef_f, u.cp.cout, u.rows_f);
   }
-  // out16 (fp16x2m, training passes): plain fp16 copy of the activation for the backward pass
-  void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s, half* out16 = nullptr) {
+  void bn_act(Unit& u, const T* res, int relu, T* out, hipStream_t s) {
     long np = u.M * u.cp.cout / VEC;
     bn_finalize(u, s);
     if (h2) {  // fp32 conv output in, h2 activation out (residual: an h2 activation)
       const long ni = u.M * u.cp.cout / 8;
       hipLaunchKernelGGL(bn_apply_h2_kernel, dim3(ew_grid(ni)), dim3(256), 0, s, (const float*)u.y, (const float*)u.coef_f,
-                         (const half*)res, (half*)out, ni, u.cp.cout, relu, cur_training ? out16 : (half*)nullptr, q8 ? 1 : 0);
+                         (const half*)res, (half*)out, ni, u.cp.cout, relu, q8 ? 1 : 0);
       return;
     }
     hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const float*)u.coef_f, res, out,
@@ -819,7 +807,7 @@ struct Plan : PlanBase {
       bn_finalize(stem, s);
       hipLaunchKernelGGL(bn_relu_maxpool_h2_kernel, dim3(ew_grid((long)B * H1 * W1 * 64 / 8)), dim3(256), 0, s,
                          (const float*)stem.y, (const float*)stem.coef_f, (half*)p0, pool_idx, B, H0, W0, 64, H1, W1,
-                         training ? p0_16 : (half*)nullptr, training && stem_bwd_f16() ? (half*)a0 : (half*)nullptr, q8 ? 1 : 0);
+                         training && stem_bwd_f16() ? (half*)a0 : (half*)nullptr, q8 ? 1 : 0);
     } else if (fuse_stem) {  // BatchNorm + ReLU + max-pool in one pass; the normalised stem activation is never stored
       bn_finalize(stem, s);
       hipLaunchKernelGGL((bn_relu_maxpool_kernel<T>), dim3(ew_grid((long)B * H1 * W1 * 64 / VEC)), dim3(256), 0, s,
@@ -832,7 +820,7 @@ struct Plan : PlanBase {
     for (auto& blk : blocks) {
       if (blk.stage >= 1) join_wgrad(s);  // no-op once joined
       conv_bn_stats(blk.u1, blk.x, training, s);
-      bn_act(blk.u1, nullptr, 1, blk.a1, s, blk.a1_16);
+      bn_act(blk.u1, nullptr, 1, blk.a1, s);
       conv_bn_stats(blk.u2, blk.a1, training, s);
       const T* res = blk.x;
       if (blk.down) {
@@ -840,7 +828,7 @@ struct Plan : PlanBase {
         bn_act(blk.ud, nullptr, 0, blk.zd, s);
         res = blk.zd;
       }
-      bn_act(blk.u2, res, 1, blk.out, s, blk.out16);
+      bn_act(blk.u2, res, 1, blk.out, s);
     }
     join_wgrad(s);
     const Block& last = blocks.back();
@@ -943,8 +931,9 @@ struct Plan : PlanBase {
     // reduction splits (measured, tools/conv_bench.py): one round of 2 workgroups per CU for the wide layers (half
     // the atomic traffic of 1024), more for layer1 and the stem whose pixel dimension is 4-16x longer
     const int target = u.cp.cout >= 128 ? 512 : (u.M > 2000000 ? 2048 : 1024);
-    if (mixed && &u != &stem) {  // plain fp16 d(conv output) and activation copy: the fp16 mode's kernels
+    if (mixed && &u != &stem) {  // plain fp16 d(conv output) against the HI halves of the h2 activation: the fp16 mode's kernels
       a.g.mma = MMA_NATIVE;
+      a.x_h2 = true;
       launch_wgrad<half>(a, target, ws, zero_page);
     } else if (h2 && &u != &stem) {  // h2 d(conv output) and activation
       a.g.mma = MMA_H2;
@@ -959,7 +948,8 @@ struct Plan : PlanBase {
     ep.out_gate = out_gate;
     ep.alpha = 1.f;
     auto* tp = timer.begin(0, s);
-    if (mixed) {  // the fp16 mode's launches: fp16 d(conv output), weights, gradient, residual and gate (the activation COPY)
+    if (mixed) {  // the fp16 mode's launches: fp16 d(conv output), weights, gradient and residual; the gate = hi halves of the h2 activation
+      ep.gate_h2 = true;
       if (use_halo_bwd && conv_halo_applies(u.dg.full) && conv_halo_pp_applies(u.dg.full, ep))
         launch_conv_halo_pp(u.dg.full, (const half*)u.gy, (const half*)u.wd, ep, s);
       else
@@ -1000,9 +990,10 @@ struct Plan : PlanBase {
   // path of this block use `gout` as it is and never read `out`.
   void block_backward(Block& blk, hipStream_t s) {
     // the gate of the block below = ReLU that produced this block's input (none below layer1.0: its input is the max-pool)
-    // (fp16x2m: gates and the weight gradients' X operands are the plain fp16 copies; typed T* for the shared call sites)
-    const T* bx = mixed ? (const T*)blk.x16 : blk.x;
-    const T* ba1 = mixed ? (const T*)blk.a1_16 : blk.a1;
+    // (fp16x2m: gates and the weight gradients' X operands are the HI halves of the h2 activations, read in place by the fp16
+    //  kernels: conv_wgrad sets WgradArgs::x_h2, conv_dgrad Epilogue::gate_h2)
+    const T* bx = blk.x;
+    const T* ba1 = blk.a1;
     // (fp16x2m with the fp16 stem kernels: the gradient of the pooled stem activation leaves layer1.0 gated by that activation)
     const T* below = &blk == &blocks.front() ? (stem_bwd_f16() ? bx : nullptr) : bx;
     const T* og = nullptr;  // (bn2 / the projection / the identity path take `gout` as stored: already gated)
@@ -1075,15 +1066,15 @@ struct Plan : PlanBase {
     else
       launch_igemm<float>(gd, (const float*)dz, (const float*)fcT, ep, s, (const float*)zero_page);
     Block& last = blocks.back();
-    if (mixed)  // fp16 gradient out, gate = the plain fp16 copy of the last block's output
+    if (mixed)  // fp16 gradient out, gate = the hi halves of the last block's h2 output
       hipLaunchKernelGGL((avgpool_bwd_kernel<half>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
-                         (const float*)dpooled, (half*)last.gout, B, Hl * Wl, 512, (const half*)last.out16);
+                         (const float*)dpooled, (half*)last.gout, B, Hl * Wl, 512, (const half*)last.out, 1);
     else if (h2)
       hipLaunchKernelGGL(avgpool_bwd_h2_kernel, dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s, (const float*)dpooled,
                          (float*)last.gout, B, Hl * Wl, 512, (const half*)last.out);
     else
       hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((long)B * Hl * Wl * 512)), dim3(256), 0, s,
-                         (const float*)dpooled, last.gout, B, Hl * Wl, 512, (const T*)last.out);
+                         (const float*)dpooled, last.gout, B, Hl * Wl, 512, (const T*)last.out, 0);
   }
   // (MN_DETERMINISTIC: the stem's backward goes through bn_bwd + the split-slice weight gradient instead)
   bool use_stem_bwd = DT == MN_F16 && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
@@ -1175,7 +1166,6 @@ struct Plan : PlanBase {
     const int GT = mixed ? MN_F16 : AT, GD = mixed ? MN_F16 : DT;
     if (n == "p0") return give(p0, n1, AT);
     if (n == "gp0") return give(gp0, n1, GD);
-    if (mixed && n == "p0.f16") return give(p0_16, n1, MN_F16);
     if (n == "pooled") return give(pooled, (long)B * 512, MN_F32);
     if (n == "feat") return give(feat, (long)B * cfg.feat_dim, MN_F32);
     if (n == "poses") return give(poses, (long)B * 6, MN_F32);
@@ -1199,8 +1189,6 @@ struct Plan : PlanBase {
           if (t == "ga1") return give(k.ga1, no, GD);
           if (t == "gy2") return give(k.u2.gy, no, GT);
           if (t == "gout") return give(k.gout, no, GD);
-          if (mixed && t == "a1.f16") return give(k.a1_16, no, MN_F16);
-          if (mixed && t == "out.f16") return give(k.out16, no, MN_F16);
           if (k.down && t == "yd") return give(k.ud.y, no, DT);
           if (k.down && t == "zd") return give(k.zd, no, AT);
           if (k.down && t == "gyd") return give(k.ud.gy, no, GT);

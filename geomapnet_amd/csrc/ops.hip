@@ -85,24 +85,6 @@ extern "C" int mn_op_igemm(int dtype, const mn_gather_geom* gg, const void* A, c
   return check_launch("igemm");
 }
 
-// EXPERIMENT (round 5): out = conv3x3(relu(A * scale + shift), Bw), fp16, with the BatchNorm apply + ReLU fused into the
-// convolution's A-fragment path (igemm_halo.h FBN); coef = [2][C] floats (scale | shift)
-extern "C" int mn_op_igemm_fbn(const mn_gather_geom* gg, const void* A, const float* coef, const void* Bw, void* out, int ldc,
-                               void* stream) {
-  begin_call();
-  GatherGeom g = to_geom(gg);
-  if (int e = check_geom(g, MN_F16)) return e;
-  if (!coef) return fail("igemm_fbn: coef is required");
-  g.tap_inner = 1;
-  g.a_bn = coef;
-  Epilogue ep;
-  ep.out = out; ep.ldc = ldc; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = nullptr; ep.res_gate = nullptr;
-  ep.alpha = 1.f;
-  if (launch_igemm_halo(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream, 2, true) < 0)
-    return fail("igemm_fbn: 3x3 stride-1 same-size fp16 convolutions with C % 64 == 0, C <= 512, N % 128 == 0 only");
-  return check_launch("igemm_fbn");
-}
-
 extern "C" int mn_op_conv_halo_pp(const mn_gather_geom* gg, const void* A, const void* Bw, void* out, int ldc, double* stats_accum,
                                  int stats_rows, int relu, const void* res, const void* res_gate, const void* out_gate,
                                  float alpha, int wgs, void* stream) {
@@ -413,12 +395,14 @@ extern "C" int mn_op_maxpool_bwd(int dtype, const unsigned char* idx, const void
   return check_launch("maxpool_bwd");
 }
 
-extern "C" int mn_op_occupy(int workgroups, int threads, float microseconds, const void* src, void* dst, int64_t bytes, void* stream) {
+extern "C" int mn_op_occupy(int workgroups, int threads, float microseconds, const void* src, void* dst, int64_t bytes, int lds_kb,
+                            void* stream) {
   begin_call();
   if (workgroups < 1 || workgroups > 4096 || threads < 64 || threads > 1024 || threads % 64 != 0)
     return fail("mn_op_occupy: 1..4096 workgroups of 64..1024 threads (a multiple of 64)");
   if (!(microseconds >= 0.f) || microseconds > 1e6f) return fail("mn_op_occupy: 0 <= microseconds <= 1e6");
   if (bytes < 0 || (bytes > 0 && (!src || !dst))) return fail("mn_op_occupy: bytes > 0 needs src and dst");
-  launch_occupy(workgroups, threads, microseconds, src, dst, (long)bytes, (hipStream_t)stream);
+  if (lds_kb != 0 && lds_kb != 32 && lds_kb != 64) return fail("mn_op_occupy: lds_kb must be 0, 32 or 64");
+  launch_occupy(workgroups, threads, microseconds, src, dst, (long)bytes, lds_kb, (hipStream_t)stream);
   return check_launch("occupy");
 }

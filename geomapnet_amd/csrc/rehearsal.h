@@ -11,7 +11,13 @@
 
 namespace mn {
 
-__global__ void occupy_kernel(const floatx4* __restrict__ src, floatx4* __restrict__ dst, long n16, long long ticks, int chunks) {
+// LDS_KB: LDS the workgroup holds while resident (an RCCL workgroup keeps its ncclShmem staging there; a convolution workgroup of
+// this library needs 150 of the CU's 160 KB, so a CU that hosts a collective workgroup with tens of KB cannot host one)
+template <int LDS_KB>
+__global__ void __launch_bounds__(1024) occupy_kernel(const floatx4* __restrict__ src, floatx4* __restrict__ dst, long n16,
+                                                      long long ticks, int chunks) {
+  __shared__ float pad[LDS_KB > 0 ? LDS_KB * 256 : 1];
+  pad[threadIdx.x % (LDS_KB > 0 ? LDS_KB * 256 : 1)] = (float)threadIdx.x;  // (the allocation must be live)
   const long long t0 = wall_clock64();
   const long per_wg = (n16 + gridDim.x - 1) / gridDim.x;
   const long lo = (long)blockIdx.x * per_wg;
@@ -27,6 +33,7 @@ __global__ void occupy_kernel(const floatx4* __restrict__ src, floatx4* __restri
     const long long until = t0 + ticks * (c + 1) / chunks;
     while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
   }
+  if (n16 < 0) dst[0][0] = pad[0];  // (never true: keeps `pad` observable)
 }
 
 // ticks of wall_clock64 per microsecond (constant-rate counter: hipDeviceAttributeWallClockRate is in kHz)
@@ -40,10 +47,16 @@ inline double wall_ticks_per_us() {
   return khz / 1e3;
 }
 
-inline void launch_occupy(int workgroups, int threads, float microseconds, const void* src, void* dst, long bytes, hipStream_t s) {
+inline void launch_occupy(int workgroups, int threads, float microseconds, const void* src, void* dst, long bytes, int lds_kb,
+                          hipStream_t s) {
   const long n16 = src && dst ? bytes / 16 : 0;
   const long long ticks = (long long)(microseconds * wall_ticks_per_us());
-  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(threads), 0, s, (const floatx4*)src, (floatx4*)dst, n16, ticks, 16);
+  if (lds_kb >= 64)
+    hipLaunchKernelGGL(occupy_kernel<64>, dim3(workgroups), dim3(threads), 0, s, (const floatx4*)src, (floatx4*)dst, n16, ticks, 16);
+  else if (lds_kb >= 32)
+    hipLaunchKernelGGL(occupy_kernel<32>, dim3(workgroups), dim3(threads), 0, s, (const floatx4*)src, (floatx4*)dst, n16, ticks, 16);
+  else
+    hipLaunchKernelGGL(occupy_kernel<0>, dim3(workgroups), dim3(threads), 0, s, (const floatx4*)src, (floatx4*)dst, n16, ticks, 16);
 }
 
 }  // namespace mn

@@ -37,7 +37,15 @@ struct WgradArgs {
   // the gradient in split order; the fused kernel reduces its partial tiles with one group.
   bool det = false;
   long split_stride = 0;
+  // (round 6, the fp16x2m mode) X is an h2 tensor (common.h: per row and 32-channel group 64 bytes of fp16 hi halves, then 64
+  // bytes of lo halves) of which only the HI halves are read -- fp16(x) exactly, what the plain fp16 copy beside the h2 tensor
+  // used to hold: rows are 4 C bytes apart and channel c lies at half (c >> 5) * 64 + (c & 31) of its row.  fp16 kernels only.
+  bool x_h2 = false;
 };
+// half index of channel c0 (a multiple of 8: one 16-byte piece never straddles a 32-channel group) inside a row of X, and the row
+// pitch in halves, for plain fp16 rows / the hi halves of h2 rows
+__host__ __device__ inline int x_col_halves(bool x_h2, int c0) { return x_h2 ? ((c0 >> 5) * 64 + (c0 & 31)) : c0; }
+__host__ __device__ inline int x_row_halves(bool x_h2, int C) { return x_h2 ? 2 * C : C; }
 
 template <typename T, int BMO, int BNO>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
@@ -75,6 +83,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   const int tap = x_col_ok ? kcol / g.C : 0;
   const int c0 = x_col_ok ? kcol % g.C : 0;
   const int dh = g.rsign * (tap / g.S), dw = g.ssign * (tap % g.S);
+  // (x_h2: hi halves of an h2 tensor, fp16 instantiations only)
+  const bool xh2 = sizeof(T) == 2 && a.x_h2;
+  const int xc0 = x_col_halves(xh2, c0), xrow_h = x_row_halves(xh2, g.C);
   int xb[XPT], xp[XPT], xq[XPT];
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
@@ -104,7 +115,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
         wn >>= 1;
       }
       ok = ok && (unsigned)hn < (unsigned)g.Hi && (unsigned)wn < (unsigned)g.Wi;
-      rx[i] = ok ? *reinterpret_cast<const piece_t*>(X + ((long)((xb[i] * g.Hi + hn) * g.Wi + wn) * g.C + c0))
+      rx[i] = ok ? *reinterpret_cast<const piece_t*>(X + ((long)((xb[i] * g.Hi + hn) * g.Wi + wn) * xrow_h + xc0))
                  : zero_piece();
       // advance (b, p, q) by BKM rows
       xq[i] += BKM;
@@ -286,6 +297,7 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
   const int tap = x_ok ? kcol / g.C : 0;
   const int c0 = x_ok ? kcol % g.C : 0;
   const int dh = g.rsign * (tap / g.S), dw = g.ssign * (tap % g.S);
+  const int xc0 = x_col_halves(a.x_h2, c0), xrow_h = x_row_halves(a.x_h2, g.C);  // (x_h2: hi halves of an h2 tensor)
   int xb[XPT], xp[XPT], xq[XPT];
   // FAST state
   const int PQ = g.P * g.Q;
@@ -295,7 +307,7 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
   __amdgpu_buffer_rsrc_t rsrc_y, rsrc_x;
   if constexpr (FAST) {
     rsrc_y = make_rsrc(dY, (long)g.M * a.ldy * 2);
-    rsrc_x = make_rsrc(X, (long)g.B * g.Hi * g.Wi * g.C * 2);
+    rsrc_x = make_rsrc(X, (long)g.B * g.Hi * g.Wi * xrow_h * 2);
     // validity table: bit `tap` of tbl[pix] is set when that tap of pixel pix = p*Q + q is outside the image
     for (int pix = t; pix < PQ; pix += 256) {
       const int p = pix / g.Q, q = pix - p * g.Q;
@@ -315,7 +327,7 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int m = m_begin + xrow + i * XRS;
-      x_fix[i] = (unsigned)(((m + shift) * g.C + c0) * 2);
+      x_fix[i] = (unsigned)(((m + shift) * xrow_h + xc0) * 2);
       x_pix[i] = m % PQ;
     }
   } else {
@@ -345,7 +357,7 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
         x_pix[i] -= x_pix[i] >= PQ ? PQ : 0;
       }
       step_y += (unsigned)(BKM * a.ldy * 2);
-      step_x += (unsigned)(BKM * g.C * 2);
+      step_x += (unsigned)(BKM * xrow_h * 2);
       return;
     }
 #pragma unroll
@@ -365,7 +377,7 @@ static __global__ void __launch_bounds__(256, MINW) wgrad_dma_kernel(WgradArgs a
         wn_ >>= 1;
       }
       ok = ok && (unsigned)hn < (unsigned)g.Hi && (unsigned)wn_ < (unsigned)g.Wi;
-      const half* src = ok ? X + ((long)((xb[i] * g.Hi + hn) * g.Wi + wn_) * g.C + c0) : zero_page;
+      const half* src = ok ? X + ((long)((xb[i] * g.Hi + hn) * g.Wi + wn_) * xrow_h + xc0) : zero_page;
       dma16(src, tx + (i * XRS * XCP + wave * 64) * VEC);
       xq[i] += BKM;
       while (xq[i] >= g.Q) {
@@ -726,7 +738,7 @@ struct WgradDma<half> {
     const GatherGeom& g = a.g;
     const bool fast = g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.P == g.Hi && g.Q == g.Wi && g.R * g.S <= 16 &&
                       g.P * g.Q <= WG_TBL && g.P * g.Q >= BKM && g.C % 8 == 0 && (long)g.M * a.ldy * 2 < 0xfffffff0l &&
-                      (long)g.M * g.C * 2 < 0xfffffff0l;
+                      (long)g.M * x_row_halves(a.x_h2, g.C) * 2 < 0xfffffff0l;
     // fast form: transpose reads from inline assembly with hand-placed waits (ASMRD above); measured on MI355X (round 2):
     // layer1 189 -> 155 us, layer2 140 -> 122, layer3 144 -> 124, layer4 129 -> 117 against the builtin reads
     if (fast) {

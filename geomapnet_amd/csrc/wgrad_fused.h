@@ -49,6 +49,7 @@ struct WgradFusedArgs {
   FastDiv dq, dp;  // divisors Q+1 and P+1
   float alpha;
   bool det = false;  // MN_DETERMINISTIC: one reduction group (plain ordered sums, no atomics anywhere)
+  bool x_h2 = false; // (round 6) X is an h2 tensor of which the hi halves are read (WgradArgs::x_h2); wgrad_fused_h2_kernel<.., LO = false>
 };
 
 // LDS rows of the X ring: (D+1) steps + 2 Gpad; bounds the image width (Gpad <= 96 -> Q <= 94, i.e. inputs up to 376
@@ -601,14 +602,17 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFuse
 
   // the h2 tensors as the DMA sees them: rows of 4 ldy / 4 C bytes
   const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dY, (long)a.B * a.P * a.Q * a.ldy * (long)EB);
-  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X, (long)a.B * a.P * a.Q * a.C * (long)EB);
+  // (LO = false with WgradFusedArgs::x_h2: plain fp16 dY against the HI halves of an h2 X -- rows of 4 C bytes, the h2 column map)
+  const bool xh2 = LO || a.x_h2;
+  const int EBX = xh2 ? 4 : 2;
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X, (long)a.B * a.P * a.Q * a.C * (long)EBX);
   // DMA role (the fp16 kernel's): row t/8 of a 64-row block, LDS slot t%8 = source piece slot ^ swz(row) = channels
   // 8 piece .. 8 piece + 7 of the 64-channel tile; the lo halves of the same channels lie 64 bytes behind the hi halves
   const int drow = t >> 3, dslot = t & 7;
   const int dpiece = dslot ^ wg_swz<8>(drow);
   const int ych = n0 + dpiece * 8, xch = c0 + dpiece * 8;
   const unsigned ycol = LO ? (unsigned)(((ych >> 5) * 64 + (ych & 31)) * 2) : (unsigned)(ych * 2);
-  const unsigned xcol = LO ? (unsigned)(((xch >> 5) * 64 + (xch & 31)) * 2) : (unsigned)(xch * 2);
+  const unsigned xcol = xh2 ? (unsigned)(((xch >> 5) * 64 + (xch & 31)) * 2) : (unsigned)(xch * 2);
   const bool y_ok = ych < a.N, x_ok = xch < a.C;
   auto pixel_of = [&](int j) -> int {
     if ((unsigned)j >= (unsigned)a.J) return -1;
@@ -627,7 +631,7 @@ static __global__ void __launch_bounds__(512, 2) wgrad_fused_h2_kernel(WgradFuse
   };
   auto issue_x = [&](int u0) {
     const int m = pixel_of(j0 - Gpad + u0 + drow);
-    const unsigned off = (m >= 0 && x_ok) ? (unsigned)m * (unsigned)(a.C * EB) + xcol : ~0u;
+    const unsigned off = (m >= 0 && x_ok) ? (unsigned)m * (unsigned)(a.C * EBX) + xcol : ~0u;
     const int rr = u0 % RING;
     half* dst = xh + rr * ROWH + wave * 64 * 8;
     dma16(rsrc_x, off, 0u, dst);
@@ -848,7 +852,8 @@ inline bool wgrad_fused_applies(const WgradArgs& a) {
   const GatherGeom& g = a.g;
   return g.R == 3 && g.S == 3 && g.mul_p == 1 && g.mul_q == 1 && g.div == 1 && g.rsign == 1 && g.ssign == 1 && g.off_h == -1 &&
          g.off_w == -1 && g.P == g.Hi && g.Q == g.Wi && g.C % 8 == 0 && g.N % 8 == 0 && a.colmap == nullptr && a.ldw >= 9 * g.C &&
-         ((g.Q + 2 + 31) / 32) * 32 <= 96 && (long)g.M * a.ldy * 2 < 0xfffffff0l && (long)g.M * g.C * 2 < 0xfffffff0l &&
+         ((g.Q + 2 + 31) / 32) * 32 <= 96 && (long)g.M * a.ldy * 2 < 0xfffffff0l &&
+         (long)g.M * x_row_halves(a.x_h2, g.C) * 2 < 0xfffffff0l && (!a.x_h2 || g.C % 32 == 0) &&
          (long)g.B * (g.P + 1) * (g.Q + 1) < (1L << 30);
 }
 
@@ -921,7 +926,8 @@ inline void launch_wgrad_fused(const WgradArgs& w, int target_blocks, hipStream_
   // SIMD left no room for a BatchNorm-backward wave (122 registers) of the main stream, so the two streams time-sliced the CUs.
   // MN_WGF_LIGHT=0 restores wgrad_fused_kernel.
   static const bool light = !(getenv("MN_WGF_LIGHT") && atoi(getenv("MN_WGF_LIGHT")) == 0);
-  if (form == 0 && light) form = 3;
+  if (form == 0 && (light || w.x_h2)) form = 3;  // (the hi halves of an h2 X: the low-register kernel is the one that reads them)
+  a.x_h2 = w.x_h2;
   a.ring = ((form != 0 ? 1 : D) + 1) * BKM + 2 * a.Gpad;
   a.dq = make_fastdiv(a.Qp);
   a.dp = make_fastdiv(g.P + 1);

@@ -14,11 +14,57 @@ Bucket b = parameters of stage b (3 = layer4+fc+heads+criterion scalars, 2 = lay
 xGMI is point-to-point (7 links x ~153 GB/s): the 57 MB stage-3 bucket is in flight while ~80 % of
 the backward FLOPs (layers 3..1) are still to run.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from ._binding import ptr
 from .engine import _stream
+
+# ---- schedule knobs (read per step, so tools can flip them inside one process) ----------------------------------------------
+# MN_DP_DEFER: when the buckets' all-reduces are ISSUED.  0 (default): each right after its backward stage (maximum overlap);
+#   1: bucket 3 (57 MB, layer4 + head) right after stage 3, buckets 2..0 after backward_stage(0) -- they would otherwise sit on the
+#   CUs beside layer3 / layer2 / layer1 launches that are sized as exactly one round of the chip; 2: every bucket after the last
+#   stage (no overlap, no contention).  The rehearsal table (profiles/r06/rccl_rehearsal.txt) is what the default was chosen from.
+# MN_DP_STANDIN="c[,threads[,busbw_GBps[,latency_us[,lds_kb]]]]": ONE-GPU rehearsal of an 8-GPU run -- instead of an all-reduce (a 1-rank
+#   all-reduce launches nothing) each bucket launches the library's occupancy stand-in (mn_op_occupy) on a communication stream:
+#   c workgroups of `threads` threads resident for the time a ring all-reduce of the bucket over 8 GPUs would take at `busbw`
+#   (default 200 GB/s bus bandwidth + 40 us latency), streaming the bucket's reduce traffic through HBM meanwhile; lds_kb (0, 32,
+#   64): LDS each stand-in workgroup holds -- with tens of KB a CU cannot host a 150 KB convolution workgroup beside it.
+RING_WORLD = 8  # the world the stand-in's duration model assumes
+
+
+def _defer_mode():
+    return int(os.environ.get("MN_DP_DEFER", "0"))
+
+
+def _standin():
+    v = os.environ.get("MN_DP_STANDIN", "")
+    if not v:
+        return None
+    f = v.split(",")
+    return {"c": int(f[0]), "threads": int(f[1]) if len(f) > 1 else 256, "busbw": float(f[2]) if len(f) > 2 else 200.0,
+            "lat_us": float(f[3]) if len(f) > 3 else 40.0, "lds_kb": int(f[4]) if len(f) > 4 else 0}
+
+
+def ring_allreduce_us(nbytes, world=RING_WORLD, busbw_GBps=200.0, lat_us=40.0):
+    """duration model of a ring all-reduce: every GPU moves 2 (world-1)/world of the bucket over its links"""
+    return lat_us + nbytes * 2.0 * (world - 1) / world / (busbw_GBps * 1e3)
+
+
+def rccl_env(defaults=None):
+    """RCCL channel budget for the data-parallel step, set (setdefault) BEFORE the process group is created: every RCCL channel is
+    one resident workgroup per collective, and the backward convolutions are launches of one workgroup per CU sized as one round
+    of the chip -- each channel beyond the 20-odd CUs those launches leave idle pushes a convolution tile into a second round
+    (the stand-in rehearsal, profiles/r06/rccl_rehearsal.txt).  The buckets are 0.9-57 MB under >= 2 ms of backward each: they
+    need residency discipline, not peak bus bandwidth."""
+    env = {"NCCL_MIN_NCHANNELS": "4", "NCCL_MAX_NCHANNELS": "8"}
+    if defaults:
+        env.update(defaults)
+    for k, v in env.items():
+        os.environ.setdefault(k, v)
+    return {k: os.environ[k] for k in env}
 
 
 def world_size():
@@ -82,6 +128,41 @@ def train_step(engine, plan, images, targets):
     return loss, poses
 
 
+class _StandinWork:
+    """what `dist.all_reduce(async_op=True)` returns, for the one-GPU stand-in: wait() = the compute stream waits for the event"""
+
+    def __init__(self, ev):
+        self._ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self._ev)
+
+
+_standin_state = {}
+
+
+def _standin_launch(engine, lib, bucket, cfg):
+    """the stand-in kernel on a communication stream of its own, ordered after the compute stream as RCCL's stream is"""
+    import ctypes as C
+    dev = engine.device
+    st = _standin_state.get(dev)
+    if st is None:
+        st = _standin_state[dev] = {"stream": torch.cuda.Stream(device=dev), "src": None, "dst": None}
+    nbytes = bucket.numel() * bucket.element_size()
+    if st["src"] is None or st["src"].numel() < bucket.numel():
+        st["src"] = torch.zeros(bucket.numel(), dtype=bucket.dtype, device=dev)
+        st["dst"] = torch.zeros(bucket.numel(), dtype=bucket.dtype, device=dev)
+    us = ring_allreduce_us(nbytes, RING_WORLD, cfg["busbw"], cfg["lat_us"])
+    comm = st["stream"]
+    comm.wait_stream(torch.cuda.current_stream(dev))
+    # local HBM traffic of a ring step: every byte of the bucket is read ~2x and written ~2x on each GPU (reduce-scatter + all-gather)
+    lib.check(lib.op_occupy(cfg["c"], cfg["threads"], C.c_float(us), ptr(st["src"]), ptr(st["dst"]), C.c_int64((nbytes // 16) * 16),
+                            cfg["lds_kb"], C.c_void_p(comm.cuda_stream)))
+    ev = torch.cuda.Event()
+    ev.record(comm)
+    return _StandinWork(ev)
+
+
 def _staged_step(engine, plan, images, targets, lib, h, s):
     import ctypes as C
     poses = plan["poses"]
@@ -89,11 +170,22 @@ def _staged_step(engine, plan, images, targets, lib, h, s):
     grads = engine.grads()
     works = []
     multi = world_size() > 1 or (dist.is_available() and dist.is_initialized())
+    standin = _standin() if (s is not None and not multi) else None
+    defer = _defer_mode()
+    deferred = []
     timed = _profile["on"] and s is not None
     if timed:
         t0 = torch.cuda.Event(enable_timing=True)
         t0.record()
         ready, passed = [], []
+
+    def issue(bucket):
+        # async: RCCL runs on its own stream, ordered after the kernels enqueued so far
+        if multi:
+            works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+        elif standin is not None:
+            works.append(_standin_launch(engine, lib, bucket, standin))
+
     for stage in (3, 2, 1, 0):
         lib.check(lib.train_backward_stage(h, stage, s))
         if timed:
@@ -103,9 +195,12 @@ def _staged_step(engine, plan, images, targets, lib, h, s):
         off, cnt = C.c_int64(), C.c_int64()
         lib.check(lib.grad_bucket(h, stage, C.byref(off), C.byref(cnt)))
         bucket = grads[off.value: off.value + cnt.value]
-        # async: RCCL runs on its own stream, ordered after the kernels enqueued so far
-        if multi:
-            works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+        if defer == 2 or (defer == 1 and stage != 3):
+            deferred.append(bucket)  # issued after the last backward stage, in backward order
+        else:
+            issue(bucket)
+    for bucket in deferred:
+        issue(bucket)
     if timed:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()

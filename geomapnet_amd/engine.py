@@ -27,7 +27,10 @@ MODE_POSENET, MODE_MAPNET, MODE_ONLINE, MODE_GPS = 0, 1, 2, 3
 DTYPES = {"fp32": 0, "fp16": 1, "fp32x3": 2, "fp16x2": 3, "fp16x2m": 4, "fp16x2q": 5}
 SCALED_DTYPES = ("fp16", "fp16x2", "fp16x2m", "fp16x2q")  # modes whose gradients pass through fp16 halves
 
-_default_dtype = "fp16"
+# The library default is the mode inside the north-star tolerance (loss 1e-4 / poses 1e-3 against the fp32 reference): the same
+# default as scripts/train.py, scripts/eval.py and bench.py (round-5 ADVICE: API users and script users must not get different
+# numerics).  set_compute_dtype("fp16") buys ~1.5x the throughput at poses 1.3e-2 from the reference.
+_default_dtype = "fp16x2m"
 _default_loss_scale = 1024.0
 
 # Where a plan's work arena comes from: None = torch.empty (the caching allocator), or a callable (nbytes, device) -> uint8
@@ -37,8 +40,9 @@ _step_streams = {}  # device index -> the process-wide step stream (Engine.step_
 
 
 def set_compute_dtype(name, loss_scale=None):
-    """'fp16' (fp16 tensors, fp32 accumulate; the benchmark configuration), 'fp16x2' (fp16-pair conv operands, fp32
-    everything else: the parity configuration), 'fp16x2m' (that forward pass, the fp16 mode's backward pass),
+    """'fp16x2m' (default: fp16-pair conv operands in the forward pass -- loss and poses inside the north-star tolerance -- and the
+    fp16 mode's one-MFMA backward pass), 'fp16' (fp16 tensors, fp32 accumulate: ~1.5x faster, outside the tolerance), 'fp16x2'
+    (fp16-pair conv operands forward and backward, fp32 everything else),
     'fp32x3' (fp32 tensors, operands split inside the convolution kernels) or
     'fp32' (fp32 tensors on v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain)."""
     global _default_dtype, _default_loss_scale
@@ -205,7 +209,11 @@ class Engine:
         if p.get("dropout", (0.0, 0)) != self.dropout:
             self.lib.check(self.lib.set_dropout(p["handle"], C.c_float(self.dropout[0]), C.c_uint64(self.dropout[1])))
             p["dropout"] = self.dropout
-            if self.dropout[0] > 0.0:  # (mn_set_dropout restarts the mask sequence at 0: continue from the model's step count)
+            if self.dropout[0] > 0.0:
+                # mn_set_dropout restarts the mask sequence at 0: continue from the model's count of APPLIED steps, which lives on
+                # the device of the plan that stepped last (round-5 ADVICE: the host's view is stale while that plan owns the
+                # counter, and _own_step returns early for the owner -- the sequence would replay its first masks)
+                self._read_step()
                 self.lib.check(self.lib.set_dropout_calls(p["handle"], self.step_count & 0xffffffff))
         self._own_step(p)
         return p

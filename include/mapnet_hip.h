@@ -213,7 +213,8 @@ int64_t mn_stuck_overflow_steps(mn_handle* h);
  * (+ "yd", "zd", "gyd" for blocks with a projection); NHWC.  In the fp16x2 mode the tensors the convolutions consume ("p0",
  * "a1", "out", "zd", "gy1", "gy2", "gyd") are h2 tensors and report dtype MN_DTYPE_F16X2; in the fp16x2m mode the forward ones
  * of these are h2 and every gradient tensor of the blocks ("gp0", "gy1", "ga1", "gy2", "gout", "gyd") is plain fp16 (MN_DTYPE_F16),
- * and "p0.f16" / "b<i>.a1.f16" / "b<i>.out.f16" name the plain fp16 copies of the activations; in the fp16x2q mode the forward ones are
+ * (round 5's plain fp16 copies "p0.f16" / "b<i>.a1.f16" / "b<i>.out.f16" are gone: the backward kernels read the hi halves of the h2
+ * tensors in place); in the fp16x2q mode the forward ones are
  * h2q tensors (geomapnet_amd/csrc/common.h) and report MN_DTYPE_F16X2Q.  Read-only for the caller. */
 int mn_debug_tensor(mn_handle* h, const char* name, void** ptr, int64_t* numel, int32_t* dtype);
 
@@ -238,10 +239,6 @@ typedef struct mn_gather_geom {
  * the image are zero-filled by the hardware bounds check.  zero_page: >= 16 zero bytes in device memory,
  * 16-byte aligned; required (the weight-gradient kernels that gather strided convolutions read their
  * out-of-image taps from it; mn_op_igemm accepts it for symmetry). */
-/* EXPERIMENT (round 5, not used by the plans): out = conv3x3 stride 1 (relu(A * scale[c] + shift[c]), Bw) in fp16 with the
- * BatchNorm apply + ReLU of the producing layer fused into the convolution's operand path; coef = [2][C] floats (scale | shift).
- * The consumer-side fusion of SURVEY.md section 7 step 5, measured against the conv + bn_apply launches it would replace. */
-int mn_op_igemm_fbn(const mn_gather_geom* g, const void* A, const float* coef, const void* Bw, void* out, int ldc, void* stream);
 int mn_op_igemm(int dtype, const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, float* stats,
                 const float* bias, int relu, const void* res, const void* res_gate, float alpha, const void* zero_page,
                 void* stream);
@@ -356,9 +353,11 @@ int mn_op_maxpool_bwd(int dtype, const unsigned char* idx, const void* gout, voi
  * for `microseconds`, streaming `bytes` of dst += src (fp32, 16-byte pieces) at an even pace over that time.  geomapnet_amd/dp.py
  * launches it where a gradient bucket's all-reduce is issued (MN_DP_STANDIN) so that the CU contention between the collective and
  * the backward convolutions -- one workgroup per CU, launches sized as one round of the chip -- can be measured without peers
- * (tools/rccl_rehearsal.py, profiles/r06/rccl_rehearsal.txt).  src / dst may be NULL with bytes = 0 (residency only).
+ * (tools/rccl_rehearsal.py, profiles/r06/rccl_rehearsal.txt).  src / dst may be NULL with bytes = 0 (residency only); lds_kb = 0, 32
+ * or 64: LDS each stand-in workgroup holds (a CU hosting one with tens of KB cannot also host a 150 KB convolution workgroup).
  * ------------------------------------------------------------------------------------------ */
-int mn_op_occupy(int workgroups, int threads, float microseconds, const void* src, void* dst, int64_t bytes, void* stream);
+int mn_op_occupy(int workgroups, int threads, float microseconds, const void* src, void* dst, int64_t bytes, int lds_kb,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ hot path (NVlabs/geomapnet): ResNet-34 feature extractor + PoseNet/MapNet heads,
 pose criteria, the log-quaternion relative-pose math, and one `step_feedfwd` training step
 with Adam.  Every function cites the reference file:line it follows.
 
-Rules (enforced by tests/test_no_oracle_in_product.py):
+Rules (enforced by tests/test_host_logic.py::test_product_never_imports_the_oracle_or_the_emulator):
   * only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import it;
   * nothing under geomapnet_amd/ imports it -- the product path is the HIP library and fails
     loudly when that library is missing.

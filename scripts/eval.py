@@ -39,7 +39,8 @@ def build_parser():
                         help="apply the config's dropout on the device in training mode (default: identity, the reference's "
                              "behaviour under its pinned PyTorch 0.4.1)")
     parser.add_argument("--dtype", choices=("fp16", "fp16x2m", "fp16x2q", "fp16x2", "fp32x3", "fp32"), default="fp16x2m",
-                        help="compute precision (default: the split-fp16 forward pass, whose poses match the fp32 reference to 1e-3)")
+                        help="compute precision (default: the split-fp16 forward pass, whose poses match the fp32 reference to 1e-3; "
+                             "fp16x2q is experimental: fp8 cross terms that saturate silently beyond |activation| 448 / |weight| 7)")
     parser.add_argument("--synthetic_length", type=int, default=256)
     parser.add_argument("--u8_input", action="store_true", help="frames as uint8 [H,W,3]; ToTensor + Normalize run on the "
                         "device (model.set_input_u8)")

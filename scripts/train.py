@@ -50,7 +50,9 @@ def build_parser():
                              "(common/train.py:322-363) and this is the fastest mode whose loss and poses match it to 1e-4 / 1e-3 "
                              "(split-fp16 forward pass, single-fp16 backward pass).  fp16 is 1.5x faster and trains to the same "
                              "accuracy on the synthetic scene (profiles/r05) but deviates 1.3e-2 on the poses of a single step; fp16x2 "
-                             "/ fp32x3 / fp32 keep fp32-class arithmetic in the backward pass too")
+                             "/ fp32x3 / fp32 keep fp32-class arithmetic in the backward pass too; fp16x2q is EXPERIMENTAL (forward cross terms from fp8 "
+                             "copies with fixed exponents: they saturate silently beyond |activation| 448 / |weight| 7, poses 6e-4 from the "
+                             "reference, gradients off by percents -- not for pretrained or diverging networks)")
     parser.add_argument("--pretrained", choices=("auto", "yes", "no"), default="auto",
                         help="start from the torchvision ImageNet ResNet-34 ($TORCH_MODEL_ZOO/resnet34-333f7ec4.pth, as the "
                              "reference does: models.resnet34(pretrained=True), scripts/train.py:76) and re-initialise only the "

@@ -10,10 +10,11 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, same_data, out_dir):
+def _worker(rank, world, port, same_data, out_dir, defer=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MAPNET_EMU_THREADS"] = "4"
+    os.environ["MN_DP_DEFER"] = str(defer)
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     import emu_lib
@@ -113,6 +114,25 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     l0, g0, _ = _single(7, None)
     l1, g1, _ = _single(8, None)
     # all-reduced buckets = sum of the per-rank gradients; reported loss = mean of the rank losses
+    want = g0 + g1
+    assert (r0["grads"] - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    assert abs(r0["loss"] - 0.5 * (l0 + l1)) <= 1e-5 * abs(l0)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("defer", [1, 2])
+def test_two_rank_deferred_bucket_schedules_give_the_same_step(tmp_path, defer):
+    """MN_DP_DEFER (geomapnet_amd/dp.py): bucket 3 at once and buckets 2..0 after the last backward stage (1), or every bucket
+    after the last stage (2) -- schedules for when RCCL's workgroups must not sit beside the one-round convolution launches
+    (profiles/r06/rccl_rehearsal.txt).  WHEN a bucket is reduced must not change WHAT the step computes: all-reduced gradients =
+    sum of the per-rank gradients, replicas identical, as under the default schedule"""
+    port = 35500 + os.getpid() % 2000 + 100 * defer
+    mp.spawn(_worker, args=(2, port, False, str(tmp_path), defer), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grads"], r1["grads"])
+    l0, g0, _ = _single(7, None)
+    l1, g1, _ = _single(8, None)
     want = g0 + g1
     assert (r0["grads"] - want).abs().max().item() <= 1e-5 * want.abs().max().item()
     assert abs(r0["loss"] - 0.5 * (l0 + l1)) <= 1e-5 * abs(l0)

@@ -35,15 +35,6 @@ def test_conv_forward_with_fp8_cross_terms(lib, shape):
     checks.check_conv_fwd_h2q(lib, DEV, *shape)
 
 
-@pytest.mark.parametrize("shape", [
-    (2, 6, 7, 128, 256),    # 256-column shape, two 64-channel chunks
-    (1, 5, 9, 192, 128),    # 128-column shape, three chunks
-])
-def test_conv_with_the_batchnorm_apply_fused_into_its_operand_path(lib, shape):
-    """igemm_halo.h FBN (round-5 experiment, not used by the plan)"""
-    checks.check_conv_fbn(lib, DEV, *shape)
-
-
 @pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [
     (2, 9, 11, 64, 64, 3, 1, 1),
@@ -250,3 +241,21 @@ def test_chunk_resident_a_kernel_h2(force256):
     if force256 == "0":  # the 128-column launches again through layer2's two-workgroup single-image shape
         subprocess.run([sys.executable, os.path.join(here, "forced_config_cases.py"), "emu"], check=True, env=dict(env, MN_HALO_A1="2"),
                        timeout=1500)
+
+
+def test_occupancy_stand_in_streams_its_bytes_and_lasts_its_time(lib):
+    """mn_op_occupy (csrc/rehearsal.h), the one-GPU stand-in for an RCCL ring step: dst += src over the whole range, resident for at
+    least the requested time"""
+    import ctypes as C
+    import time
+
+    import torch
+    from geomapnet_amd._binding import ptr
+    src = torch.arange(4096, dtype=torch.float32)
+    dst = torch.ones(4096, dtype=torch.float32)
+    t0 = time.perf_counter()
+    lib.check(lib.op_occupy(2, 64, C.c_float(20000.0), ptr(src), ptr(dst), C.c_int64(4096 * 4), 32, None))
+    dt = time.perf_counter() - t0
+    assert torch.equal(dst, src + 1.0)
+    assert dt >= 0.02, dt
+    assert lib.op_occupy(0, 64, C.c_float(1.0), None, None, C.c_int64(0), 0, None) != 0  # argument check

@@ -450,6 +450,22 @@ def test_uint8_input_pipeline(lib):
     checks.check_u8_input(lib, DEV, N=2, H=128, W=171, dtype_name="fp16x2m")
 
 
+@pytest.mark.parametrize("dtype,u8", [("fp16", False), ("fp16x2m", True)])
+def test_device_feed_prefetch_cannot_race_the_step(lib, dtype, u8):
+    """DeviceFeed (geomapnet_amd/feed.py; Trainer's input path): batch k+1 is copied from pinned host memory on a copy stream while
+    step k runs.  Eight distinct 24-image full-resolution batches through two rotating staging buffers against synchronous copies,
+    bit for bit under MN_DETERMINISTIC=1 (losses of every step and the final parameters)"""
+    checks.check_device_feed(lib, DEV, dtype, N=8, H=256, W=341, batches=8, u8=u8)
+
+
+def test_staged_step_with_stand_in_collectives_and_deferred_buckets_computes_the_same_bits(lib):
+    """the one-GPU rehearsal of the 8-GPU step (MN_DP_STANDIN: the library's occupancy stand-in on a communication stream where each
+    bucket's all-reduce is issued; MN_DP_DEFER=1: buckets 2..0 after the last backward stage) is a change of SCHEDULE: the staged step
+    fed by DeviceFeed must compute the bits of the plain fused step"""
+    checks.check_device_feed(lib, DEV, "fp16", N=4, H=128, W=171, batches=4,
+                             staged_env={"MN_FORCE_STAGED": "1", "MN_DP_STANDIN": "16,256,200,40", "MN_DP_DEFER": "1"})
+
+
 def test_eval_flow_and_metric(lib):
     """scripts/eval.py flow on synthetic windows: median / mean translation and rotation error"""
     checks.check_eval_flow(lib, DEV, "fp32", L=8, T=3, H=128, W=171)

@@ -193,9 +193,7 @@ def test_shipped_k_loops_have_no_scratch_access_and_asm_reads_skip_the_dma_wait(
                            r"igemm_kernelIDF16_Li2ELi2ELi2ELi2ELi8ELi2ELi2ELb1ELb0ELi0ELi0E|"
                            r"igemm_kernelIDF16_Li2ELi2ELi4ELi2ELi4ELi3ELi2ELb1ELb0ELi0ELi0E|"
                            r"wgrad_dma_kernelILi\d+ELi\d+ELi32ELi\dELb1ELb1E|"
-                           r"igemm_halo_kernelILi\d+ELi\d+ELi0ELi1ELb[01]ELi\dELi\dELb[01]ELb0E")  # igemm_halo_kernel<BN, kAH, ABL = 0, DP = 1, H2, WM, WN, A1, FBN = false>
-    # (the FBN = true variants are round 5's consumer-side BatchNorm fusion EXPERIMENT, not launched by any plan: the 256-column one
-    #  holds 8 more registers than the 168 a 12-wave shape may have and spills 7 of them -- recorded with its timing, profiles/r05)
+                           r"igemm_halo_kernelILi\d+ELi\d+ELi0ELi1ELb[01]ELi\dELi\dELb[01]ELi[12]E")  # igemm_halo_kernel<BN, kAH, ABL = 0, DP = 1, H2, WM, WN, A1, OCC, Q>
     # two fp16 shapes + the four h2 shapes of the fp16x2 mode (256 columns, 128 columns at 288 / 384 rows, layer1's 64 columns)
     # (igemm.h: 3, wgrad_dma: 4, igemm_halo: the fp16 shapes 256 / 128 x 288 / 128 x 384 + the four h2 shapes; every shape that
     # is added joins the audit below by matching the pattern)
@@ -238,3 +236,27 @@ def test_evaluate_scatters_middle_predictions_by_frame_index(monkeypatch):
     assert np.allclose(pred[2, :3], 0.4), "the later window overwrites the earlier one"
     assert np.allclose(pred[3], 0) and np.allclose(pred[4], 0)  # no window centres there: rows stay zero, as in the reference
     assert np.allclose(targ[2, :3], 3.0)
+
+
+def test_device_feed_is_a_pass_through_on_cpu_and_keeps_the_loader_contract():
+    """geomapnet_amd.DeviceFeed on a CPU device hands out the loader's own batches, in order, and reports the loader's length"""
+    import geomapnet_amd as G
+    batches = [(torch.full((2, 3), float(i)), torch.full((2, 6), -float(i))) for i in range(5)]
+    feed = G.DeviceFeed(batches, "cpu")
+    assert len(feed) == 5
+    got = list(feed)
+    assert all(a is b for (a, _), (b, _) in zip(got, batches)) and len(got) == 5
+    with pytest.raises(ValueError):
+        G.DeviceFeed(batches, "cpu", depth=1)
+
+
+def test_ring_allreduce_duration_model_and_rccl_channel_budget(monkeypatch):
+    """dp.py's stand-in duration model and the RCCL environment the data-parallel bench sets before creating its process group"""
+    from geomapnet_amd import dp
+    assert abs(dp.ring_allreduce_us(57e6, 8, 200.0, 40.0) - (40.0 + 57e6 * 1.75 / 200e3)) < 1e-6
+    assert dp.ring_allreduce_us(0.9e6) < dp.ring_allreduce_us(4.5e6) < dp.ring_allreduce_us(27e6)
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "0")  # (so that the teardown restores the variable's original state)
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "2")  # a user's setting wins
+    env = dp.rccl_env()
+    assert env["NCCL_MIN_NCHANNELS"] == "2" and int(env["NCCL_MAX_NCHANNELS"]) >= 2

@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 for rep in 1 2; do
   for arm in "$@"; do
-    v=$(env $arm python bench.py --dtype ${DT:-fp16} --no-cpu-baseline --no-events --no-parity-mode --no-eval-metric --steps ${STEPS:-30} --warmup 8 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
-    echo "[${DT:-fp16} $arm] $v"
+    v=$(env $arm python bench.py --dtype ${DT:-fp16x2m} --no-cpu-baseline --no-events --no-fast-mode --no-eval-metric --no-feed --steps ${STEPS:-30} --warmup 8 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    echo "[${DT:-fp16x2m} $arm] $v"
   done
 done

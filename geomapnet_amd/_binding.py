@@ -65,6 +65,8 @@ _PROTOS = {
     "mn_train_backward_stage": (c_i, [c_void, c_i, c_void]),
     "mn_grad_bucket": (c_i, [c_void, c_i, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "mn_optim_step": (c_i, [c_void, c_f, c_void]),
+    "mn_grad_bucket_pack_bf16": (c_i, [c_void, c_i, c_void, c_void]),
+    "mn_grad_bucket_unpack_bf16": (c_i, [c_void, c_i, c_void, c_void]),
     "mn_params_changed": (c_i, [c_void]),
     "mn_set_profiling": (c_i, [c_void, c_i]),
     "mn_last_kernel_ms": (c_i, [c_void, c_i, C.POINTER(c_f), C.POINTER(c_i)]),

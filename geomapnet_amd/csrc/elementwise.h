@@ -22,9 +22,11 @@ inline int ew_grid(long work_items) {
 }
 
 // ---- input: NCHW fp32 -> zero-padded NHWC4 (pad 3 top/left, >=3 bottom/right) -------------------
+// out16 (optional, fp16x2m: the stem's fp16 backward kernels read an fp16 image of the input): the same pixels once more as fp16, from
+// the same loads (round 5 launched the conversion twice)
 template <typename T>
 static __global__ void __launch_bounds__(256) nchw_to_padded_nhwc4_kernel(const float* __restrict__ in, T* __restrict__ out,
-                                                                    int B, int H, int W, int Hp, int Wp) {
+                                                                    int B, int H, int W, int Hp, int Wp, half* __restrict__ out16) {
   long total = (long)B * Hp * Wp;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int wp = (int)(i % Wp);
@@ -44,6 +46,10 @@ static __global__ void __launch_bounds__(256) nchw_to_padded_nhwc4_kernel(const 
     o[1] = v[1];
     o[2] = v[2];
     o[3] = v[3];
+    if (out16) {
+      half4 h = {(half)(float)v[0], (half)(float)v[1], (half)(float)v[2], (half)0.f};
+      *reinterpret_cast<half4*>(out16 + i * 4) = h;
+    }
   }
 }
 
@@ -56,7 +62,7 @@ struct InputNorm {
 template <typename T>
 static __global__ void __launch_bounds__(256) u8nhwc_to_padded_nhwc4_kernel(const unsigned char* __restrict__ in,
                                                                       T* __restrict__ out, int B, int H, int W, int Hp,
-                                                                      int Wp, InputNorm nm) {
+                                                                      int Wp, InputNorm nm, half* __restrict__ out16) {
   long total = (long)B * Hp * Wp;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int wp = (int)(i % Wp);
@@ -76,6 +82,10 @@ static __global__ void __launch_bounds__(256) u8nhwc_to_padded_nhwc4_kernel(cons
     o[1] = v[1];
     o[2] = v[2];
     o[3] = v[3];
+    if (out16) {
+      half4 h = {(half)(float)v[0], (half)(float)v[1], (half)(float)v[2], (half)0.f};
+      *reinterpret_cast<half4*>(out16 + i * 4) = h;
+    }
   }
 }
 

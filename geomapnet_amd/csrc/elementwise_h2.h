@@ -82,26 +82,48 @@ __device__ __forceinline__ void f16_store8(half* __restrict__ base, long row, in
   *reinterpret_cast<piece_t*>(base + row * C + c) = o.p;
 }
 
+// ---- the backward record of a BatchNorm (round 6, fp16x2m) ------------------------------------------------------------------------
+// What BatchNorm's backward pass needs of the forward pass is xhat = (y - mean) * invstd, to the precision of a REDUCTION operand and
+// of an O(mgx) correction term, plus -- for the unit in front of a ReLU -- the exact OUTCOME of that ReLU.  Round 5 re-read the fp32
+// conv output for both (4 bytes per element in each of the two backward passes, the gate recomputed with the forward's arithmetic).
+// The record is 2 bytes: fp16(xhat), round to nearest, with its lowest mantissa bit replaced by the gate -- xhat to 2^-10 relative
+// (it has zero mean and unit variance per channel, so no offset eats the bits, unlike fp16(y)), the gate EXACT.  Dense [M][C] fp16.
+// Cost: +2 bytes per element written by the forward apply; saving: 2 bytes per element in each backward pass.
+__device__ __forceinline__ half rec_pack(float xhat, bool gate) {
+  const half h = (half)xhat;
+  const unsigned short b = (unsigned short)((__builtin_bit_cast(unsigned short, h) & 0xfffeu) | (gate ? 1u : 0u));
+  return __builtin_bit_cast(half, b);
+}
+__device__ __forceinline__ float rec_xhat(half r) {
+  return (float)__builtin_bit_cast(half, (unsigned short)(__builtin_bit_cast(unsigned short, r) & 0xfffeu));
+}
+__device__ __forceinline__ bool rec_gate(half r) { return (__builtin_bit_cast(unsigned short, r) & 1u) != 0; }
+
 // out(h2) = [relu]( y * scale[c] + shift[c] [+ res(h2)] );  bn_apply_kernel with 8 channels per thread.  (Round 5 wrote a plain fp16
 // copy of the same values beside it for the fp16x2m mode's backward pass; its kernels now read the hi halves in place.)
+// rec (round 6, training passes of the fp16x2m mode; may be null): the BACKWARD RECORD of this BatchNorm (rec_pack below), written
+// here because this pass holds y, the statistics and the ReLU's outcome at once.
 static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __restrict__ y, const float* __restrict__ coef,
                                                                  const half* __restrict__ res, half* __restrict__ out,
-                                                                 long nitems, int C, int relu, int q) {
+                                                                 long nitems, int C, int relu, int q, half* __restrict__ rec,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd) {
   constexpr int VEC = 8;
   const int cpr = C / VEC;
-  __shared__ floatx2 tab[512];  // [e][piece] -> (scale, shift)
+  __shared__ floatx4 tab[512];  // [e][piece] -> (scale, shift, mean, invstd)
   for (int c = threadIdx.x; c < C; c += 256) {
-    const floatx2 v = {coef[c], coef[C + c]};
+    const floatx4 v = {coef[c], coef[C + c], rec ? mean[c] : 0.f, rec ? invstd[c] : 0.f};
     tab[(c % VEC) * cpr + c / VEC] = v;
   }
   __syncthreads();
   const int cp = (int)(threadIdx.x % cpr);  // loop invariant: the grid stride is a multiple of cpr (a power of two <= 64)
-  float sc[VEC], sh[VEC];
+  float sc[VEC], sh[VEC], mu[VEC], is[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
-    const floatx2 v = tab[e * cpr + cp];
+    const floatx4 v = tab[e * cpr + cp];
     sc[e] = v[0];
     sh[e] = v[1];
+    mu[e] = v[2];
+    is[e] = v[3];
   }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nitems; i += (long)gridDim.x * blockDim.x) {
     const long row = i / cpr;
@@ -116,9 +138,14 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
       else
         h2_load8(res, row, C, cp * VEC, r);
     }
+    PieceView<half> rc;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
+      const float xh = (f[e] - mu[e]) * is[e];
       f[e] = f[e] * sc[e] + sh[e];
+      // the gate the backward pass of THIS BatchNorm may need is its own ReLU's (a unit whose ReLU follows the residual add never
+      // needs one: the gradient of a block output arrives already gated)
+      rc.e[e] = rec_pack(xh, !res && relu ? f[e] > 0.f : true);
       if (res) f[e] += r[e];
       if (relu) f[e] = fmaxf(f[e], 0.f);
     }
@@ -126,6 +153,7 @@ static __global__ void __launch_bounds__(256) bn_apply_h2_kernel(const float* __
       h2q_store8(out, row, C, cp * VEC, f);
     else
       h2_store8(out, row, C, cp * VEC, f);
+    if (rec) *reinterpret_cast<piece_t*>(rec + row * C + cp * VEC) = rc.p;
   }
 }
 
@@ -270,6 +298,123 @@ inline void launch_bn_bwd_h2(const float* g, const float* y, long M, int C, cons
   const long ni = M * C / 8;
   hipLaunchKernelGGL(bn_bwd_apply_h2_kernel, dim3(ew_grid(ni)), dim3(256), 0, s, g, y, mean, invstd, (const float*)coef, gy, ni, C,
                      self_gate_beta ? 1 : 0);
+}
+
+// ---- BatchNorm backward from the record (fp16x2m): fp16 gradient + fp16 record in, fp16 d(conv output) out ------------------------
+// reduce: accum[0][c] += sum gm, accum[1][c] += sum gm * xhat, gm = g where the record's gate bit is set (use_gate) or g as it is
+template <int U>
+static __global__ void __launch_bounds__(256) bn_bwd_reduce_rec_kernel(const half* __restrict__ g, const half* __restrict__ rec, long M,
+                                                                       int C, double* __restrict__ accum, int rows_per_block,
+                                                                       int use_gate, int accum_rows) {
+  constexpr int VEC = 8;
+  __shared__ float red[2][256][VEC];
+  const int cpr = C / VEC, rlanes = 256 / cpr;
+  const int cp = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  for (long r = r0 + rl; r < r1; r += (long)U * rlanes) {
+    PieceView<half> vg[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long rr = r + (long)u * rlanes;
+      const bool in = rr < r1;
+      const long idx = (in ? rr : r) * cpr + cp;
+      vg[u].p = in ? reinterpret_cast<const piece_t*>(g)[idx] : zero_piece();
+      vr[u].p = reinterpret_cast<const piece_t*>(rec)[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float gv = (float)vg[u].e[e];
+        if (use_gate && !rec_gate(vr[u].e[e])) gv = 0.f;
+        s1[e] += gv;
+        s2[e] += gv * rec_xhat(vr[u].e[e]);
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[0][threadIdx.x][e] = s1[e];
+    red[1][threadIdx.x][e] = s2[e];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < C; idx += 256) {
+    const int p = idx / VEC, e = idx % VEC;
+    double a = 0, b = 0;
+    for (int l = 0; l < rlanes; ++l) {
+      a += red[0][l * cpr + p][e];
+      b += red[1][l * cpr + p][e];
+    }
+    double* row = accum + (long)((int)blockIdx.x % accum_rows) * 2 * C;  // [accum_rows][2][C]
+    atomicAdd(row + idx, a);
+    atomicAdd(row + C + idx, b);
+  }
+}
+
+// apply: gy = k1 * (gm - mg - xhat * mgx) = k1 gm + kx xhat + kd with (k1, kx, kd) per channel in registers (coef: bn_finalize_bwd_kernel's)
+static __global__ void __launch_bounds__(256) bn_bwd_apply_rec_kernel(const half* __restrict__ g, const half* __restrict__ rec,
+                                                                      const float* __restrict__ coef, half* __restrict__ gy,
+                                                                      long npieces, int C, int use_gate) {
+  constexpr int VEC = 8;
+  const int cpr = C / VEC;
+  float k1[VEC], kx[VEC], kd[VEC];
+  {
+    __shared__ floatx4 tab[512];  // [e][piece] -> (k1, kx, kd, -)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float a = coef[c];
+      const floatx4 v = {a, -a * coef[2 * C + c], -a * coef[C + c], 0.f};
+      tab[(c % VEC) * cpr + c / VEC] = v;
+    }
+    __syncthreads();
+    const int cp = (int)(threadIdx.x % cpr);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const floatx4 v = tab[e * cpr + cp];
+      k1[e] = v[0];
+      kx[e] = v[1];
+      kd[e] = v[2];
+    }
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) {
+    PieceView<half> vg, vr, o;
+    vg.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(g) + i);
+    vr.p = MN_LOAD_LAST(reinterpret_cast<const piece_t*>(rec) + i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float gv = (float)vg.e[e];
+      if (use_gate && !rec_gate(vr.e[e])) gv = 0.f;
+      o.e[e] = (half)(k1[e] * gv + (kx[e] * rec_xhat(vr.e[e]) + kd[e]));
+    }
+    reinterpret_cast<piece_t*>(gy)[i] = o.p;
+  }
+}
+
+// reduce -> finalize (elementwise.h: sums -> coefficients, d gamma, d beta) -> apply, all on the record
+inline void launch_bn_bwd_rec(const half* g, const half* rec, long M, int C, const float* gamma, const float* mean, const float* invstd,
+                              float* dgamma, float* dbeta, half* gy, double* accum, float* coef, float grad_unscale, hipStream_t s,
+                              bool use_gate, int accum_rows) {
+  constexpr int VEC = 8;
+  static const long target = getenv("MN_BN_REDUCE_WGS") ? atol(getenv("MN_BN_REDUCE_WGS")) : 512;  // (launch_bn_bwd explains)
+  const int rlanes = 256 / (C / VEC);
+  long rows = (M + target - 1) / target;
+  rows = ((rows + rlanes - 1) / rlanes) * rlanes;
+  if (rows < 4L * rlanes) rows = 4L * rlanes;
+  const int rows_per_block = (int)rows;
+  const int nblk = cdiv(M, rows_per_block);
+  static const int reduce_u = getenv("MN_BN_REDUCE_U") ? atoi(getenv("MN_BN_REDUCE_U")) : 4;
+  if (reduce_u == 2)
+    hipLaunchKernelGGL((bn_bwd_reduce_rec_kernel<2>), dim3(nblk), dim3(256), 0, s, g, rec, M, C, accum, rows_per_block, use_gate ? 1 : 0,
+                       accum_rows);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce_rec_kernel<4>), dim3(nblk), dim3(256), 0, s, g, rec, M, C, accum, rows_per_block, use_gate ? 1 : 0,
+                       accum_rows);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, kBnFinalizeChannels)), dim3(256), 0, s, (const double*)accum, (double)M, gamma, mean,
+                     invstd, dgamma, dbeta, grad_unscale, (const float*)nullptr, coef, C, accum_rows);
+  const long np = M * C / VEC;
+  hipLaunchKernelGGL(bn_bwd_apply_rec_kernel, dim3(ew_grid(np)), dim3(256), 0, s, g, rec, (const float*)coef, gy, np, C, use_gate ? 1 : 0);
 }
 
 // out[i] = (float) in[i], 8 elements per thread (fp16x2m: the pooled stem activation's fp16 gradient for the stem's fp32 chain)

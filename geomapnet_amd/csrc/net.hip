@@ -219,6 +219,7 @@ struct PlanBase {
   virtual int backward_stage(int stage, hipStream_t s) = 0;
   virtual int optim_step(float grad_mul, hipStream_t s) = 0;
   virtual int debug_tensor(const char* name, void** ptr, int64_t* numel, int32_t* dtype) = 0;
+  virtual float* grad_arena() = 0;
   mn_config cfg;
   // fp16 loss scaling.  cur_scale multiplies d(pred) and is divided out where gradients enter the fp32 arena.  An
   // overflowed step is skipped on the device (optim.h, adam_prep_kernel); the count of skipped steps is copied to a
@@ -305,6 +306,7 @@ struct Plan : PlanBase {
     T* wd = nullptr;  // data-gradient operand [Cin][R*S*Cout]
     T* y = nullptr;   // raw conv output [M][Cout]
     T* gy = nullptr;  // its gradient
+    half* rec = nullptr;  // fp16x2m: the BatchNorm's backward record [M][Cout] (elementwise_h2.h rec_pack), written by the forward apply
     float *mean, *invstd;
     float *coef_f, *coef_b;  // per-channel coefficients of the forward apply [2][C] / backward apply [4][C] (finalize kernels)
     double *accum_f, *accum_b;  // fp64 sums of the forward statistics / backward reductions, [rows_f | rows_b][2][C]
@@ -438,6 +440,7 @@ struct Plan : PlanBase {
       for (Unit* u : us) {
         if (!u) continue;
         unit_bufs(*u);
+        if (use_rec) u->rec = (half*)A((size_t)u->M * u->cp.cout * sizeof(half));
         size_t wn = (size_t)u->cp.cout * u->cp.cin * u->cp.k * u->cp.k;
         if (DT == MN_F16 || h2)
           u->wf = (T*)A(wn * sizeof(T));  // (h2: 4 bytes per element as well)
@@ -518,8 +521,17 @@ struct Plan : PlanBase {
   // What stays exact: every gate (sign of the forward value) and BatchNorm's backward statistics (fp32 conv output, fp64 sums).
   // What it costs the gradients: 1.1e-3 relative L2 overall / 1.6e-3 worst tensor (tools/mixed_budget.py: the oracle's own step
   // with fp16 conv operands in the backward pass) -- a fifth of the 4.9e-3 / 1.1e-2 by which two correct fp32 evaluations of this
-  // network differ through ReLU gate flips.  The stem's backward stays on the fp32 chain of fp16x2.
+  // network differ through ReLU gate flips.  The STEM is the exception to "statistics from the exact forward
+  // values": by default (stem_f16) its two backward kernels (stem_bwd.h) read an fp16 copy of the fp32 conv output (written by the
+  // stem's BatchNorm + max-pool pass) and an fp16 image of the input, so its BatchNorm-backward sums and xhat come from fp16-rounded
+  // y; only its ReLU gate stays exact (the pooled gradient arrives already gated by layer1.0's data gradient).  MN_DETERMINISTIC=1
+  // or MN_STEM_BWD=0 keep the fp32 chain of fp16x2 for the stem.
   bool mixed = false;
+  // fp16x2m, round 6: BatchNorm's backward pass reads a 2-byte RECORD of the forward pass (fp16 xhat + the ReLU's outcome in its
+  // lowest bit, written by the forward apply) instead of the 4-byte conv output -- 2 bytes per element more in one forward pass, 2
+  // fewer in each of the two backward passes, and the gate stays exact.  MN_BN_REC=0: round 5's form (fp32 conv output re-read, gate
+  // recomputed), for same-box A/Bs.
+  bool use_rec = false;
   // MN_DTYPE_F16X2Q (round 5; Plan<float> only): fp16x2m whose FORWARD convolutions take both cross terms of a split-operand product
   // from fp8 copies on the block-scaled MFMA (common.h MMA_H2Q, h2q tensors): 2 instead of 3 MFMA-equivalents per forward product,
   // poses ~3e-4 from the fp32 reference instead of 1.6e-5 (bar 1e-3)
@@ -532,6 +544,7 @@ struct Plan : PlanBase {
     mixed = DT == MN_F32 && (c.dtype == MN_DTYPE_F16X2M || q8);
     h2 = DT == MN_F32 && (c.dtype == MN_DTYPE_F16X2 || mixed);
     stem_f16 = mixed && !deterministic && !(getenv("MN_STEM_BWD") && atoi(getenv("MN_STEM_BWD")) == 0);
+    use_rec = mixed && !(getenv("MN_BN_REC") && atoi(getenv("MN_BN_REC")) == 0);
     if (c.dtype == MN_DTYPE_F32X3 || h2) {  // (fp16x2m: the stem's backward and its fp32 tensors)
       mma_fwd = MMA_F16X3;
       mma_bwd = MMA_BF16X3;
@@ -760,7 +773,8 @@ struct Plan : PlanBase {
     if (h2) {  // fp32 conv output in, h2 activation out (residual: an h2 activation)
       const long ni = u.M * u.cp.cout / 8;
       hipLaunchKernelGGL(bn_apply_h2_kernel, dim3(ew_grid(ni)), dim3(256), 0, s, (const float*)u.y, (const float*)u.coef_f,
-                         (const half*)res, (half*)out, ni, u.cp.cout, relu, q8 ? 1 : 0);
+                         (const half*)res, (half*)out, ni, u.cp.cout, relu, q8 ? 1 : 0,
+                         cur_training ? u.rec : (half*)nullptr, (const float*)u.mean, (const float*)u.invstd);
       return;
     }
     hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(np)), dim3(256), 0, s, (const T*)u.y, (const float*)u.coef_f, res, out,
@@ -781,20 +795,14 @@ struct Plan : PlanBase {
       launch_zero_fill(reinterpret_cast<float*>(acc_region), (long)(acc_bytes / 4), s);
       sqnorm_clean = true;
     }
+    // (fp16x2m: the stem's fp16 backward kernels read an fp16 image of the input -- written by the same launch)
+    half* const x16 = stem_bwd_f16() && training ? xpad16 : (half*)nullptr;
     if (input_u8)
       hipLaunchKernelGGL((u8nhwc_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
-                         (const unsigned char*)images, xpad, B, H, W, Hp, Wp, input_norm);
+                         (const unsigned char*)images, xpad, B, H, W, Hp, Wp, input_norm, x16);
     else
       hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<T>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
-                         (const float*)images, xpad, B, H, W, Hp, Wp);
-    if (stem_bwd_f16() && training) {  // fp16x2m: the stem's backward kernels read an fp16 image of the input
-      if (input_u8)
-        hipLaunchKernelGGL((u8nhwc_to_padded_nhwc4_kernel<half>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
-                           (const unsigned char*)images, xpad16, B, H, W, Hp, Wp, input_norm);
-      else
-        hipLaunchKernelGGL((nchw_to_padded_nhwc4_kernel<half>), dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, s,
-                           (const float*)images, xpad16, B, H, W, Hp, Wp);
-    }
+                         (const float*)images, xpad, B, H, W, Hp, Wp, x16);
     // forked AFTER the (HBM-bound) input conversion, so that the side stream's copies run beside the stem's MFMA-bound
     // convolution instead of competing with the conversion for bandwidth (step time: equal within noise)
     if (dirty || zero_grads) {
@@ -896,7 +904,12 @@ struct Plan : PlanBase {
       stage_error = "bn_bwd: the fp16x2 / fp16x2m modes take block-output gradients as stored (already gated); only self_gate exists";
       return;  // (reported by backward_stage: this call site has no status to return)
     }
-    if (mixed && &u != &stem) {  // fp16 gradient, fp32 conv output in; plain fp16 d(conv output) out
+    if (mixed && &u != &stem && u.rec) {  // fp16 gradient and the forward pass's record in; plain fp16 d(conv output) out
+      launch_bn_bwd_rec((const half*)g, (const half*)u.rec, u.M, u.cp.cout, params + u.bp.gamma, u.mean, u.invstd, grads + u.bp.gamma,
+                        grads + u.bp.beta, (half*)u.gy, u.accum_b, u.coef_b, 1.f / cur_scale, s, self_gate, u.rows_b);
+      return;
+    }
+    if (mixed && &u != &stem) {  // (MN_BN_REC=0) fp16 gradient, fp32 conv output in; plain fp16 d(conv output) out
       launch_bn_bwd<half, float>((const half*)g, (const half*)nullptr, (const float*)u.y, u.M, u.cp.cout, params + u.bp.gamma, u.mean,
                                  u.invstd, grads + u.bp.gamma, grads + u.bp.beta, (half*)u.gy, u.accum_b, u.coef_b, 1.f / cur_scale, s,
                                  self_gate ? params + u.bp.beta : nullptr, PoolGradSrc(), u.rows_b);
@@ -1000,6 +1013,7 @@ struct Plan : PlanBase {
     if (wgrad_sched == 2) {
       flush_wgrads(s);
       bn_bwd(blk.u2, blk.gout, og, s);
+      if (!stage_error.empty()) return;
       conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
       pending_wgrads.push_back({&blk.u2, ba1});
       flush_wgrads(s);
@@ -1016,6 +1030,7 @@ struct Plan : PlanBase {
       return;
     }
     bn_bwd(blk.u2, blk.gout, og, s);
+    if (!stage_error.empty()) return;  // (round-5 ADVICE: do not run data / weight gradients on a d(conv output) that was never written)
     const bool early = wgrad_sched == 1;
     if (early) conv_wgrad(blk.u2, ba1, fork_wgrad(s));
     conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
@@ -1132,9 +1147,10 @@ struct Plan : PlanBase {
     if (stage < 0 || stage > 3) return fail("backward_stage: stage must be 0..3");
     if (!cur_targets) return fail("backward_stage: call mn_train_forward_loss first");
     if (stage == 3) head_backward(s);
-    for (int i = (int)blocks.size() - 1; i >= 0; --i)
+    // (a launch helper that refuses its arguments -- bn_bwd -- records stage_error: nothing that depends on its output is launched)
+    for (int i = (int)blocks.size() - 1; i >= 0 && stage_error.empty(); --i)
       if (blocks[i].stage == stage) block_backward(blocks[i], s);
-    if (stage == 0) {
+    if (stage == 0 && stage_error.empty()) {
       flush_wgrads(s);  // beside the stem's BatchNorm backward
       stem_backward(s);
     }
@@ -1148,6 +1164,7 @@ struct Plan : PlanBase {
     return check_launch("backward_stage");
   }
 
+  float* grad_arena() override { return grads; }
   // ---- inspection (mn_debug_tensor): activations / gradients of the last step by name ---------------------------
   int debug_tensor(const char* name, void** ptr, int64_t* numel, int32_t* dtype) override {
     const std::string n(name);
@@ -1450,6 +1467,22 @@ extern "C" int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t*
   *offset = P.L.stage_begin[stage];
   *count = P.L.stage_end[stage] - P.L.stage_begin[stage];
   return 0;
+}
+extern "C" int mn_grad_bucket_pack_bf16(mn_handle* h, int stage, void* out_bf16, void* stream) {
+  MN_H(h);
+  if (stage < 0 || stage > 3 || !out_bf16) return fail("mn_grad_bucket_pack_bf16: stage 0..3 and an output buffer are required");
+  const long off = P.L.stage_begin[stage], n = P.L.stage_end[stage] - off;
+  hipLaunchKernelGGL(grad_pack_bf16_kernel, dim3(grad_transport_grid(n)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)(P.grad_arena() + off), (__bf16*)out_bf16, n);
+  return check_launch("grad_bucket_pack_bf16");
+}
+extern "C" int mn_grad_bucket_unpack_bf16(mn_handle* h, int stage, const void* in_bf16, void* stream) {
+  MN_H(h);
+  if (stage < 0 || stage > 3 || !in_bf16) return fail("mn_grad_bucket_unpack_bf16: stage 0..3 and an input buffer are required");
+  const long off = P.L.stage_begin[stage], n = P.L.stage_end[stage] - off;
+  hipLaunchKernelGGL(grad_unpack_bf16_kernel, dim3(grad_transport_grid(n)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)in_bf16,
+                     P.grad_arena() + off, n);
+  return check_launch("grad_bucket_unpack_bf16");
 }
 extern "C" int mn_optim_step(mn_handle* h, float grad_mul, void* stream) {
   MN_H(h);

@@ -71,6 +71,22 @@ inline void launch_zero_fill(float* p, long n, hipStream_t s) {  // p 16-byte al
   hipLaunchKernelGGL(zero_fill_kernel, dim3((int)blocks), dim3(256), 0, s, reinterpret_cast<floatx4*>(p), n4, p + n4 * 4, (int)(n - n4 * 4));
 }
 
+// Data-parallel gradient transport in bf16 (geomapnet_amd/dp.py, MN_DP_GRAD_DTYPE=bf16): a bucket of the fp32 gradient arena is
+// rounded to bf16 for the all-reduce (half the bytes on xGMI, half the time RCCL's workgroups sit on the CUs) and widened back in
+// place.  bf16, not fp16: weight gradients are sums over up to a million pixels and reach O(100) at random init -- times the loss
+// scale they leave fp16's range (measured: 144 NaNs in the stem + layer1 bucket of the first 2-rank test), and their small entries
+// would underflow without it; bf16 has fp32's exponent range, so there is no scale to carry, at 8 bits of mantissa per rank.
+static __global__ void __launch_bounds__(256) grad_pack_bf16_kernel(const float* __restrict__ g, __bf16* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (__bf16)g[i];
+}
+static __global__ void __launch_bounds__(256) grad_unpack_bf16_kernel(const __bf16* __restrict__ in, float* __restrict__ g, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] = (float)in[i];
+}
+inline int grad_transport_grid(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
 struct AdamArgs {
   float* p;
   const float* g;

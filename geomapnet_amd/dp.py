@@ -32,6 +32,12 @@ from .engine import _stream
 #   c workgroups of `threads` threads resident for the time a ring all-reduce of the bucket over 8 GPUs would take at `busbw`
 #   (default 200 GB/s bus bandwidth + 40 us latency), streaming the bucket's reduce traffic through HBM meanwhile; lds_kb (0, 32,
 #   64): LDS each stand-in workgroup holds -- with tens of KB a CU cannot host a 150 KB convolution workgroup beside it.
+# MN_DP_GRAD_DTYPE=fp32|bf16|auto (default fp32): element type the buckets travel in.  bf16 (auto = bf16 for the plain fp16 mode, fp32
+#   otherwise): the library rounds a bucket to bf16 (mn_grad_bucket_pack_bf16), the all-reduce runs on the 2-byte values, and
+#   mn_grad_bucket_unpack_bf16 widens them back in place before the optimiser -- half the bytes on xGMI and half the time the
+#   collective's workgroups share the CUs.  Costs one rounding of every rank's gradient to 8 bits and bf16 partial sums inside the
+#   ring: far below the fp16 mode's own gradient deviation (16 %), far ABOVE fp16x2m's backward rounding budget (8e-4), which is why
+#   the parity mode keeps fp32 transport unless asked.  (fp16 is not an option: weight gradients times the loss scale overflow it.)
 RING_WORLD = 8  # the world the stand-in's duration model assumes
 
 
@@ -46,6 +52,15 @@ def _standin():
     f = v.split(",")
     return {"c": int(f[0]), "threads": int(f[1]) if len(f) > 1 else 256, "busbw": float(f[2]) if len(f) > 2 else 200.0,
             "lat_us": float(f[3]) if len(f) > 3 else 40.0, "lds_kb": int(f[4]) if len(f) > 4 else 0}
+
+
+def _grad_transport(plan):
+    v = os.environ.get("MN_DP_GRAD_DTYPE", "fp32")
+    if v == "auto":
+        v = "bf16" if plan.get("dtype") == "fp16" else "fp32"
+    if v not in ("fp32", "bf16"):
+        raise ValueError("MN_DP_GRAD_DTYPE must be fp32, bf16 or auto")
+    return v
 
 
 def ring_allreduce_us(nbytes, world=RING_WORLD, busbw_GBps=200.0, lat_us=40.0):
@@ -149,9 +164,9 @@ def _standin_launch(engine, lib, bucket, cfg):
     if st is None:
         st = _standin_state[dev] = {"stream": torch.cuda.Stream(device=dev), "src": None, "dst": None}
     nbytes = bucket.numel() * bucket.element_size()
-    if st["src"] is None or st["src"].numel() < bucket.numel():
-        st["src"] = torch.zeros(bucket.numel(), dtype=bucket.dtype, device=dev)
-        st["dst"] = torch.zeros(bucket.numel(), dtype=bucket.dtype, device=dev)
+    if st["src"] is None or st["src"].numel() < nbytes:  # (scratch: the stand-in must not touch the gradients)
+        st["src"] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        st["dst"] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     us = ring_allreduce_us(nbytes, RING_WORLD, cfg["busbw"], cfg["lat_us"])
     comm = st["stream"]
     comm.wait_stream(torch.cuda.current_stream(dev))
@@ -179,8 +194,18 @@ def _staged_step(engine, plan, images, targets, lib, h, s):
         t0.record()
         ready, passed = [], []
 
-    def issue(bucket):
+    half = _grad_transport(plan) == "bf16" and (multi or standin is not None)
+    unpack = []  # stages whose halves must be widened back into the arena once their all-reduce has landed
+
+    def issue(bucket, stage):
         # async: RCCL runs on its own stream, ordered after the kernels enqueued so far
+        if half:
+            bufs = plan.setdefault("dp_bf16", {})
+            if stage not in bufs:
+                bufs[stage] = torch.empty(bucket.numel(), dtype=torch.bfloat16, device=bucket.device)
+            lib.check(lib.grad_bucket_pack_bf16(h, stage, ptr(bufs[stage]), s))
+            bucket = bufs[stage]
+            unpack.append(stage)
         if multi:
             works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
         elif standin is not None:
@@ -196,11 +221,11 @@ def _staged_step(engine, plan, images, targets, lib, h, s):
         lib.check(lib.grad_bucket(h, stage, C.byref(off), C.byref(cnt)))
         bucket = grads[off.value: off.value + cnt.value]
         if defer == 2 or (defer == 1 and stage != 3):
-            deferred.append(bucket)  # issued after the last backward stage, in backward order
+            deferred.append((bucket, stage))  # issued after the last backward stage, in backward order
         else:
-            issue(bucket)
-    for bucket in deferred:
-        issue(bucket)
+            issue(bucket, stage)
+    for bucket, stage in deferred:
+        issue(bucket, stage)
     if timed:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
@@ -215,6 +240,8 @@ def _staged_step(engine, plan, images, targets, lib, h, s):
         _profile["pairs"].append(ev)
         if passed:
             _profile["timelines"].append((t0, ready, passed))
+    for stage in unpack:  # (every all-reduce has been waited for on this stream)
+        lib.check(lib.grad_bucket_unpack_bf16(h, stage, ptr(plan["dp_bf16"][stage]), s))
     lib.check(lib.optim_step(h, 1.0 / world_size(), s))
     engine._stepped(plan)
     # reported loss = mean of the rank losses (one scalar all-reduce)

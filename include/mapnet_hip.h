@@ -49,8 +49,11 @@ extern "C" {
  *                 step ARE that mode's, i.e. inside the north-star tolerance -- and a backward pass on the MN_DTYPE_F16 kernels:
  *                 one MFMA per product on single fp16 operands (d(conv output), data gradients and the data-gradient weight copy
  *                 are plain fp16; the weight gradients' X operand and the ReLU gates read plain fp16 copies of the activations
- *                 that the h2 producers write beside the h2 tensor).  Gates and BatchNorm's backward statistics come from the
- *                 exact forward values (fp32 conv outputs), so the gradients differ from MN_DTYPE_F16X2's by operand rounding
+ *                 that the h2 producers write beside the h2 tensor -- round 6: the hi halves of the h2 tensors in place).  Every
+ *                 ReLU gate is the exact outcome of the forward pass and BatchNorm's backward sums are taken in fp64 over the forward
+ *                 pass's xhat rounded once to fp16 (round 6: a 2-byte record written by the forward apply, csrc/elementwise_h2.h
+ *                 rec_pack; round 5 re-read the fp32 conv output; the stem reads an fp16 copy of its conv output unless
+ *                 MN_DETERMINISTIC / MN_STEM_BWD=0), so the gradients differ from MN_DTYPE_F16X2's by operand rounding
  *                 only: 1.1e-3 relative L2 overall (tools/mixed_budget.py), below the 4.9e-3 by which two fp32 evaluations of
  *                 the reference's step differ through ReLU gate flips.  Loss scale + overflow guard as MN_DTYPE_F16.
  * MN_DTYPE_F16X2Q: (round 5, plans only; experimental) MN_DTYPE_F16X2M whose forward convolutions take BOTH cross terms of a
@@ -190,6 +193,12 @@ int mn_train_forward_loss(mn_handle* h, const void* images, const float* targets
 int mn_train_backward_stage(mn_handle* h, int stage, void* stream);
 int mn_grad_bucket(mn_handle* h, int stage, int64_t* offset, int64_t* count); /* range in the grads arena */
 int mn_optim_step(mn_handle* h, float grad_mul, void* stream);
+/* Optional bf16 transport of a bucket: pack = out_bf16[i] = bf16(grads[offset + i]), `count` values (mn_grad_bucket); the host
+ * all-reduces them; unpack = grads[offset + i] = in_bf16[i].  Half the bytes on xGMI and half the time the collective's workgroups
+ * share the CUs with the backward convolutions, at 8 bits of mantissa per rank's contribution (bf16 because weight gradients span
+ * fp32's range: times the loss scale they overflow fp16).  geomapnet_amd/dp.py, MN_DP_GRAD_DTYPE=bf16. */
+int mn_grad_bucket_pack_bf16(mn_handle* h, int stage, void* out_bf16, void* stream);
+int mn_grad_bucket_unpack_bf16(mn_handle* h, int stage, const void* in_bf16, void* stream);
 
 /* fp16 loss scaling.  The reference trains in fp32 (common/train.py:351-359) and cannot overflow; the fp16 plan scales
  * d(pred) by `scale` (mn_config.loss_scale initially) and divides it out where gradients enter the fp32 arena.  A step

@@ -738,7 +738,7 @@ def _record_deviation(rec):
 
 def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps=1, max_grad_norm=0.0, lr=1e-4, wd=5e-4,
                      loss_rtol=1e-4, pose_atol=1e-3, grad_l2_rtol=2e-2, gps=False, filter_nans=False, adam_eps=None,
-                     pose_abs=None):
+                     pose_abs=None, later_tol=None):
     """one (or more) full training steps, HIP library vs the oracle on identical inputs and weights.
     adam_eps: Adam's epsilon for both sides.  With the default 1e-8 the update m/(sqrt(v)+eps) is +-1 for every element
     however small its gradient, so last-bit differences of near-zero gradients move parameters by a full lr and later
@@ -782,7 +782,9 @@ def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps
                            "loss_rel": abs(l - lo) / max(1.0, abs(lo)), "pose_abs_max": pose_err, "dev": str(dev)})
         # steps after the first start from Adam's sign-like first update (m/sqrt(v) = +-1 for every element,
         # however small its gradient), which amplifies summation-order noise: compared loosely
-        lt, pt = (loss_rtol, pose_atol) if step == 0 or adam_eps is not None else (max(loss_rtol, 5e-3), max(pose_atol, 2e-2))
+        # (later_tol: (loss, pose) for the steps after the first when a mode's measured second-step deviation is known -- fp16)
+        lt, pt = (loss_rtol, pose_atol) if step == 0 or adam_eps is not None else (
+            later_tol if later_tol is not None else (max(loss_rtol, 5e-3), max(pose_atol, 2e-2)))
         assert abs(l - lo) <= lt * max(1.0, abs(lo)), (step, l, lo)
         assert pose_err <= pt * max(1.0, po.abs().max().item()), (step, pose_err)
         # the north-star bar as written -- max abs over all predicted components, not relative to the pose scale -- for the first
@@ -813,7 +815,9 @@ def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps
             names = ("sax", "saq", "srx", "srq")
             for i, nm in enumerate(names):
                 if hasattr(oc, nm) and getattr(oc, nm).grad is not None:
-                    assert abs(cg[i] - getattr(oc, nm).grad.item()) <= 1e-3 * max(1.0, abs(getattr(oc, nm).grad.item()))
+                    # d loss / d s = 1 - e^-s * (its mean term): as far off as the loss itself in a mode whose loss gate is loose (fp16)
+                    ref = getattr(oc, nm).grad.item()
+                    assert abs(cg[i] - ref) <= max(1e-3 * max(1.0, abs(ref)), loss_rtol * max(1.0, abs(lo))), (nm, cg[i], ref)
     if adam_eps is not None:
         # total displacement of the parameters over all steps: the optimiser-state dynamics (moments carried from step to
         # step, bias corrections, weight decay) seen directly, not through the next loss
@@ -926,7 +930,10 @@ def check_eval_forward(lib, dev, dtype_name, B=3, H=64, W=85, atol=1e-3):
     with torch.no_grad():
         ref = onet(x)
     out = net(x.to(dev))
-    assert (out.cpu() - ref).abs().max().item() <= atol * max(1.0, ref.abs().max().item())
+    err = (out.cpu() - ref).abs().max().item()
+    _record_deviation({"check": "eval_forward", "dtype": dtype_name, "B": B, "H": H, "W": W, "pose_abs_max": err,
+                       "scale": ref.abs().max().item(), "dev": str(dev)})
+    assert err <= atol * max(1.0, ref.abs().max().item())
 
 
 def check_eval_flow(lib, dev, dtype_name, L=4, T=3, H=64, W=85, rtol=2e-3, check_q=True):
@@ -960,6 +967,9 @@ def check_eval_flow(lib, dev, dtype_name, L=4, T=3, H=64, W=85, rtol=2e-3, check
     # check_q=False: with random-init weights and eval-mode BatchNorm the predicted log-quaternions are hundreds
     # of radians, so the wrapped rotation error is chaotic in the last bits of the pose (fp16 runs)
     k = 4 if check_q else 2
+    _record_deviation({"check": "eval_flow", "dtype": dtype_name, "L": L, "H": H, "W": W, "dev": str(dev),
+                       "max_abs_diff": float(np.max(np.abs(np.asarray(got[:k]) - np.asarray(want[:k])))),
+                       "max_rel_diff": float(np.max(np.abs(np.asarray(got[:k]) - np.asarray(want[:k])) / (np.abs(np.asarray(want[:k])) + 1e-12)))})
     np.testing.assert_allclose(got[:k], want[:k], rtol=rtol, atol=rtol)
     return summary
 
@@ -1512,6 +1522,22 @@ def check_deterministic(lib, dev, dtype_name, N=2, H=40, W=53, steps=3, max_grad
 # build keeps in fp16 are rounded (profiles/r02/fp16_budget_cpu.txt: pose 1.29e-2 max; profiles/r03/
 # fp16_budget_backward_cpu.txt: gradients), and the largest values measured on MI355X over the three BASELINE shapes
 # (profiles/r02/parity_full_size.jsonl: loss 7.9e-4, pose 1.44e-2, gradients 0.158 overall / 0.389 worst tensor), x 1.5.
+# The fp16 mode at the SMALL shapes of the suite (round 6): 1.5x what the mode measures on MI355X at each
+# shape (profiles/r06/c3_fp16_deviation_at_the_suite_shapes.txt) -- a 3x regression of the fast mode used to pass the 1e-2 / 3e-2 /
+# unchecked-gradient gates.  key = (N, H, W): first-step loss (relative), pose (max abs), worst-tensor gradient (relative L2), and the
+# second step's (loss, pose) where two steps are taken (Adam's sign-like first update amplifies the first step's deviation ~30x).
+FP16_SMALL = {
+    (2, 64, 85): {"loss": 1.5 * 7.74e-4, "pose": 1.5 * 2.04e-2, "grad": 1.5 * 0.340, "later": (1.5 * 5.53e-3, 1.5 * 0.214)},
+    (2, 256, 341): {"loss": 1.5 * 6.88e-4, "pose": 1.5 * 9.55e-3, "grad": 1.5 * 0.355, "later": None},
+}
+
+
+def fp16_small_gates(N, H, W):
+    """keyword arguments of check_train_step for the fp16 mode at a suite shape"""
+    e = FP16_SMALL[(N, H, W)]
+    return {"loss_rtol": e["loss"], "pose_atol": e["pose"], "grad_l2_rtol": e["grad"], "later_tol": e["later"]}
+
+
 FP16_ENVELOPE = {"loss_rel": 1.2e-3, "pose_abs_max": 2.2e-2, "grad_l2_rel_all": 0.25, "grad_l2_rel_worst_tensor": 0.6}
 
 

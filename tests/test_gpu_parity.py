@@ -178,8 +178,8 @@ def test_mapnet_train_step_under_every_weight_gradient_schedule(lib, monkeypatch
     if dtype in ("fp16x2", "fp16x2m"):
         checks.check_train_step(lib, DEV, dtype, mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
     else:
-        checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=2e-2, pose_atol=5e-2,
-                                grad_l2_rtol=None)
+        # (fp16: 1.5x what the mode measures at this shape, gradients included -- checks.FP16_SMALL)
+        checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=64, W=85, steps=2, **checks.fp16_small_gates(2, 64, 85))
 
 
 def test_mapnet_train_step_fp32_parity_full_resolution(lib):
@@ -311,10 +311,10 @@ def test_mapnet_gps_train_step_fp32(lib):
 
 def test_mapnet_train_step_fp16_close(lib):
     """fp16 build, two windows (6 images) at full resolution: BatchNorm statistics over so few samples make the storage
-    rounding weigh more than at 64 windows (FP16_ENVELOPE).  Measured on MI355X (profiles/r03/c17_fp16_step_small_batches.txt):
-    loss 8.6e-4 relative, pose 9.8e-3 max abs; N=4: 3.3e-3 / 1.05e-2 -- asserted at ~3x the larger of the two."""
-    checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-2, pose_atol=3e-2,
-                            grad_l2_rtol=None)
+    rounding weigh more than at 64 windows (FP16_ENVELOPE).  Held to 1.5x what the mode measures on MI355X at this shape
+    (checks.FP16_SMALL, profiles/r06/c3_fp16_deviation_at_the_suite_shapes.txt: loss 6.9e-4 relative, pose 9.6e-3 max abs, worst-tensor
+    gradient 0.355) -- until round 6 the gates were 1e-2 / 3e-2 and no gradient check, i.e. a 3x regression passed."""
+    checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=256, W=341, steps=1, **checks.fp16_small_gates(2, 256, 341))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])

@@ -2,7 +2,7 @@
 # serial kernel stats of one dtype mode (every kernel alone on the device): DT=fp16x2 TAG=c5 bash tools/prof_mode.sh
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; DT=${DT:-fp16x2}; O=$R/gpurun_out/${TAG:-cur}; mkdir -p $O; export TMPDIR=/tmp
-cd /tmp && MN_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_m -o r -- python $R/bench.py --dtype $DT --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --no-events --no-parity-mode --no-eval-metric > $O/rocprof_$DT.log 2>&1
+cd /tmp && MN_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_m -o r -- python $R/bench.py --dtype $DT --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --no-events --no-fast-mode --no-eval-metric --no-feed > $O/rocprof_$DT.log 2>&1
 cp /tmp/prof_m/r_kernel_stats.csv $O/kernel_stats_serial_$DT.csv
 python3 - <<PY
 import csv, collections

@@ -304,6 +304,7 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")  # (main() explains; the ranks inherit it before their runtimes load)
     return subprocess.call(cmd, env=env)
 
 
@@ -456,10 +457,20 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
 
     rccl = None
-    if world > 1 and not args.emu:  # the RCCL channel budget of the data-parallel step, before the runtime reads the environment
+    if world > 1 and not args.emu:
+        # Before torch (and with it the HIP runtime and RCCL) is imported.  (1) The RCCL channel budget of the data-parallel step
+        # (geomapnet_amd/dp.py rccl_env: the same defaults; profiles/r06/rccl_rehearsal.txt).  (2) GPU_MAX_HW_QUEUES: HIP multiplexes a
+        # process's streams onto 4 hardware queues by default and two streams on one queue run in order; a data-parallel rank has FIVE
+        # (null stream, step stream, weight-gradient side stream, RCCL's stream, the input feed's copy stream), so without this the
+        # collective may share a queue with the compute it is meant to overlap (profiles/r06/c1_fourth_model_root_cause.txt is what
+        # that costs between the step and its side stream: 7-11 %).  Measured harmless on one GPU (20.04 vs 20.00 ms).
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        from geomapnet_amd import dp as _dp
-        rccl = _dp.rccl_env()
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        rccl = {}
+        for k, v in (("NCCL_MIN_NCHANNELS", "4"), ("NCCL_MAX_NCHANNELS", "8")):
+            os.environ.setdefault(k, v)
+            rccl[k] = os.environ[k]
+        rccl["GPU_MAX_HW_QUEUES"] = os.environ["GPU_MAX_HW_QUEUES"]
     import torch
     import torch.distributed as dist
     binding = None

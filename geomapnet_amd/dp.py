@@ -74,6 +74,8 @@ def rccl_env(defaults=None):
     of the chip -- each channel beyond the 20-odd CUs those launches leave idle pushes a convolution tile into a second round
     (the stand-in rehearsal, profiles/r06/rccl_rehearsal.txt).  The buckets are 0.9-57 MB under >= 2 ms of backward each: they
     need residency discipline, not peak bus bandwidth."""
+    # (GPU_MAX_HW_QUEUES is read when the HIP runtime loads, i.e. at `import torch`: a launcher has to export it -- bench.py does; two
+    #  streams that share one of HIP's 4 default hardware queues run in order, and a data-parallel rank has five streams)
     env = {"NCCL_MIN_NCHANNELS": "4", "NCCL_MAX_NCHANNELS": "8"}
     if defaults:
         env.update(defaults)

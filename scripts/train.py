@@ -25,6 +25,13 @@ import sys
 ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # one rank of a data-parallel job (torch.distributed.run): before torch loads the HIP runtime.  HIP multiplexes a process's
+    # streams onto 4 hardware queues by default and streams that share a queue run in order; a rank has five (null, step,
+    # weight-gradient side stream, RCCL, the input feed's copy stream): give the collective a queue of its own (bench.py)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("NCCL_MIN_NCHANNELS", "4")
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
 
 
 def build_parser():

@@ -738,7 +738,7 @@ def _record_deviation(rec):
 
 def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps=1, max_grad_norm=0.0, lr=1e-4, wd=5e-4,
                      loss_rtol=1e-4, pose_atol=1e-3, grad_l2_rtol=2e-2, gps=False, filter_nans=False, adam_eps=None,
-                     pose_abs=None, later_tol=None):
+                     pose_abs=None, later_tol=None, crit_grad_rtol=1e-3):
     """one (or more) full training steps, HIP library vs the oracle on identical inputs and weights.
     adam_eps: Adam's epsilon for both sides.  With the default 1e-8 the update m/(sqrt(v)+eps) is +-1 for every element
     however small its gradient, so last-bit differences of near-zero gradients move parameters by a full lr and later
@@ -815,9 +815,12 @@ def check_train_step(lib, dev, dtype_name, mode="mapnet", N=2, H=64, W=85, steps
             names = ("sax", "saq", "srx", "srq")
             for i, nm in enumerate(names):
                 if hasattr(oc, nm) and getattr(oc, nm).grad is not None:
-                    # d loss / d s = 1 - e^-s * (its mean term): as far off as the loss itself in a mode whose loss gate is loose (fp16)
+                    # d loss / d s = 1 - e^-s * (its mean term): e^-s = 20 at s = -3 amplifies the mean term's deviation (fp16 measures
+                    # 4.0e-3 / 2.3e-3 relative at the suite's two shapes: FP16_SMALL)
                     ref = getattr(oc, nm).grad.item()
-                    assert abs(cg[i] - ref) <= max(1e-3 * max(1.0, abs(ref)), loss_rtol * max(1.0, abs(lo))), (nm, cg[i], ref)
+                    _record_deviation({"dtype": dtype_name, "mode": mode, "N": N, "H": H, "W": W, "crit_grad": nm,
+                                       "rel": abs(cg[i] - ref) / max(1.0, abs(ref)), "dev": str(dev)})
+                    assert abs(cg[i] - ref) <= crit_grad_rtol * max(1.0, abs(ref)), (nm, cg[i], ref)
     if adam_eps is not None:
         # total displacement of the parameters over all steps: the optimiser-state dynamics (moments carried from step to
         # step, bias corrections, weight decay) seen directly, not through the next loss
@@ -1527,15 +1530,17 @@ def check_deterministic(lib, dev, dtype_name, N=2, H=40, W=53, steps=3, max_grad
 # unchecked-gradient gates.  key = (N, H, W): first-step loss (relative), pose (max abs), worst-tensor gradient (relative L2), and the
 # second step's (loss, pose) where two steps are taken (Adam's sign-like first update amplifies the first step's deviation ~30x).
 FP16_SMALL = {
-    (2, 64, 85): {"loss": 1.5 * 7.74e-4, "pose": 1.5 * 2.04e-2, "grad": 1.5 * 0.340, "later": (1.5 * 5.53e-3, 1.5 * 0.214)},
-    (2, 256, 341): {"loss": 1.5 * 6.88e-4, "pose": 1.5 * 9.55e-3, "grad": 1.5 * 0.355, "later": None},
+    (2, 64, 85): {"loss": 1.5 * 7.74e-4, "pose": 1.5 * 2.04e-2, "grad": 1.5 * 0.340, "later": (1.5 * 5.53e-3, 1.5 * 0.214),
+                  "crit": 1.5 * 4.0e-3},
+    (2, 256, 341): {"loss": 1.5 * 6.88e-4, "pose": 1.5 * 9.55e-3, "grad": 1.5 * 0.355, "later": None, "crit": 1.5 * 2.3e-3},
 }
 
 
 def fp16_small_gates(N, H, W):
     """keyword arguments of check_train_step for the fp16 mode at a suite shape"""
     e = FP16_SMALL[(N, H, W)]
-    return {"loss_rtol": e["loss"], "pose_atol": e["pose"], "grad_l2_rtol": e["grad"], "later_tol": e["later"]}
+    return {"loss_rtol": e["loss"], "pose_atol": e["pose"], "grad_l2_rtol": e["grad"], "later_tol": e["later"],
+            "crit_grad_rtol": e["crit"]}
 
 
 FP16_ENVELOPE = {"loss_rel": 1.2e-3, "pose_abs_max": 2.2e-2, "grad_l2_rel_all": 0.25, "grad_l2_rel_worst_tensor": 0.6}

@@ -438,7 +438,7 @@ def test_mapnet_staged_step_fp32_parity_with_rccl(lib, monkeypatch):
 def test_eval_forward_parity(lib):
     checks.check_eval_forward(lib, DEV, "fp32", B=3, H=128, W=171)
     checks.check_eval_forward(lib, DEV, "fp16x2m", B=3, H=128, W=171)  # (the scripts' default dtype: the split-operand forward pass)
-    checks.check_eval_forward(lib, DEV, "fp16", B=3, H=128, W=171, atol=3e-2)
+    checks.check_eval_forward(lib, DEV, "fp16", B=3, H=128, W=171, atol=2.5e-3)  # (1.5x the measured 1.66e-3 of the pose scale; was 3e-2)
 
 
 def test_checkpoint_interop_and_resume(lib):
@@ -469,7 +469,7 @@ def test_staged_step_with_stand_in_collectives_and_deferred_buckets_computes_the
 def test_eval_flow_and_metric(lib):
     """scripts/eval.py flow on synthetic windows: median / mean translation and rotation error"""
     checks.check_eval_flow(lib, DEV, "fp32", L=8, T=3, H=128, W=171)
-    checks.check_eval_flow(lib, DEV, "fp16", L=8, T=3, H=128, W=171, rtol=3e-2, check_q=False)
+    checks.check_eval_flow(lib, DEV, "fp16", L=8, T=3, H=128, W=171, rtol=4.6e-3, check_q=False)  # (1.5x the measured 3.05e-3; was 3e-2)
 
 
 # ---- BASELINE full size: size-independent properties -----------------------------------------------------

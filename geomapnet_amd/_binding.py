@@ -78,6 +78,7 @@ _PROTOS = {
     "mn_op_wgrad_ws": (c_i, [c_i, C.POINTER(GatherGeom), c_void, c_i, c_void, c_void, c_i, c_f, c_void, c_i64, c_void, c_void]),
     "mn_op_conv_halo_pp": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_i, c_i, c_void, c_void, c_void, c_f,
                                  c_i, c_void]),
+    "mn_op_conv_halo_h2": (c_i, [C.POINTER(GatherGeom), c_void, c_void, c_void, c_i, c_void, c_i, c_void]),
     "mn_op_conv_dgrad": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_void, c_void, c_void, c_void, c_void, c_void, c_i,
                                c_void, c_void]),
     "mn_op_stem_conv": (c_i, [c_void, c_void, c_void, c_void, c_i, c_i, c_i, c_i, c_i, c_void]),

@@ -1034,8 +1034,20 @@ inline int launch_igemm(const GatherGeom& g_in, const T* A, const T* Bw, const E
 // channels.  128x128 / 128x64 tiles of four waves, two workgroups per CU (3x3 stride-1 shapes go to igemm_halo.h).
 inline int launch_igemm_halo_h2(const GatherGeom& g2, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream);
 // q: A and Bw are h2q tensors (common.h), the cross terms run on the scaled fp8 MFMA (MMA_H2Q)
+// (halo_h2.h, round 6: layer1's 64 -> 64 h2 convolutions with the weights in registers)
+inline bool conv_halo_h2_applies(const GatherGeom& g, const Epilogue& ep);
+inline int conv_halo_h2_grid(const GatherGeom& g);
+inline void launch_conv_halo_h2(const GatherGeom& g, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream);
+inline bool use_conv_halo_h2() {  // MN_HALO_H2=0: the chunk-resident 64-column shape of igemm_halo.h (A/B measurements)
+  static const bool on = !(getenv("MN_HALO_H2") && atoi(getenv("MN_HALO_H2")) == 0);
+  return on;
+}
 inline int launch_igemm_h2(const GatherGeom& g_in, const half* A, const half* Bw, const Epilogue& ep, hipStream_t stream,
                            const half* zero_page, bool q = false) {
+  if (!q && use_conv_halo_h2() && conv_halo_h2_applies(g_in, ep)) {
+    launch_conv_halo_h2(g_in, A, Bw, ep, stream);
+    return conv_halo_h2_grid(g_in);
+  }
   GatherGeom g = g_in;
   g.C = 2 * g_in.C;
   g.K = 2 * g_in.K;
@@ -1070,3 +1082,4 @@ inline int launch_igemm_h2(const GatherGeom& g_in, const half* A, const half* Bw
 }  // namespace mn
 
 #include "igemm_halo.h"
+#include "halo_h2.h"

@@ -391,6 +391,11 @@ struct Plan : PlanBase {
         u.rows_f = u.gf.B * cdiv(u.gf.P, kHaloTH) * cdiv(u.gf.Q, kHaloTW);
       else
         u.rows_f = cdiv((int)u.M, 128);
+      // (layer1's h2 convolutions on the persistent register-resident-weight kernel, halo_h2.h: one row per workgroup)
+      if (h2 && !q8 && !is_stem && use_conv_halo_h2() && u.cp.k == 3 && u.cp.stride == 1 && u.cp.cin == 64 && u.cp.cout == 64) {
+        const int wgs = conv_halo_h2_grid(u.gf);
+        if (u.rows_f < wgs) u.rows_f = wgs;
+      }
       u.rows_b = 1024;  // >= the workgroups of a backward reduction (launch_bn_bwd: ~512)
     };
     set_rows(stem, true);
@@ -550,7 +555,9 @@ struct Plan : PlanBase {
       mma_bwd = MMA_BF16X3;
     }
     overflow_guard = (DT == MN_F16 || h2) && !(getenv("MN_OVERFLOW_GUARD") && atoi(getenv("MN_OVERFLOW_GUARD")) == 0);
-    if (!getenv("MN_WGRAD_SCHED") && early_fork) wgrad_sched = mixed ? 0 : h2 ? 1 : (DT == MN_F16 ? 0 : 2);  // (see wgrad_sched)
+    // (fp16x2m: 0 / 1 / 2 measured equal in round 5; with round 6's shorter BatchNorm-backward passes 1 leads by 0.3 %: 18.96 / 19.02 /
+    //  19.15 ms for 1 / 0 / 2, two interleaved repeats, profiles/r06/c6_*)
+    if (!getenv("MN_WGRAD_SCHED") && early_fork) wgrad_sched = (mixed || h2) ? 1 : (DT == MN_F16 ? 0 : 2);  // (see wgrad_sched)
     L = Layout(c.feat_dim);
     frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
     B = c.windows * frames;

@@ -103,6 +103,20 @@ extern "C" int mn_op_conv_halo_pp(const mn_gather_geom* gg, const void* A, const
 static int op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
                     const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, float* ws, long ws_floats,
                     void* stream);
+extern "C" int mn_op_conv_halo_h2(const mn_gather_geom* gg, const void* A, const void* Bw, float* out, int ldc, double* stats_accum,
+                                  int stats_rows, void* stream) {
+  begin_call();
+  GatherGeom g = to_geom(gg);
+  if (int e = check_geom(g, MN_DTYPE_F16X2)) return e;
+  Epilogue ep;
+  ep.out = out; ep.ldc = ldc; ep.stats = nullptr; ep.bias = nullptr; ep.relu = 0; ep.res = nullptr; ep.res_gate = nullptr;
+  ep.out_gate = nullptr; ep.alpha = 1.f; ep.stats_accum = stats_accum; ep.stats_rows = stats_rows;
+  if (!conv_halo_h2_applies(g, ep))
+    return fail("conv_halo_h2: 3x3 stride-1 same-size forward convolutions of 64 -> 64 channel h2 tensors only (stats_rows > 0 with stats_accum)");
+  launch_conv_halo_h2(g, (const half*)A, (const half*)Bw, ep, (hipStream_t)stream);
+  return check_launch("conv_halo_h2");
+}
+
 extern "C" int mn_op_wgrad(int dtype, const mn_gather_geom* gg, const void* dY, int ldy, const void* X, float* dW, int ldw,
                            const int32_t* colmap, float alpha, int target_blocks, const void* zero_page, void* stream) {
   return op_wgrad(dtype, gg, dY, ldy, X, dW, ldw, colmap, alpha, target_blocks, zero_page, nullptr, 0, stream);

@@ -272,6 +272,13 @@ int mn_op_wgrad_ws(int dtype, const mn_gather_geom* g, const void* dY, int ldy, 
 int mn_op_conv_halo_pp(const mn_gather_geom* g, const void* A, const void* Bw, void* out, int ldc, double* stats_accum,
                        int stats_rows, int relu, const void* res, const void* res_gate, const void* out_gate, float alpha,
                        int wgs, void* stream);
+/* 3x3 stride-1 same-size FORWARD convolution of 64 -> 64 channel h2 tensors (ResNet layer1 in the fp16x2 / fp16x2m modes) with the
+ * weights held in registers (csrc/halo_h2.h): one persistent 4-wave workgroup per CU, a wave keeps the hi and lo halves of its 32
+ * output channels' weights as MFMA operands for the whole launch and only the input halo of an 8 x 16-pixel tile passes through LDS.
+ * A: h2 activation [B][H][W][64], Bw: h2 weights [64][9*64] (mn_op_igemm's dtype-3 operands), out: fp32 [B][H][W][64];
+ * stats_accum: optional [stats_rows][2][64] fp64 column sums (sum, sum of squares), added to atomically. */
+int mn_op_conv_halo_h2(const mn_gather_geom* g, const void* A, const void* Bw, float* out, int ldc, double* stats_accum,
+                       int stats_rows, void* stream);
 /* Data gradient of a convolution (what autograd computes for conv2d's input, torch 0.4.1 `loss.backward()` under
  * common/train.py:351): gx[B][Hin][Win][Cin] = conv_transpose(gy[B][Hout][Wout][Cout], W) (+ res, res only where
  * res_gate > 0), zeroed where out_gate <= 0.  wd: weights in the data-gradient layout [Cin][k][k][Cout].  stride 1 or 2;

@@ -262,6 +262,32 @@ def check_conv_dgrad_op(lib, dev, dtype, B, H, W, Cin, Cout, k, stride, pad, par
     assert err <= OUT_TOL[dtype] * want.abs().max().item() + 1e-6, err
 
 
+def check_conv_halo_h2(lib, dev, B, H, W, seed=23, stats=True):
+    """csrc/halo_h2.h: the 64 -> 64 channel 3x3 forward convolution of h2 tensors with the weights in registers (layer1 of the fp16x2 /
+    fp16x2m modes) vs torch fp64 on exactly the values the h2 operands stand for: fp32 output to the h2 kernels' tolerance, BatchNorm
+    column sums; ragged tiles (H, W not multiples of 8 / 16) exercise the out-of-image masks and the zero-filled halo"""
+    _fresh()
+    gen = torch.Generator().manual_seed(seed)
+    x = h2_value(torch.randn(B, 64, H, W, generator=gen))
+    w = h2_value(torch.randn(64, 64, 3, 3, generator=gen) * (2.0 / (64 * 9)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), padding=1).permute(0, 2, 3, 1).contiguous()
+    g, Ho, Wo = fwd_geom(B, H, W, 64, 64, 3, 1, 1)
+    xn, wn = to_h2(x.permute(0, 2, 3, 1)).to(dev), to_h2(w.permute(0, 2, 3, 1).reshape(64, 9 * 64)).to(dev)
+    out = torch.full((B, H, W, 64), 7.0, dtype=torch.float32, device=dev)
+    st = torch.zeros(5, 2, 64, device=dev, dtype=torch.double) if stats else None
+    lib.check(lib.op_conv_halo_h2(C.byref(g), K(xn), K(wn), K(out), 64, K(st), 5, None))
+    dev_sync(dev)
+    scale = ref.abs().max().item()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= OUT_TOL[3] * scale + 1e-6, err
+    if st is not None:
+        sums = st.cpu().double().sum(0)
+        r2 = ref.reshape(-1, 64)
+        assert (sums[0] - r2.sum(0)).abs().max().item() <= 1e-4 * scale * r2.shape[0] ** 0.5 + 1e-4
+        assert ((sums[1] - (r2 ** 2).sum(0)).abs() / (r2 ** 2).sum(0)).max().item() <= 1e-4
+    return err / scale
+
+
 def check_conv_halo(lib, dev, B, H, W, Cout=64, dgrad=False, mode="plain", seed=21, pp_wgs=0):
     """fp16 3x3 stride-1 convolution of 64 -> 64 channels from an LDS-resident halo tile, persistent two-group kernel
     (csrc/halo_pp.h) vs torch fp64: forward (with BatchNorm column sums) or data gradient, epilogue variants as

@@ -413,6 +413,7 @@ inline emu_floatx4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_fl
 
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 
 // integer min/max exist as device overloads in HIP
 inline int min(int a, int b) { return a < b ? a : b; }

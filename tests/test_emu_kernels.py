@@ -259,3 +259,9 @@ def test_occupancy_stand_in_streams_its_bytes_and_lasts_its_time(lib):
     assert torch.equal(dst, src + 1.0)
     assert dt >= 0.02, dt
     assert lib.op_occupy(0, 64, C.c_float(1.0), None, None, C.c_int64(0), 0, None) != 0  # argument check
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 11), (1, 16, 32), (3, 7, 19)])
+def test_layer1_h2_convolution_with_the_weights_in_registers(lib, shape):
+    """halo_h2.h (round 6): ragged tiles, several tiles per workgroup (the emulated chip has 4 CUs), statistics"""
+    checks.check_conv_halo_h2(lib, DEV, *shape)

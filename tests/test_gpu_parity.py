@@ -72,6 +72,16 @@ def test_conv_halo_pp(lib, mode, wgs):
         checks.check_conv_halo(lib, DEV, B, H, W, Cout=64, dgrad=True, mode=mode, seed=H * 100 + W + 1, pp_wgs=wgs)
 
 
+def test_layer1_h2_convolution_with_the_weights_in_registers(lib):
+    """halo_h2.h (round 6; layer1's forward convolutions in the fp16x2 / fp16x2m modes): one persistent 4-wave workgroup per CU keeps
+    the hi and lo halves of the weights in registers.  Layer1 geometry (rows of 86 pixels), ragged small shapes, and a size with 256
+    concurrent workgroups repeated as a race screen of its double-buffered halo DMA"""
+    for (B, H, W) in ((2, 64, 86), (3, 9, 11), (1, 33, 70)):
+        checks.check_conv_halo_h2(lib, DEV, B, H, W, seed=H * 100 + W)
+    for rep in range(4):
+        checks.check_conv_halo_h2(lib, DEV, 24, 64, 86, seed=600 + rep)
+
+
 def test_conv_halo_pp_race_screen(lib):
     """the same kernel at a size with hundreds of concurrent persistent workgroups, repeated: its DMA / two-group hand-over has
     no other detector on the hardware (the emulator runs workgroups one at a time)"""

@@ -45,9 +45,10 @@ inline bool conv_halo_h2_applies(const GatherGeom& g, const Epilogue& ep) {
 
 // ABL (timing experiments only, ablation build, results are wrong): bit 0 = halo DMA only for the first tile, bit 1 = no fragment
 // reads, bit 2 = no stores, bit 3 = no MFMAs, bit 4 = no per-tile barrier.
-// PD: K sub-steps a B fragment is requested ahead of its MFMAs.  SG: 0 = a step's reads and its MFMAs as two fenced blocks, 1 = the
-// scheduler is asked to interleave them (sched_group_barrier).
-template <bool STATS, int ABL = 0, int PD = 1, int SG = 0>
+// PD: K sub-steps a B fragment is requested ahead of its MFMAs.  SG: 0 = a step's reads and its MFMAs as two fenced blocks (first
+// version), 1 = the scheduler is asked to interleave them (sched_group_barrier: it moves every read right in front of its use),
+// 2 = interleaved by hand: one read (or one DMA of the next halo) behind each MFMA.
+template <bool STATS, int ABL = 0, int PD = 1, int SG = 2>
 static __global__ void __launch_bounds__(256, 1) conv_halo_h2_kernel(GatherGeom g, const half* __restrict__ A,
                                                                      const half* __restrict__ Bw, Epilogue ep, int tiles_x,
                                                                      int tiles_y, int ntiles) {
@@ -93,22 +94,24 @@ static __global__ void __launch_bounds__(256, 1) conv_halo_h2_kernel(GatherGeom 
   // halo of a tile -> buffer `buf`: LDS slot sidx = pass * 256 + t (a DMA writes lane l of a wave to 16 * l behind the wave's base)
   // holds piece (slot ^ (halo column & 15)) of halo pixel sidx >> 4.  (The slot geometry is recomputed per tile -- a dozen VALU
   // operations per DMA, ~150 per tile beside 216 MFMAs -- rather than held: the weights leave no registers to spare.)
+  // (one pass = one wave-wide DMA instruction per wave; SG = 2 issues the passes of the next tile's halo between the MFMAs of this one)
+  int nb = 0, ny0 = 0, nx0 = 0;  // coordinates of the tile whose halo is being requested
+  auto halo_pass = [&](int i, int buf) __attribute__((always_inline)) {
+    if (i * 256 + wave * 64 >= kH2Pieces) return;  // wave-uniform: the last pass has 64 slots
+    const int oy = ny0 - 1, ox = nx0 - 1;
+    const int base = ((nb * gHi + oy) * gWi + ox) * 256;  // (may be negative for the first row / column: only added where valid)
+    const int sidx = i * 256 + t;
+    const int hp = sidx >> 4, slot = sidx & 15;
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int iy = oy + hy, ix = ox + hx;
+    const bool ok = (unsigned)iy < (unsigned)gHi && (unsigned)ix < (unsigned)gWi;
+    const int rel = (hy * gWi + hx) * 256 + ((slot ^ (hx & 15)) << 4);
+    dma16(rsrc_a, ok ? (unsigned)(base + rel) : ~0u, 0u, &smem[buf * kH2Pieces + i * 256 + wave * 64]);
+  };
   auto issue_halo = [&](int tile, int buf) __attribute__((always_inline)) {
-    int b, y0, x0;
-    tile_coords(tile, b, y0, x0);
-    const int oy = y0 - 1, ox = x0 - 1;
-    const int base = ((b * gHi + oy) * gWi + ox) * 256;  // (may be negative for the first row / column: only added where valid)
+    tile_coords(tile, nb, ny0, nx0);
 #pragma unroll
-    for (int i = 0; i < kH2Passes; ++i) {
-      if (i * 256 + wave * 64 >= kH2Pieces) continue;  // wave-uniform: the last pass has 64 slots
-      const int sidx = i * 256 + t;
-      const int hp = sidx >> 4, slot = sidx & 15;
-      const int hy = hp / HW, hx = hp - hy * HW;
-      const int iy = oy + hy, ix = ox + hx;
-      const bool ok = (unsigned)iy < (unsigned)gHi && (unsigned)ix < (unsigned)gWi;
-      const int rel = (hy * gWi + hx) * 256 + ((slot ^ (hx & 15)) << 4);
-      dma16(rsrc_a, ok ? (unsigned)(base + rel) : ~0u, 0u, &smem[buf * kH2Pieces + i * 256 + wave * 64]);
-    }
+    for (int i = 0; i < kH2Passes; ++i) halo_pass(i, buf);
   };
 
   floatx16 acc[2];
@@ -127,7 +130,7 @@ static __global__ void __launch_bounds__(256, 1) conv_halo_h2_kernel(GatherGeom 
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) xk[dx] = (unsigned)((kh ^ ((col + dx) & 15)) << 4);
 
-  auto compute = [&](int buf) __attribute__((always_inline)) {
+  auto compute = [&](int buf, bool next) __attribute__((always_inline)) {
     const char* hb = reinterpret_cast<const char*>(&smem[buf * kH2Pieces]);
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb)
@@ -144,18 +147,23 @@ static __global__ void __launch_bounds__(256, 1) conv_halo_h2_kernel(GatherGeom 
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) fh[k][bb].p = fl[k][bb].p = zero_piece();
     }
-    auto load_frags = [&](int j) __attribute__((always_inline)) {
+    // fragment k of step j: 0 = hi of block 0, 1 = lo of block 0, 2 = hi of block 1, 3 = lo of block 1
+    auto load_frag = [&](int j, int k) __attribute__((always_inline)) {
       if constexpr ((ABL & 2) != 0) return;
       const int dy = j % 3, grp = j / 3;
       const int s = grp & 1, gg = (grp >> 1) & 1, dx = grp >> 2;
       const unsigned qc = (unsigned)((gg * 8 + 2 * s) << 4);  // even slot of the hi piece; the lo piece is 4 slots further
+      const int bb = k >> 1;
+      const char* pp = hb + (pbase[bb] + (unsigned)(dx * 256) + ((qc + ((k & 1) ? 64u : 0u)) ^ xk[dx]));
+      const piece_t v = *reinterpret_cast<const piece_t*>(pp + dy * HW * 256);
+      if (k & 1)
+        fl[j % (PD + 1)][bb].p = v;
+      else
+        fh[j % (PD + 1)][bb].p = v;
+    };
+    auto load_frags = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const char* ph_ = hb + (pbase[bb] + (unsigned)(dx * 256) + (qc ^ xk[dx]));
-        const char* pl_ = hb + (pbase[bb] + (unsigned)(dx * 256) + ((qc + 64u) ^ xk[dx]));
-        fh[j % (PD + 1)][bb].p = *reinterpret_cast<const piece_t*>(ph_ + dy * HW * 256);
-        fl[j % (PD + 1)][bb].p = *reinterpret_cast<const piece_t*>(pl_ + dy * HW * 256);
-      }
+      for (int k = 0; k < 4; ++k) load_frag(j, k);
     };
 #pragma unroll
     for (int j = 0; j < PD; ++j) load_frags(j);
@@ -163,26 +171,55 @@ static __global__ void __launch_bounds__(256, 1) conv_halo_h2_kernel(GatherGeom 
     for (int j = 0; j < NS; ++j) {
       const int dy = j % 3, grp = j / 3;
       const int i = (dy * 3 + (grp >> 2)) * 4 + (grp & 3);  // weight piece: tap * 4 + g * 2 + s
+      const int sl = j % (PD + 1);
+      if constexpr (SG == 2 && (ABL & 8) == 0) {
+        // ONE wave per SIMD: whatever is not an MFMA must issue in the shadow of one (a 32-cycle MFMA hides about five single-issue
+        // instructions, MI355X_MICROARCH.md).  The first version issued a step's four fragment reads as a block between two blocks of
+        // six MFMAs: the matrix pipe drained behind every block (SQ counters: MFMA busy 0.49, the wave ACTIVE a third of its cycles).
+        // Here every MFMA is followed by at most one fragment read of step j + PD and, every third step, one DMA of the next halo.
+        const bool more = j + PD < NS;
+        mma_piece<half>(wlo[i], fh[sl][0], acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_frag(j + PD, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_piece<half>(wlo[i], fh[sl][1], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_frag(j + PD, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_piece<half>(wh[i], fl[sl][0], acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_frag(j + PD, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_piece<half>(wh[i], fl[sl][1], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_frag(j + PD, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_piece<half>(wh[i], fh[sl][0], acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((ABL & 1) == 0 && next && j % 3 == 0) halo_pass(j / 3, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_piece<half>(wh[i], fh[sl][1], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       if (j + PD < NS) load_frags(j + PD);
       if constexpr (SG == 0) __builtin_amdgcn_sched_barrier(0);
       // weights = A operand (rows), pixels = B (columns): lo*hi + hi*lo + hi*hi; the two pixel blocks alternate so that no MFMA
       // waits for the accumulator of the one before it
       if constexpr ((ABL & 8) == 0) {
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) mma_piece<half>(wlo[i], fh[j % (PD + 1)][bb], acc[bb]);
+        for (int bb = 0; bb < 2; ++bb) mma_piece<half>(wlo[i], fh[sl][bb], acc[bb]);
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) mma_piece<half>(wh[i], fl[j % (PD + 1)][bb], acc[bb]);
+        for (int bb = 0; bb < 2; ++bb) mma_piece<half>(wh[i], fl[sl][bb], acc[bb]);
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) mma_piece<half>(wh[i], fh[j % (PD + 1)][bb], acc[bb]);
+        for (int bb = 0; bb < 2; ++bb) mma_piece<half>(wh[i], fh[sl][bb], acc[bb]);
       } else {
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) asm volatile("" ::"v"(fh[j % (PD + 1)][bb].p), "v"(fl[j % (PD + 1)][bb].p), "v"(wh[i].p), "v"(wlo[i].p));
+        for (int bb = 0; bb < 2; ++bb) asm volatile("" ::"v"(fh[sl][bb].p), "v"(fl[sl][bb].p), "v"(wh[i].p), "v"(wlo[i].p));
       }
-      if constexpr (SG == 0) {
+      if constexpr (SG != 1) {
         __builtin_amdgcn_sched_barrier(0);
       } else {
-        // one wave per SIMD: whatever is not an MFMA has to issue in the shadow of one (<= 5 single-issue instructions per 32-cycle
-        // MFMA, MI355X_MICROARCH.md): ask the scheduler for MFMA / LDS read / VALU rounds instead of a block of each
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
@@ -229,12 +266,19 @@ static __global__ void __launch_bounds__(256, 1) conv_halo_h2_kernel(GatherGeom 
   __builtin_amdgcn_s_barrier();  // the first halo is visible to every wave
   for (int p = 0; p < nitems; ++p) {
     const int buf = p & 1;
-    if ((ABL & 1) == 0 && p + 1 < nitems) issue_halo(wl + (p + 1) * G, buf ^ 1);  // in flight under this tile's MFMAs
-    compute(buf);
+    const bool next = p + 1 < nitems;
+    if (next) tile_coords(wl + (p + 1) * G, nb, ny0, nx0);
+    if constexpr (SG != 2 || (ABL & 8) != 0) {
+      if ((ABL & 1) == 0 && next) issue_halo(wl + (p + 1) * G, buf ^ 1);  // in flight under this tile's MFMAs
+    }
+    compute(buf, next);
+    // this wave's share of the next halo has landed -- waited for BEFORE this tile's stores are issued, so that the stores stay in
+    // flight across the barrier instead of being waited for (the first version waited for both: 47 us of a 300 us launch)
+    wait_vmcnt<0>();
     store(wl + p * G);
-    wait_vmcnt<0>();               // this wave's share of the next halo has landed (and its stores have left)
     if constexpr ((ABL & 16) == 0) __builtin_amdgcn_s_barrier();  // every wave is done reading `buf`; every wave's share of the next halo is visible
   }
+  wait_vmcnt<0>();
 
   if constexpr (STATS) {
     if (ep.stats_accum) {
@@ -280,15 +324,12 @@ inline void launch_conv_halo_h2(const GatherGeom& g, const half* A, const half* 
   const dim3 grid(conv_halo_h2_grid(g));
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_HALO_H2_ABLATE") ? atoi(getenv("MN_HALO_H2_ABLATE")) : 0;
-#define H2_CASE(V_) case V_: hipLaunchKernelGGL((conv_halo_h2_kernel<true, V_>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return
+#define H2_CASE(V_) case V_: hipLaunchKernelGGL((conv_halo_h2_kernel<true, V_, 1, 2>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return
   switch (abl) {
     H2_CASE(1); H2_CASE(2); H2_CASE(4); H2_CASE(8); H2_CASE(16); H2_CASE(5); H2_CASE(7); H2_CASE(10); H2_CASE(23); H2_CASE(31);
-    case 100: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 2>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;  // not ablations:
-    case 101: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 3>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;  // read-ahead depth
-    case 105: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 5, 2>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;
-    case 110: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 1, 1>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;
-    case 111: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 2, 1>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;
-    case 115: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 5, 1, 1>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;
+    case 100: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 2, 2>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;  // not ablations:
+    case 110: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 1, 0>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;  // read-ahead, SG
+    case 111: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 1, 1>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;
     default: break;
   }
 #undef H2_CASE

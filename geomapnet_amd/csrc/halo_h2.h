@@ -312,6 +312,13 @@ static __global__ void __launch_bounds__(256, 1) conv_halo_h2_kernel(GatherGeom 
   }
 }
 
+// (Measured and removed, round 6: an 8-wave form -- the reduction split over two waves per SIMD, (32 outputs) x (pixel half) x (input
+// group), 144 weight registers per wave, partial sums exchanged through 2 x 32 KB of LDS, one barrier per tile -- on the theory that
+// with two waves per SIMD one wave's reads sit beside the other's MFMAs: 293-299 us per launch against this kernel's 261, whole step
+// 18.94 against 18.55 ms (profiles/r06/c12_*).  The ablations of both forms say the same thing: MFMAs alone ~100 us; fragment reads
+// +100, halo DMA +30-60, stores +40, and they ADD in either form although the LDS array is busy a sixth of the time and conflict-free
+// (SQ_LDS_BANK_CONFLICT = 0, SQ_LDS_IDX_ACTIVE 4.15 cycles per read): what a memory instruction costs here is its ISSUE, ~40 cycles
+// of a CU's wave time per ds_read_b128, and a second wave per SIMD does not hide it.)
 // persistent workgroups: one per CU (MN_HALO_H2_WGS overrides), at most one per tile
 inline int conv_halo_h2_grid(const GatherGeom& g) {
   const int ntiles = g.B * cdiv(g.P, kH2TH) * cdiv(g.Q, kH2TW);
@@ -324,6 +331,7 @@ inline void launch_conv_halo_h2(const GatherGeom& g, const half* A, const half* 
   const dim3 grid(conv_halo_h2_grid(g));
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_HALO_H2_ABLATE") ? atoi(getenv("MN_HALO_H2_ABLATE")) : 0;
+  {
 #define H2_CASE(V_) case V_: hipLaunchKernelGGL((conv_halo_h2_kernel<true, V_, 1, 2>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return
   switch (abl) {
     H2_CASE(1); H2_CASE(2); H2_CASE(4); H2_CASE(8); H2_CASE(16); H2_CASE(5); H2_CASE(7); H2_CASE(10); H2_CASE(23); H2_CASE(31);
@@ -331,6 +339,7 @@ inline void launch_conv_halo_h2(const GatherGeom& g, const half* A, const half* 
     case 110: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 1, 0>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;  // read-ahead, SG
     case 111: hipLaunchKernelGGL((conv_halo_h2_kernel<true, 0, 1, 1>), grid, dim3(256), 0, stream, g, A, Bw, ep, tx, ty, ntiles); return;
     default: break;
+  }
   }
 #undef H2_CASE
 #endif

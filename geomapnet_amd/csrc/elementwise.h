@@ -15,8 +15,9 @@ inline int ew_grid(long work_items) {
   // grid-stride kernels: at most 16 workgroups per CU.  (Measured and removed, same-box A/Bs of the whole step in
   // profiles/r02/c25_*: fewer workgroups per CU -- to leave wave slots to the weight gradients running beside the
   // HBM-bound passes -- and several pieces per thread for the small tensors of layers 3-4: no gain.)
+  static const long cap = getenv("MN_EW_WGS") ? atol(getenv("MN_EW_WGS")) : 256L * 16;  // (A/B knob)
   long b = (work_items + 255) / 256;
-  if (b > 256L * 16) b = 256L * 16;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }

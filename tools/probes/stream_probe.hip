@@ -1,6 +1,6 @@
 // Hardware probe: what the HBM path sustains for the access patterns of the BatchNorm passes, as a function of the
-// launch shape.  The BatchNorm kernels of the step run at ~3 TB/s of ALGORITHMIC bytes (profiles/r06/c13_serial_by_grid_*);
-// this measures the ceiling of the same patterns with nothing else in the kernel:
+// launch shape.  (profiles/r06/c15_to_c20_*: the library's BatchNorm passes run at 0.9-1.0 of these figures.)
+// The ceiling of each pattern with nothing else in the kernel:
 //   read   : sum of two fp16 streams (the backward reduce), blocked per workgroup or grid-strided, U pieces in flight per stream
 //   apply  : 2 B + 2 B in, 2 B out (the backward apply)
 //   fwd    : 4 B (+ 4 B residual, h2 layout) in, 4 B h2 + 2 B record out (the forward apply); y read as two adjacent pieces per
@@ -179,7 +179,7 @@ static double time_us(F&& launch, int reps) {
 }
 
 int main(int argc, char** argv) {
-  const long elems = argc > 1 ? atol(argv[1]) : 192L * 56 * 56 * 64;  // layer1: 38.5 M elements
+  const long elems = argc > 1 ? atol(argv[1]) : 192L * 64 * 86 * 64;  // layer1 of BASELINE configs[2] (256 x 341 images): 67.6 M elements
   constexpr int NBUF = 6;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));

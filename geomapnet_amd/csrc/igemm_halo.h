@@ -520,8 +520,10 @@ inline int launch_igemm_halo(const GatherGeom& g, const half* A, const half* Bw,
 #ifdef MN_ABLATION_BUILD
   static const int abl = getenv("MN_HALO_ABLATE") ? atoi(getenv("MN_HALO_ABLATE")) : 0;
 #endif
-  static const int a1 = getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1;
-  if (level >= 1 && tile288_wanted && igemm_halo_applies(g, ep, 256, 352)) {
+  // (MN_HALO_A1_F16: the same switch for the plain-fp16 launches alone -- in the fp16x2m mode those are the data gradients, whose
+  //  70 KB form leaves room for a weight-gradient workgroup of the side stream on the same CU: A/B knob)
+  static const int a1 = getenv("MN_HALO_A1_F16") ? atoi(getenv("MN_HALO_A1_F16")) : (getenv("MN_HALO_A1") ? atoi(getenv("MN_HALO_A1")) : 1);
+  if (level >= 1 && tile288_wanted && a1 != 2 && igemm_halo_applies(g, ep, 256, 352)) {
 #ifdef MN_ABLATION_BUILD
 #define MN_HALO_ABL(BN_, AH_, V_)                                                                                          \
   if (abl == V_) {                                                                                                         \

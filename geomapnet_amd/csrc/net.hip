@@ -993,6 +993,10 @@ struct Plan : PlanBase {
   // (profiles/r04/c43_*): fp16 2 = 13.14 ms, 1 = 13.01, 0 = 12.98; fp16x2 2 = 28.60, 1 = 28.02, 0 = 28.38.  Defaults since:
   // fp16 0, fp16x2 1 (set in the constructor), fp32 / fp32x3 2 (not re-measured).
   int wgrad_sched = getenv("MN_WGRAD_SCHED") ? atoi(getenv("MN_WGRAD_SCHED")) : (early_fork ? 2 : 0);
+  // (block_backward.  Same-box A/Bs, arms interleaved, profiles/r06/c29_to_c32_*: fp16x2m 0 -> 1: -0.04 ... -0.10 ms in six of six pairs
+  //  (18.37 -> 18.31), 2: equal, 3: +0.06; fp16 12.78 -> 12.73.  3 with the stem's weight gradient at ONE workgroup per CU
+  //  (MN_STEM_WGRAD_PER_CU=1, which alone costs +0.35 ms) is within 0.03 ms of 1.)
+  int wgrad_tail = getenv("MN_WGRAD_TAIL") ? atoi(getenv("MN_WGRAD_TAIL")) : 1;
   struct PendingWgrad {
     Unit* u;
     const T* x;
@@ -1038,11 +1042,21 @@ struct Plan : PlanBase {
     }
     bn_bwd(blk.u2, blk.gout, og, s);
     if (!stage_error.empty()) return;  // (round-5 ADVICE: do not run data / weight gradients on a d(conv output) that was never written)
-    const bool early = wgrad_sched == 1;
+    // MN_WGRAD_TAIL = k: the weight gradients of the first k blocks of layer1 (the LAST k of the backward pass) are held back and
+    // forked in front of the stem's backward kernels (backward_stage: flush_wgrads), which run alone on the step stream at the end of
+    // the step and are VALU-bound -- the matrix pipe is idle under them.  Same stage, same gradient bucket.
+    const bool tail = blk.stage == 0 && !blk.down && (int)(&blk - &blocks[0]) < wgrad_tail;
+    const bool early = wgrad_sched == 1 && !tail;
     if (early) conv_wgrad(blk.u2, ba1, fork_wgrad(s));
     conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
     bn_bwd(blk.u1, blk.ga1, ba1, s, true);
     if (blk.down) bn_bwd(blk.ud, blk.gout, og, s);
+    if (tail) {
+      pending_wgrads.push_back({&blk.u2, ba1});
+      pending_wgrads.push_back({&blk.u1, bx});
+      conv_dgrad(blk.u1, blk.gx, blk.gout, og, s, below);
+      return;
+    }
     hipStream_t ws = fork_wgrad(s);
     if (!early) conv_wgrad(blk.u2, ba1, ws);
     conv_wgrad(blk.u1, bx, ws);

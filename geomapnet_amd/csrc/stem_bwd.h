@@ -419,7 +419,8 @@ inline void launch_stem_bn_reduce(StemBwdArgs a, int B, int H, int W, int Wp, hi
 }
 inline void launch_stem_wgrad(StemBwdArgs a, int B, int H, int W, int Wp, hipStream_t stream) {
   stem_bwd_geometry(a, B, H, W, Wp);
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(stem_bwd_grid(a, 2)), dim3(256), 0, stream, a);
+  static const int per_cu = getenv("MN_STEM_WGRAD_PER_CU") ? atoi(getenv("MN_STEM_WGRAD_PER_CU")) : 2;  // (A/B knob)
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(stem_bwd_grid(a, per_cu)), dim3(256), 0, stream, a);
 }
 
 }  // namespace mn

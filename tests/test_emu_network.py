@@ -38,6 +38,14 @@ def test_mapnet_train_step_fp16x2m_parity(lib):
     assert rep[0][2] < 1e-3
 
 
+def test_mapnet_train_step_fp16x2m_with_every_layer1_weight_gradient_deferred_to_the_stem(lib, monkeypatch):
+    """MN_WGRAD_TAIL=3 (default 1): all of layer1's weight gradients are queued and launched in front of the stem's backward kernels
+    (net.hip block_backward / backward_stage); the same gradients as under the default order"""
+    monkeypatch.setenv("MN_WGRAD_TAIL", "3")
+    rep = checks.check_train_step(lib, DEV, "fp16x2m", mode="mapnet", N=2, H=64, W=85, steps=1)
+    assert rep[0][2] < 1e-3
+
+
 def test_mapnet_train_step_fp16x2q_fp8_cross_terms(lib):
     """fp16x2q (experimental): fp16x2m with both cross terms of every forward product from fp8 copies on the block-scaled MFMA.  The
     poses stay inside the north-star bar (1e-3; the approximation costs ~5e-4 at this small shape, ~4e-4 at the benchmark shape,

@@ -192,6 +192,19 @@ def test_mapnet_train_step_under_every_weight_gradient_schedule(lib, monkeypatch
         checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=64, W=85, steps=2, **checks.fp16_small_gates(2, 64, 85))
 
 
+@pytest.mark.parametrize("tail", ["0", "3"])
+@pytest.mark.parametrize("dtype", ["fp16x2m", "fp16"])
+def test_mapnet_train_step_with_layer1_weight_gradients_beside_the_stem_backward(lib, monkeypatch, dtype, tail):
+    """MN_WGRAD_TAIL (read per plan; default 1, what every other test runs): the weight gradients of the first k blocks of layer1 are
+    forked in front of the stem's backward launches instead of beside their own block's data gradients.  Only the order of launches on
+    the side stream changes: gradients and the updated parameters must stay on the oracle's under k = 0 (round 5's order) and k = 3."""
+    monkeypatch.setenv("MN_WGRAD_TAIL", tail)
+    if dtype == "fp16x2m":
+        checks.check_train_step(lib, DEV, dtype, mode="mapnet", N=2, H=64, W=85, steps=2, loss_rtol=1e-4, pose_atol=2e-3)
+    else:
+        checks.check_train_step(lib, DEV, "fp16", mode="mapnet", N=2, H=64, W=85, steps=2, **checks.fp16_small_gates(2, 64, 85))
+
+
 def test_mapnet_train_step_fp32_parity_full_resolution(lib):
     """(N=2, T=3, 3, 256, 341): north-star tolerances 1e-4 on loss (relative, |loss| > 1) and 1e-3 on pose"""
     checks.check_train_step(lib, DEV, "fp32", mode="mapnet", N=2, H=256, W=341, steps=1, loss_rtol=1e-4, pose_atol=1e-3,

@@ -558,6 +558,7 @@ struct Plan : PlanBase {
     // (fp16x2m: 0 / 1 / 2 measured equal in round 5; with round 6's shorter BatchNorm-backward passes 1 leads by 0.3 %: 18.96 / 19.02 /
     //  19.15 ms for 1 / 0 / 2, two interleaved repeats, profiles/r06/c6_*)
     if (!getenv("MN_WGRAD_SCHED") && early_fork) wgrad_sched = (mixed || h2) ? 1 : (DT == MN_F16 ? 0 : 2);  // (see wgrad_sched)
+    if (!getenv("MN_WGRAD_EARLY_STAGES") && mixed) wgrad_early_stages = 13;  // (see wgrad_early_stages)
     L = Layout(c.feat_dim);
     frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
     B = c.windows * frames;
@@ -997,6 +998,10 @@ struct Plan : PlanBase {
   //  (18.37 -> 18.31), 2: equal, 3: +0.06; fp16 12.78 -> 12.73.  3 with the stem's weight gradient at ONE workgroup per CU
   //  (MN_STEM_WGRAD_PER_CU=1, which alone costs +0.35 ms) is within 0.03 ms of 1.)
   int wgrad_tail = getenv("MN_WGRAD_TAIL") ? atoi(getenv("MN_WGRAD_TAIL")) : 1;
+  // MN_WGRAD_EARLY_STAGES: bit k = schedule 1's early fork applies to stage k (else one fork per block, schedule 0's order).  fp16x2m
+  // (set in the constructor): 13 = every stage but layer2, whose data gradients run in the 70 KB two-workgroup form and share their
+  // CUs with whatever the side stream brings -- 18.61 -> 18.55 ms, six of six interleaved pairs (profiles/r06/c35_to_c37_*).
+  int wgrad_early_stages = getenv("MN_WGRAD_EARLY_STAGES") ? atoi(getenv("MN_WGRAD_EARLY_STAGES")) : 15;
   struct PendingWgrad {
     Unit* u;
     const T* x;
@@ -1046,7 +1051,7 @@ struct Plan : PlanBase {
     // forked in front of the stem's backward kernels (backward_stage: flush_wgrads), which run alone on the step stream at the end of
     // the step and are VALU-bound -- the matrix pipe is idle under them.  Same stage, same gradient bucket.
     const bool tail = blk.stage == 0 && !blk.down && (int)(&blk - &blocks[0]) < wgrad_tail;
-    const bool early = wgrad_sched == 1 && !tail;
+    const bool early = wgrad_sched == 1 && !tail && ((wgrad_early_stages >> blk.stage) & 1);
     if (early) conv_wgrad(blk.u2, ba1, fork_wgrad(s));
     conv_dgrad(blk.u2, blk.ga1, nullptr, nullptr, s);
     bn_bwd(blk.u1, blk.ga1, ba1, s, true);

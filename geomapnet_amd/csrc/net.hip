@@ -559,6 +559,7 @@ struct Plan : PlanBase {
     //  19.15 ms for 1 / 0 / 2, two interleaved repeats, profiles/r06/c6_*)
     if (!getenv("MN_WGRAD_SCHED") && early_fork) wgrad_sched = (mixed || h2) ? 1 : (DT == MN_F16 ? 0 : 2);  // (see wgrad_sched)
     if (!getenv("MN_WGRAD_EARLY_STAGES") && mixed) wgrad_early_stages = 13;  // (see wgrad_early_stages)
+    if (!getenv("MN_WGRAD_DEFER_STAGES") && mixed) wgrad_defer_stages = 2;   // (see wgrad_defer_stages)
     L = Layout(c.feat_dim);
     frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
     B = c.windows * frames;
@@ -1002,6 +1003,10 @@ struct Plan : PlanBase {
   // (set in the constructor): 13 = every stage but layer2, whose data gradients run in the 70 KB two-workgroup form and share their
   // CUs with whatever the side stream brings -- 18.61 -> 18.55 ms, six of six interleaved pairs (profiles/r06/c35_to_c37_*).
   int wgrad_early_stages = getenv("MN_WGRAD_EARLY_STAGES") ? atoi(getenv("MN_WGRAD_EARLY_STAGES")) : 15;
+  // MN_WGRAD_DEFER_STAGES: bit k = stage k takes schedule 2's order (a weight gradient queued and forked right before the NEXT
+  // BatchNorm-backward pass) whatever the plan's schedule is.  fp16x2m (set in the constructor): 2 = layer2 -- against one fork per
+  // block there: 18.25 -> 18.20 ms, six of six interleaved pairs; layer4 +0.17, layer3 +0.05, layer1 +0.05 (profiles/r06/c38_to_c40_*).
+  int wgrad_defer_stages = getenv("MN_WGRAD_DEFER_STAGES") ? atoi(getenv("MN_WGRAD_DEFER_STAGES")) : 0;
   struct PendingWgrad {
     Unit* u;
     const T* x;
@@ -1026,7 +1031,7 @@ struct Plan : PlanBase {
     // (fp16x2m with the fp16 stem kernels: the gradient of the pooled stem activation leaves layer1.0 gated by that activation)
     const T* below = &blk == &blocks.front() ? (stem_bwd_f16() ? bx : nullptr) : bx;
     const T* og = nullptr;  // (bn2 / the projection / the identity path take `gout` as stored: already gated)
-    if (wgrad_sched == 2) {
+    if (wgrad_sched == 2 || ((wgrad_defer_stages >> blk.stage) & 1)) {
       flush_wgrads(s);
       bn_bwd(blk.u2, blk.gout, og, s);
       if (!stage_error.empty()) return;

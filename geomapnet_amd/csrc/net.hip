@@ -171,8 +171,11 @@ struct PlanBase {
     hipEventRecord(e, s);
     hipStreamWaitEvent(wstream, e, 0);
     wgrad_pending = true;
+    if (head_wgrads_deferred) launch_head_wgrads(wstream);  // (head_backward: the first fork of the backward pass takes them along)
     return wstream;
   }
+  bool head_wgrads_deferred = false;
+  virtual void launch_head_wgrads(hipStream_t st) = 0;
   void join_wgrad(hipStream_t s) {
     if (!wgrad_pending) return;
     hipEvent_t e = next_fork_event();
@@ -1093,6 +1096,19 @@ struct Plan : PlanBase {
       conv_dgrad(blk.u1, blk.gx, blk.gout, og, s, below);  // + identity path (already gated)
     }
   }
+  void launch_head_wgrads(hipStream_t st) override {
+    const int F = cfg.feat_dim;
+    const float unscale = 1.f / cur_scale;
+    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(cdiv(F + 1, 64)), dim3(256), 0, st, (const float*)dposes,
+                       (const float*)feat, grads + L.xyz_w, grads + L.xyz_b, grads + L.wpqr_w, grads + L.wpqr_b, B, F,
+                       unscale, cfg.filter_nans);
+    // fc backward: weight + bias gradient in one launch of 32 x 32 tiles (dense.h)
+    DenseWgradArgs dw;
+    dw.dY = dz; dw.X = pooled; dw.dW = grads + L.fc_w; dw.db = grads + L.fc_b; dw.B = B; dw.F = F; dw.Cin = 512; dw.ldy = F;
+    dw.ldx = 512; dw.ldw = 512; dw.alpha = unscale;
+    launch_dense_wgrad(dw, st);
+    head_wgrads_deferred = false;
+  }
   void head_backward(hipStream_t s) {
     int F = cfg.feat_dim;
     float unscale = 1.f / cur_scale;
@@ -1103,14 +1119,13 @@ struct Plan : PlanBase {
     hipLaunchKernelGGL(head_bwd_input_kernel, dim3(cdiv((long)B * F, 256)), dim3(256), 0, s, (const float*)dposes,
                        (const float*)feat, (const float*)(params + L.xyz_w), (const float*)(params + L.wpqr_w), dz, B, F,
                        cfg.filter_nans, drop_this_step ? (const float*)dropmask : (const float*)nullptr);
-    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(cdiv(F + 1, 64)), dim3(256), 0, s, (const float*)dposes,
-                       (const float*)feat, grads + L.xyz_w, grads + L.xyz_b, grads + L.wpqr_w, grads + L.wpqr_b, B, F,
-                       unscale, cfg.filter_nans);
-    // fc backward: weight + bias gradient in one launch of 32 x 32 tiles (dense.h), data gradient against the transposed copy
-    DenseWgradArgs dw;
-    dw.dY = dz; dw.X = pooled; dw.dW = grads + L.fc_w; dw.db = grads + L.fc_b; dw.B = B; dw.F = F; dw.Cin = 512; dw.ldy = F;
-    dw.ldx = 512; dw.ldw = 512; dw.alpha = unscale;
-    launch_dense_wgrad(dw, s);
+    // The head's and the fc layer's WEIGHT gradients feed nothing downstream: with two streams they leave with the first fork of the
+    // backward pass (fork_wgrad), off the chain criterion -> heads -> fc -> average pool -> layer4 (MN_HEAD_WGRAD_SIDE=0: in line)
+    static const bool head_side = !(getenv("MN_HEAD_WGRAD_SIDE") && atoi(getenv("MN_HEAD_WGRAD_SIDE")) == 0);
+    if (head_side && overlap_wgrad && s != nullptr && !timer.enabled)
+      head_wgrads_deferred = true;
+    else
+      launch_head_wgrads(s);
     GatherGeom g;
     g.B = B; g.Hi = 1; g.Wi = 1; g.C = 512; g.P = 1; g.Q = 1; g.R = 1; g.S = 1; g.mul_p = 1; g.mul_q = 1; g.rsign = 1;
     g.ssign = 1; g.off_h = 0; g.off_w = 0; g.div = 1; g.M = B; g.N = F; g.K = 512;
@@ -1201,6 +1216,7 @@ struct Plan : PlanBase {
       stem_backward(s);
     }
     flush_wgrads(s);
+    if (head_wgrads_deferred) launch_head_wgrads(s);  // (no fork took them along)
     join_wgrad(s);  // the stage's gradient bucket is complete when this call's work on s is
     if (!stage_error.empty()) {  // a launch helper refused its arguments (bn_bwd): the stage is incomplete
       const std::string e = stage_error;

@@ -560,9 +560,12 @@ struct Plan : PlanBase {
     overflow_guard = (DT == MN_F16 || h2) && !(getenv("MN_OVERFLOW_GUARD") && atoi(getenv("MN_OVERFLOW_GUARD")) == 0);
     // (fp16x2m: 0 / 1 / 2 measured equal in round 5; with round 6's shorter BatchNorm-backward passes 1 leads by 0.3 %: 18.96 / 19.02 /
     //  19.15 ms for 1 / 0 / 2, two interleaved repeats, profiles/r06/c6_*)
-    if (!getenv("MN_WGRAD_SCHED") && early_fork) wgrad_sched = (mixed || h2) ? 1 : (DT == MN_F16 ? 0 : 2);  // (see wgrad_sched)
-    if (!getenv("MN_WGRAD_EARLY_STAGES") && mixed) wgrad_early_stages = 13;  // (see wgrad_early_stages)
-    if (!getenv("MN_WGRAD_DEFER_STAGES") && mixed) wgrad_defer_stages = 2;   // (see wgrad_defer_stages)
+    // (fp16: one fork per block since round 4; round 6, with the per-stage choices below: 13.10 -> 13.00 ms, four of four interleaved
+    //  pairs, profiles/r06/c52_to_c54_*)
+    if (!getenv("MN_WGRAD_SCHED") && early_fork) wgrad_sched = (mixed || h2 || DT == MN_F16) ? 1 : 2;  // (see wgrad_sched)
+    const bool staged_choice = mixed || (DT == MN_F16 && !h2);
+    if (!getenv("MN_WGRAD_EARLY_STAGES") && staged_choice) wgrad_early_stages = 13;  // (see wgrad_early_stages)
+    if (!getenv("MN_WGRAD_DEFER_STAGES") && staged_choice) wgrad_defer_stages = 2;   // (see wgrad_defer_stages)
     L = Layout(c.feat_dim);
     frames = (c.mode == MN_MODE_POSENET) ? 1 : (c.mode == MN_MODE_MAPNET ? c.T : 2 * c.T);
     B = c.windows * frames;
